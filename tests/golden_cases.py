@@ -1,0 +1,64 @@
+"""Golden-vector case definitions shared by ``oracle/gen_golden.py`` (runs in the build
+container against the real reference) and the parity tests (run anywhere, against the
+committed outputs in tests/golden/).  Python >= 3.8 syntax only (the generator runs under
+the conda python3.9 that has the reference's real third-party stack)."""
+
+# lengths cycled over the reads of a "mixed" case; "m" = preload size, ints are literal.
+# 1012 keeps exactly one pooled block valid (reads with NO valid pooled block crash the
+# reference's minibatch: reference adapted/detect/_c_llr.pyx:202-236 with an empty array).
+MIXED_LENS = ["m", "m+5000", 30000, "m", 8000, "m", 3000, 1500, "m", 1012, 600000, 5400, "m", 12345]
+
+CASES = {
+    # RNA004 preset, LLR primary, default window (m = 17500)
+    "rna004_llr_default": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=11,
+                               first=0, n=96, lens="mixed", minibatch=96, dump=[0, 1, 2, 6, 9]),
+    # the north-star shape: T = 200000, m = 201500
+    "rna004_llr_200k": dict(chem="RNA004", primary="llr", max_obs_trace=200000, seed=12,
+                            first=1000, n=10, lens="mixed200", minibatch=10, dump=[0]),
+    # config 1: RNA002 preset (LLR primary), short preload (T=4000 -> m=5500)
+    "rna002_llr_4k": dict(chem="RNA002", primary="llr", max_obs_trace=4000, seed=13,
+                          first=0, n=48, lens="full", minibatch=48, dump=[0, 1]),
+    # RNA002 preset as shipped (T=25000, m=26500, ds=20)
+    "rna002_llr_default": dict(chem="RNA002", primary="llr", max_obs_trace=None, seed=14,
+                               first=0, n=40, lens="mixed002", minibatch=40, dump=[0]),
+    # two minibatches in one call: normalisation is per minibatch (reference
+    # adapted/detect/normalize.py:15-22 called with the 2-D minibatch)
+    "rna004_llr_two_minibatches": dict(chem="RNA004", primary="llr", max_obs_trace=None,
+                                       seed=15, first=500, n=64, lens="mixed", minibatch=32,
+                                       dump=[]),
+    # start-peak primary (API only in the reference), mvs check off, med-shift on
+    "rna004_start_peak": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=16,
+                              first=0, n=64, lens="mixed", minibatch=64, dump=[],
+                              mvs_detect_check=False, detect_med_shift=True),
+    # same, all reads full length: no None row, so the pandas float-column quirk stays dormant
+    "rna004_start_peak_full": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=18,
+                                   first=0, n=64, lens="full", minibatch=64, dump=[],
+                                   mvs_detect_check=False, detect_med_shift=True),
+    # start-peak primary with the preset's mvs check left on: polya_end_topk is None -> TypeError
+    "rna004_start_peak_mvs": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=19,
+                                  first=0, n=16, lens="full", minibatch=16, dump=[]),
+    # CNN primary with the shipped weights (default window)
+    "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
+                               first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
+}
+
+
+def resolve_lens(spec, n, m):
+    out = []
+    if spec == "full":
+        return [m] * n
+    if spec == "mixed200":
+        pat = ["m", "m+5000", 150000, "m", 60000, "m", 9000, "m", 1012, "m"]
+    elif spec == "mixed002":  # RNA002: min_obs_adapter=2000, ds=20 -> need >= 2020 samples
+        pat = ["m", "m+5000", 30000, "m", 8000, 2025, 3000, "m", 2400, 12345]
+    else:
+        pat = MIXED_LENS
+    for k in range(n):
+        v = pat[k % len(pat)]
+        if v == "m":
+            out.append(m)
+        elif v == "m+5000":
+            out.append(m + 5000)
+        else:
+            out.append(int(v))
+    return out

@@ -1,0 +1,87 @@
+"""The CPU oracle against the golden vectors made by the REAL reference
+(oracle/gen_golden.py, run in the build container).  Bit-exact on every field."""
+import numpy as np
+import pytest
+
+from golden_cases import CASES
+from util import load_case, load_stages, row_diffs
+
+LLR_CASES = [k for k, c in CASES.items() if c["primary"] == "llr"]
+SP_CASES = [k for k, c in CASES.items() if c["primary"] == "start_peak"]
+
+
+def _run(oracle, case, spc, sig, lens):
+    rows = []
+    mb = case["minibatch"]
+    for s in range(0, case["n"], mb):
+        if case["primary"] == "llr":
+            rows += oracle.detect_llr(sig[s:s + mb], lens[s:s + mb], spc)
+        else:
+            rows += oracle.detect_start_peak(sig[s:s + mb], lens[s:s + mb], spc)
+    return rows
+
+
+@pytest.mark.parametrize("name", LLR_CASES + SP_CASES)
+def test_rows_bit_exact(oracle_mod, name):
+    case, spc, sig, lens, want = load_case(name)
+    got = _run(oracle_mod, case, spc, sig, lens)
+    assert len(got) == len(want)
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in row_diffs(g, w)]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("name", [k for k in LLR_CASES if CASES[k]["dump"]])
+def test_llr_stages_bit_exact(oracle_mod, name):
+    case, spc, sig, lens, _ = load_case(name)
+    st = load_stages(name)
+    mb = case["minibatch"]
+    rc, np4 = oracle_mod.norm_params(sig[:mb], spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    assert rc == 0
+    assert np4[0] == st["n1_med_mad"][0] and np4[1] == st["n1_med_mad"][1]
+    for k in st["dump_idx"]:
+        k = int(k)
+        o = oracle_mod.llr_stages(sig[k], spc, np4)
+        assert o["n_valid"] == int(st["n_valid"][k])
+        assert np.array_equal(o["down"], st["down_%d" % k])
+        assert np.array_equal(o["g1"], st["g1_%d" % k], equal_nan=True)
+        p1 = st["p1_%d" % k]
+        assert o["raw_first"] == (int(p1[0]) if len(p1) else -1)
+        cands = st["cands_%d" % k]
+        assert o["cand"] == (int(cands[0]) if len(cands) else -1)
+        if len(cands):
+            assert np.array_equal(o["g2"], st["g2_%d" % k], equal_nan=True)
+            assert o["polya_idx"] == int(st["p4_%d" % k][0])
+
+
+def test_start_peak_table(oracle_mod):
+    import json
+    import os
+
+    from util import GOLD
+
+    case, spc, sig, lens, _ = load_case("rna004_start_peak")
+    with open(os.path.join(GOLD, "rna004_start_peak.table.json")) as fh:
+        tab = json.load(fh)
+    got = oracle_mod.start_peak_table(sig, lens, spc)
+    for i in range(case["n"]):
+        if tab["start_peak_idx"][i] is None:
+            assert not got["valid"][i]
+            continue
+        assert got["valid"][i]
+        assert int(got["start_peak_idx"][i]) == int(tab["start_peak_idx"][i])
+        assert int(got["next_greater_idx"][i]) == int(tab["next_greater_idx"][i])
+        assert float(got["start_peak_pa"][i]) == tab["start_peak_pa"][i]
+        assert float(got["next_greater_pa"][i]) == tab["next_greater_pa"][i]
+        types = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
+        assert types[int(got["flagged_type"][i])] == tab["flagged_type"][i]
+        if tab["open_pore_idx"][i] is not None:
+            assert int(got["open_pore_idx"][i]) == int(tab["open_pore_idx"][i])
+
+
+def test_mad_zero_raises(oracle_mod):
+    from util import make_spc
+
+    spc = make_spc(CASES["rna004_llr_default"])
+    sig = np.full((4, spc.sig_preload_size), 80.0, dtype=np.float32)
+    with pytest.raises(ValueError, match="scale is 0"):
+        oracle_mod.detect_llr(sig, np.full(4, spc.sig_preload_size, dtype=np.int32), spc)
