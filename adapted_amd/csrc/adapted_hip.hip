@@ -1,0 +1,553 @@
+// adapted_hip.hip -- libadapted_hip.so: C ABI (include/adapted_hip.h) over the gfx950 kernels.
+// One translation unit; kernels live in the headers next to this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "adapted_hip.h"
+#include "common.h"
+#include "llr_stream.h"
+#include "n1_select.h"
+#include "peaks.h"
+#include "synth.h"
+#include "validate.h"
+#include "wave_stats.h"
+
+static thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return ADP_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { if (hipFree(p) != hipSuccess) return -1; p = nullptr; cap = 0; }
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return -1; }
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfEntry { const char *name; hipEvent_t a, b; };
+
+struct adp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    adp_cfg cfg;
+    int max_reads = 0, m = 0;
+    // geometry of the LLR path
+    int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
+    DevBuf mbs, ghist, gbelow, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf bounds, topk_none, rows, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
+    int vslots = 0, vstride = 0, pslots = 0;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    int last_n = 0, last_nmb = 0;
+};
+
+static int geom(adp_handle *h)
+{
+    const adp_cfg &c = h->cfg;
+    if (c.downscale_factor < 1 || c.downscale_factor > 64 || c.sp_downscale_factor < 1 || c.sp_downscale_factor > 64) {
+        g_err = "downscale_factor must be in [1, 64]"; return ADP_ERR_UNSUPPORTED;
+    }
+    if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
+    if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
+    h->T = c.max_obs_trace < h->m ? c.max_obs_trace : h->m;
+    h->off = c.min_obs_adapter;
+    h->ds = c.downscale_factor;
+    int Lseg = h->T - h->off;
+    h->L = Lseg > 0 ? (Lseg + h->ds - 1) / h->ds : 0;
+    h->Lp = ((h->L + 63) / 64) * 64;
+    if (h->Lp == 0) h->Lp = 64;
+    h->nck = h->Lp / CK;
+    h->nsum = h->Lp / SUMBLK;
+    return 0;
+}
+
+static int alloc_all(adp_handle *h)
+{
+    const size_t R = (size_t)h->max_reads, Lp = (size_t)h->Lp;
+    int bad = 0;
+    bad |= h->down.ensure(R * Lp * 4);
+    bad |= h->nvalid.ensure(R * 4);
+    bad |= h->ck.ensure(R * h->nck * sizeof(double2));
+    bad |= h->tail.ensure(R * sizeof(double2));
+    bad |= h->trace.ensure(R * Lp * 8);
+    bad |= h->bmax.ensure(R * h->nsum * 8);
+    bad |= h->bmin.ensure(R * h->nsum * 8);
+    bad |= h->t1.ensure(R * sizeof(int2));
+    bad |= h->adapter_idx.ensure(R * 4);
+    bad |= h->polya_idx.ensure(R * 4);
+    bad |= h->bounds.ensure(R * (1 + ADP_MAX_CAND) * 8);
+    bad |= h->topk_none.ensure(R);
+    bad |= h->rows.ensure(R * sizeof(adp_row));
+    bad |= h->sp.ensure(R * sizeof(SpOut));
+    bad |= h->any_none.ensure(64);
+    h->vslots = (int)(R < 2048 ? R : 2048);
+    h->vstride = ((h->m + 63) / 64) * 64;
+    bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
+    h->pslots = (int)(R < 4096 ? R : 4096);
+    bad |= h->pk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
+    bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
+    bad |= h->st.ensure((size_t)h->pslots * Lp);
+    if (bad) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    return 0;
+}
+
+extern "C" {
+
+int adp_abi_version(void) { return ADP_ABI_VERSION; }
+int adp_sizeof_cfg(void) { return (int)sizeof(adp_cfg); }
+int adp_sizeof_row(void) { return (int)sizeof(adp_row); }
+const char *adp_last_error(void) { return g_err.c_str(); }
+
+int adp_device_count(void)
+{
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    return n;
+}
+
+int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle **out)
+{
+    if (!cfg || !out || max_reads < 1 || m < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(device));
+    adp_handle *h = new adp_handle();
+    h->device = device;
+    h->cfg = *cfg;
+    h->max_reads = max_reads;
+    h->m = m;
+    int rc = geom(h);
+    if (rc) { delete h; return rc; }
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
+    rc = alloc_all(h);
+    if (rc) { adp_destroy(h); return rc; }
+    *out = h;
+    return ADP_OK;
+}
+
+int adp_destroy(adp_handle *h)
+{
+    if (!h) return ADP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->vscratch, &h->pk,
+                     &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
+    for (DevBuf *b : all) b->release();
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ADP_OK;
+}
+
+int adp_set_config(adp_handle *h, const adp_cfg *cfg)
+{
+    if (!h || !cfg) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cfg = *cfg;
+    int rc = geom(h);
+    if (rc) return rc;
+    return alloc_all(h);
+}
+
+void *adp_stream(adp_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int adp_synchronize(adp_handle *h)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+int adp_set_profiling(adp_handle *h, int on)
+{
+    if (!h) return ADP_ERR_INVALID;
+    h->profiling = on != 0;
+    return ADP_OK;
+}
+
+} // extern "C"
+
+// ---- profiling helpers -------------------------------------------------------------
+static hipEvent_t next_event(adp_handle *h)
+{
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_used++];
+}
+struct Scope {
+    adp_handle *h; hipEvent_t b = nullptr;
+    Scope(adp_handle *h_, const char *name) : h(h_)
+    {
+        if (!h->profiling) return;
+        hipEvent_t a = next_event(h);
+        b = next_event(h);
+        (void)hipEventRecord(a, h->stream);
+        h->prof.push_back({name, a, b});
+    }
+    ~Scope() { if (b) (void)hipEventRecord(b, h->stream); }
+};
+
+// ---- input staging -----------------------------------------------------------------
+static int stage_inputs(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int flags,
+                        const float **dsig, const int32_t **dlen)
+{
+    if (flags & ADP_IN_DEVICE) { *dsig = signals; *dlen = full_len; return 0; }
+    if (h->sig_stage.ensure((size_t)n * m * 4) || h->len_stage.ensure((size_t)n * 4)) { g_err = "staging allocation failed"; return ADP_ERR_HIP; }
+    HIPCHK(hipMemcpyAsync(h->sig_stage.p, signals, (size_t)n * m * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->len_stage.p, full_len, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    *dsig = h->sig_stage.as<float>();
+    *dlen = h->len_stage.as<int32_t>();
+    return 0;
+}
+
+static int deliver_rows(adp_handle *h, int n, int flags, adp_row *rows_out)
+{
+    if (!rows_out) return 0;
+    HIPCHK(hipMemcpyAsync(rows_out, h->rows.p, (size_t)n * sizeof(adp_row),
+                          (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
+
+__global__ void k_mb_set_status(MbState *mbs, int n_mb, int status)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mb) mbs[i].status = status;
+}
+
+// a read without any valid pooled block sinks its minibatch (the reference raises there)
+__global__ void k_check_empty(const int32_t *nvalid, int n_reads, int mbsize, MbState *mbs)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    if (nvalid[r] <= 0 && mbs[r / mbsize].status == ADP_MB_OK) mbs[r / mbsize].status = ADP_MB_EMPTY_TRACE;
+}
+
+__global__ void k_mb_status_out(const MbState *mbs, int n_mb, int32_t *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mb) out[i] = mbs[i].status;
+}
+
+__global__ void k_mb_params_out(const MbState *mbs, int n_mb, double *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_mb) {
+        out[4 * i] = (double)mbs[i].med; out[4 * i + 1] = (double)mbs[i].mad;
+        out[4 * i + 2] = (double)mbs[i].lo; out[4 * i + 3] = (double)mbs[i].hi;
+    }
+}
+
+static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
+                           bool gate_mb)
+{
+    ValidateIn in;
+    in.sig = dsig; in.full_len = dlen; in.bounds = h->bounds.as<int64_t>(); in.topk_none = h->topk_none.as<int8_t>();
+    in.kmax = kmax; in.n_reads = n; in.m = m; in.mbsize = mbsize;
+    in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
+    in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
+    int grid = n < h->vslots ? n : h->vslots;
+    Scope s(h, "k_validate");
+    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>());
+    return 0;
+}
+
+static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int minibatch, int flags,
+                        adp_row *rows_out, int32_t *mb_status, int upto)
+{
+    if (!h || !signals || !full_len || n < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear();
+    h->ev_used = 0;
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    const int n_mb = (n + minibatch - 1) / minibatch;
+    h->last_n = n; h->last_nmb = n_mb;
+    if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 4)) {
+        g_err = "device allocation failed"; return ADP_ERR_HIP;
+    }
+    hipStream_t st = h->stream;
+    MbState *mbs = h->mbs.as<MbState>();
+    HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
+    HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
+    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 4, st));
+    const int T = h->T;
+    if (h->L <= 0) {
+        hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
+    } else {
+        // ---- N1: median, then MAD (three radix passes each) -----------------------------
+        int bpm = 4096 / n_mb; if (bpm > 256) bpm = 256; if (bpm < 16) bpm = 16;
+        dim3 hg(bpm, n_mb);
+        uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
+        const double thr = h->cfg.sig_norm_outlier_thresh;
+        for (int mode = 0; mode < 2; mode++) {
+            { Scope s(h, mode ? "k_n1_hist<0> mad" : "k_n1_hist<0> med");
+              hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
+            hipLaunchKernelGGL(k_n1_pick<0>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+            { Scope s(h, mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med");
+              hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
+            hipLaunchKernelGGL(k_n1_pick<1>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+            { Scope s(h, mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med");
+              hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
+            hipLaunchKernelGGL(k_n1_pick<2>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+        }
+        if (upto >= 2) {
+            Scope s(h, "k_norm_pool");
+            hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+                               minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>());
+        }
+        if (upto >= 2)
+            hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);
+        if (upto >= 3) {
+            Scope s(h, "k_cumsum");
+            hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
+                               h->nck, h->ck.as<double2>(), h->tail.as<double2>());
+        }
+        if (upto >= 4) {
+            Scope s(h, "k_gains<1>");
+            hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+                               h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>());
+        }
+        if (upto >= 5) {
+            Scope s(h, "k_adapter_peak");
+            hipLaunchKernelGGL(k_adapter_peak, dim3(n), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+                               h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), minibatch, mbs,
+                               h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
+                               h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>());
+        }
+        if (upto >= 6) {
+            Scope s(h, "k_gains<2>");
+            hipLaunchKernelGGL(k_gains<2>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+                               h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>());
+        }
+        if (upto >= 7) {
+            Scope s(h, "k_polya_peak");
+            int grid = n < h->pslots ? n : h->pslots;
+            hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+                               h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
+                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->st.as<uint8_t>(), h->polya_idx.as<int32_t>());
+        }
+    }
+    if (upto >= 8) {
+        if (h->L > 0)
+            hipLaunchKernelGGL(k_llr_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->adapter_idx.as<int32_t>(),
+                               h->polya_idx.as<int32_t>(), n, h->ds, h->off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>());
+        rc = launch_validate(h, dsig, dlen, n, m, 1, minibatch, true);
+        if (rc) return rc;
+        if (flags & ADP_WITH_START_PEAK) {
+            { Scope s(h, "k_start_peak");
+              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), 0, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+            hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
+                               (const int32_t *)nullptr);
+        }
+        rc = deliver_rows(h, n, flags, rows_out);
+        if (rc) return rc;
+    }
+    if (mb_status) {
+        // through a small device buffer -> host
+        hipLaunchKernelGGL(k_mb_status_out, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, h->gbelow.as<int32_t>());
+        HIPCHK(hipMemcpyAsync(mb_status, h->gbelow.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+extern "C" {
+
+int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch, int flags,
+                   adp_row *rows_out, int32_t *mb_status)
+{
+    return llr_pipeline(h, signals, full_len, n_reads, m, minibatch, flags, rows_out, mb_status, 8);
+}
+
+int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch,
+                       int flags, int stage)
+{
+    return llr_pipeline(h, signals, full_len, n_reads, m, minibatch, flags, nullptr, nullptr, stage);
+}
+
+int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch,
+                          int flags, adp_row *rows_out)
+{
+    if (!h || !signals || !full_len || n_reads < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    // the pandas float-column quirk couples the reads of ONE minibatch: process minibatch by minibatch
+    for (int s0 = 0; s0 < n_reads; s0 += minibatch) {
+        int n = n_reads - s0 < minibatch ? n_reads - s0 : minibatch;
+        const float *sg = dsig + (size_t)s0 * m;
+        const int32_t *ln = dlen + s0;
+        HIPCHK(hipMemsetAsync(h->any_none.p, 0, 4, st));
+        { Scope s(h, "k_start_peak");
+          hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), 0, st, sg, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
+        hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
+                           h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
+        rc = launch_validate(h, sg, ln, n, m, 1, minibatch, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 1,
+                           h->any_none.as<int32_t>());
+        if (rows_out) {
+            HIPCHK(hipMemcpyAsync(rows_out + s0, h->rows.p, (size_t)n * sizeof(adp_row),
+                                  (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    HIPCHK(hipGetLastError());
+    return ADP_OK;
+}
+
+int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
+                            const int64_t *bounds, int k, int flags, adp_row *rows_out)
+{
+    if (!h || !signals || !full_len || !bounds || n_reads < 1 || k < 1 || k > ADP_MAX_CAND) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemcpyAsync(h->bounds.p, bounds, (size_t)n_reads * (1 + k) * 8,
+                          (flags & ADP_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
+    rc = launch_validate(h, dsig, dlen, n_reads, m, k, n_reads, false);
+    if (rc) return rc;
+    rc = deliver_rows(h, n_reads, flags, rows_out);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out)
+{
+    (void)h; (void)signals; (void)n_reads; (void)m; (void)flags; (void)prepared_out;
+    g_err = "adp_cnn_prepare: not implemented yet";
+    return ADP_ERR_UNSUPPORTED;
+}
+
+int adp_synth_fill(adp_handle *h, float *dev_signals, const int32_t *dev_full_len, int n, int m, uint32_t seed,
+                   uint32_t first_read, int decorate)
+{
+    if (!h || !dev_signals || n < 1 || m < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const double ih_sd = std::sqrt(8.0 * (256.0 * 256.0 - 1.0) / 12.0);
+    SynthConst k;
+    k.sd_adapter = (float)(7.0 / ih_sd); k.sd_polya = (float)(2.5 / ih_sd); k.sd_rna = (float)(3.0 / ih_sd);
+    k.sd_level = (float)(14.0 / ih_sd);
+    hipLaunchKernelGGL(k_synth, dim3((m + 255) / 256, n), dim3(256), 0, h->stream, dev_signals, dev_full_len, n, m, seed, first_read,
+                       decorate, k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+int adp_dev_alloc(adp_handle *h, uint64_t bytes, void **out)
+{
+    if (!h || !out) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMalloc(out, bytes));
+    return ADP_OK;
+}
+int adp_dev_free(adp_handle *h, void *p)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipFree(p));
+    return ADP_OK;
+}
+int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+int adp_kernel_times(adp_handle *h, const char **names_out, float *ms_out, int cap)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    int k = 0;
+    for (const ProfEntry &e : h->prof) {
+        if (k >= cap) break;
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(e.b));
+        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+        names_out[k] = e.name;
+        ms_out[k] = ms;
+        k++;
+    }
+    return k;
+}
+
+int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
+{
+    if (!h || !host_out) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    const void *src = nullptr;
+    switch (what) {
+    case 0: {
+        if (h->ghist.cap < (size_t)h->last_nmb * 32) return ADP_ERR_INVALID;
+        hipLaunchKernelGGL(k_mb_params_out, dim3((h->last_nmb + 255) / 256), dim3(256), 0, h->stream, h->mbs.as<MbState>(),
+                           h->last_nmb, h->ghist.as<double>());
+        src = h->ghist.p; break; }
+    case 1: src = h->nvalid.p; break;
+    case 2: src = h->down.p; break;
+    case 3: src = h->trace.p; break;
+    case 4: src = h->adapter_idx.p; break;
+    case 5: src = h->polya_idx.p; break;
+    case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
+    case 7: src = h->t1.p; break;
+    default: return ADP_ERR_INVALID;
+    }
+    HIPCHK(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (what == 0) HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)h->last_nmb * 32, h->stream));
+    return ADP_OK;
+}
+
+} // extern "C"

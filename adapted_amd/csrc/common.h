@@ -1,0 +1,86 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "adapted_hip.h"
+
+#define WAVE 64
+#define CK 16          // cumulative-sum checkpoint spacing (pooled samples)
+#define TRACE_TILE 1024 // pooled samples handled per wave iteration in the gains kernel (64 lanes x CK)
+#define SUMBLK 64      // trace summary block (max/min per 64 trace points)
+
+// per-minibatch state of the batch-global normalisation (N1)
+struct MbState {
+    unsigned long long n_valid;   // non-NaN samples in batch[:, :T]
+    unsigned long long krem;      // rank of the upper median inside the current prefix bucket
+    uint32_t prefix;              // resolved high bits of the selected key
+    uint32_t maxbelow;            // max key strictly below the prefix bucket (0 = none)
+    float med, mad, lo, hi;       // N1 parameters (float32, as numpy holds them)
+    int32_t status;               // ADP_MB_*
+    int32_t pad;
+};
+
+static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// order-preserving float32 <-> uint32 key
+static __device__ __forceinline__ uint32_t f2key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static __device__ __forceinline__ float key2f(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+template <class T>
+static __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <class T>
+static __device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+template <class T>
+static __device__ __forceinline__ T wave_min(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+// inclusive prefix sum across the wave
+static __device__ __forceinline__ int wave_scan_incl(int v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int w = __shfl_up(v, o); if (lane_id() >= o) v += w; }
+    return v;
+}
+
+// numpy's pairwise float32 sum of n <= 128 values read through `get(i)` (sequential in one lane).
+// numpy/_core/src/umath/loops_utils.h.src (pairwise_sum): n < 8 plain loop; else 8 accumulators.
+template <class F>
+static __device__ __forceinline__ float pw_leaf_f32(int n, F get)
+{
+    if (n < 8) {
+        float res = 0.f;
+        for (int i = 0; i < n; i++) res += get(i);
+        return res;
+    }
+    float r0 = get(0), r1 = get(1), r2 = get(2), r3 = get(3), r4 = get(4), r5 = get(5), r6 = get(6), r7 = get(7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += get(i); r1 += get(i + 1); r2 += get(i + 2); r3 += get(i + 3);
+        r4 += get(i + 4); r5 += get(i + 5); r6 += get(i + 6); r7 += get(i + 7);
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += get(i);
+    return res;
+}

@@ -1,0 +1,215 @@
+// llr_stream.h -- D1 (clip + normalise + mean-pool), sequential float64 cumulative sums with
+// checkpoints, and the LLR gains trace (G1/G2).
+//
+//   D1  downscale_signal(normalize_signal(batch[:, :T])[:, min_obs:], ds)
+//       reference adapted/detect/downscale.py:4-41, adapted/detect/normalize.py:25-63,
+//       adapted/detect/combined.py:128-140.  float32, numpy's pairwise order inside a pool block.
+//   G1  c_llr_trace -> _gains(0, n-1, c, c2, 5, 5)      adapted/detect/_c_llr.pyx:202-236, 67-88
+//   G2  c_llr_trace_gains -> _gains(a, n-1, c, c2, 1, 1) adapted/detect/_c_llr.pyx:176-199
+//       var_c                                            adapted/detect/_c_llr.pyx:23-37
+//
+// np.cumsum is a strictly sequential float64 recurrence and the pass-2 trace next to the
+// adapter boundary is pure cumulative-sum rounding noise, so the recurrence is kept bit-exact:
+// one LANE per read walks the pooled signal once (64 reads per wave) and stores the running
+// sums every CK points; the gains kernel (one WAVE per read) restarts from those checkpoints,
+// so every lane reproduces the reference's partial sums exactly while 64 split points are
+// evaluated in parallel.
+#pragma once
+#include "common.h"
+
+// ---------------------------------------------------------------- D1
+// grid = n_reads blocks of 256 threads; dynamic LDS = 256 * ds floats
+__global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig, int m, int T, int off, int ds, int L, int Lp,
+                                                   int mbsize, const MbState *__restrict__ mbs,
+                                                   float *__restrict__ down, int32_t *__restrict__ nvalid)
+{
+    extern __shared__ float tile[];
+    __shared__ int s_nan;
+    const int r = blockIdx.x;
+    const MbState st = mbs[r / mbsize];
+    if (st.status != ADP_MB_OK) { if (threadIdx.x == 0) nvalid[r] = 0; return; }
+    const float med = st.med, mad = st.mad, lo = st.lo, hi = st.hi;
+    const float *row = sig + (size_t)r * m + off;
+    const int Lseg = T - off; // > 0 guaranteed by the host
+    if (threadIdx.x == 0) s_nan = 0;
+    int my_nan = 0;
+    const int tile_n = 256 * ds;
+    for (int tb = 0; tb < L; tb += 256) {
+        const int base = tb * ds;
+        __syncthreads();
+        for (int i = threadIdx.x; i < tile_n; i += 256) {
+            int idx = base + i;
+            float v = 0.0f; // np.pad(..., mode="constant") for a ragged tail
+            if (idx < Lseg) {
+                float c = row[idx];
+                c = c < lo ? lo : c; // np.clip; NaN stays NaN
+                c = c > hi ? hi : c;
+                v = (c - med) / mad;
+            }
+            tile[i] = v;
+        }
+        __syncthreads();
+        const int j = tb + threadIdx.x;
+        if (j < L) {
+            const float *p = tile + threadIdx.x * ds;
+            float s = pw_leaf_f32(ds, [&](int k) { return p[k]; });
+            float pooled = s / (float)ds;
+            down[(size_t)r * Lp + j] = pooled;
+            if (pooled != pooled) my_nan++;
+        }
+    }
+    my_nan = wave_sum(my_nan);
+    if (lane_id() == 0 && my_nan) atomicAdd(&s_nan, my_nan);
+    __syncthreads();
+    if (threadIdx.x == 0) nvalid[r] = L - s_nan;
+}
+
+// ---------------------------------------------------------------- cumulative sums
+// one lane per read.  ck[r][q] = (c, c2) BEFORE pooled sample q*CK; tail[r] = (c[n-2], c2[n-2]).
+__global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int n_reads,
+                                               int nck, double2 *__restrict__ ck, double2 *__restrict__ tail)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_reads) return;
+    const int n = nvalid[r];
+    const float *s = down + (size_t)r * Lp;
+    double2 *c = ck + (size_t)r * nck;
+    double a = 0.0, b = 0.0;
+    double2 t = make_double2(0.0, 0.0);
+    for (int j = 0; j < n; j++) {
+        if ((j & (CK - 1)) == 0) c[j / CK] = make_double2(a, b);
+        if (j == n - 1) t = make_double2(a, b);
+        double v = (double)s[j];
+        a += v;
+        b += v * v;
+    }
+    tail[r] = t;
+}
+
+// ---------------------------------------------------------------- gains
+static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, double len)
+{
+    double mu = (chi - clo) / len;
+    return (c2hi - c2lo) / len - mu * mu;
+}
+
+// grid = n_reads waves (block = 64).  PASS 1: start = 0, offsets (5, 5), also emits T1 (first / last
+// index with a positive-or-NaN gain).  PASS 2: start = adapter candidate, offsets (1, 1).
+// Emits the trace (float64) and per-64-point summaries: PASS 1 of the raw trace (NaN => +inf max),
+// PASS 2 of the np.nan_to_num-sanitised trace that find_peaks sees in P4.
+template <int PASS>
+__global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
+                                              const double2 *__restrict__ ck, const double2 *__restrict__ tail,
+                                              const int32_t *__restrict__ adapter_idx, int mbsize,
+                                              const MbState *__restrict__ mbs, double *__restrict__ trace,
+                                              double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
+                                              int2 *__restrict__ t1)
+{
+    __shared__ float sd[64 * (CK + 1)];
+    __shared__ double sg[64 * (CK + 1)];
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    if (mbs[r / mbsize].status != ADP_MB_OK) return;
+    const int n = nvalid[r];
+    if (n <= 0) return;
+    int start = 0, oh = 5, ot = 5;
+    if (PASS == 2) {
+        start = adapter_idx[r];
+        if (start < 0) return;
+        oh = 1; ot = 1;
+    }
+    const int E = n - 1;
+    const float *s = down + (size_t)r * Lp;
+    const double2 *c = ck + (size_t)r * nck;
+    double *g = trace + (size_t)r * Lp;
+    // c[E-1], c2[E-1]
+    const double2 te = tail[r];
+    // c[start-1], c2[start-1] (sequential restart from the checkpoint, identical operations)
+    double cs = 0.0, c2s = 0.0;
+    if (PASS == 2 && start > 0) {
+        int q = start / CK;
+        double2 p = c[q];
+        double a = p.x, b = p.y;
+        for (int j = q * CK; j < start; j++) { double v = (double)s[j]; a += v; b += v * v; }
+        cs = a; c2s = b;
+    }
+    double vs;
+    {
+        double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, (double)(E - start));
+        vs = (double)(E - start) * log(v);
+    }
+    int first_pos = 0x7fffffff, last_pos = -1;
+    for (int tb = 0; tb < n; tb += TRACE_TILE) {
+        // stage the pooled samples of this tile: coalesced -> LDS [lane][CK] (stride CK+1)
+        __syncthreads();
+        for (int k = 0; k < CK; k++) {
+            int e = k * 64 + ln;
+            int i = tb + e;
+            sd[(e / CK) * (CK + 1) + (e % CK)] = (i < n) ? s[i] : 0.0f;
+        }
+        __syncthreads();
+        const int i0 = tb + ln * CK;
+        double a = 0.0, b = 0.0;
+        if (i0 < n) { double2 p = c[i0 / CK]; a = p.x; b = p.y; }
+        double mx = -__builtin_inf(), mn = __builtin_inf();
+#pragma unroll 4
+        for (int t = 0; t < CK; t++) {
+            const int i = i0 + t;
+            double gi = 0.0;
+            if (i < n) {
+                if (i >= start + oh && i < E - ot) {
+                    double vh = var_seg(b, c2s, a, cs, (double)(i - start));
+                    double vt = var_seg(te.y, b, te.x, a, (double)(E - i));
+                    double h = (double)(i - start) * log(vh);
+                    double tl = (double)(E - i) * log(vt);
+                    gi = vs - (h + tl);
+                }
+                if (PASS == 1) {
+                    if (!(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }
+                    double m1 = (gi != gi) ? __builtin_inf() : gi;
+                    mx = m1 > mx ? m1 : mx;
+                    if (gi == gi) mn = gi < mn ? gi : mn;
+                } else {
+                    double x = gi;
+                    if (x != x) x = 0.0;
+                    else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+                    mx = x > mx ? x : mx;
+                    mn = x < mn ? x : mn;
+                }
+                double v = (double)sd[ln * (CK + 1) + t];
+                a += v;
+                b += v * v;
+            }
+            sg[ln * (CK + 1) + t] = gi;
+        }
+        // 4 lanes = one 64-point summary block
+        {
+            double w;
+            w = __shfl_xor(mx, 1); mx = w > mx ? w : mx;
+            w = __shfl_xor(mx, 2); mx = w > mx ? w : mx;
+            w = __shfl_xor(mn, 1); mn = w < mn ? w : mn;
+            w = __shfl_xor(mn, 2); mn = w < mn ? w : mn;
+            int blk = tb / SUMBLK + (ln >> 2);
+            if ((ln & 3) == 0 && blk < nsum && (tb + (ln >> 2) * SUMBLK) < n) {
+                bmax[(size_t)r * nsum + blk] = mx;
+                bmin[(size_t)r * nsum + blk] = mn;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < CK; k++) {
+            int e = k * 64 + ln;
+            int i = tb + e;
+            if (i < n) g[i] = sg[(e / CK) * (CK + 1) + (e % CK)];
+        }
+    }
+    if (PASS == 1) {
+        first_pos = wave_min(first_pos);
+        last_pos = wave_max(last_pos);
+        if (ln == 0) {
+            // np.argmin(signal <= 0): first False, 0 if none; end = size - argmin(reversed) - 1
+            int st = (last_pos < 0) ? 0 : first_pos;
+            int en = (last_pos < 0) ? n - 1 : last_pos;
+            t1[r] = make_int2(st, en);
+        }
+    }
+}

@@ -1,0 +1,346 @@
+// peaks.h -- peak picking on the LLR traces, one wave per read.
+//
+//   T1 LLRTrace._trace_start_end                       reference adapted/detect/llr.py:135-142
+//   P1 find_peaks_in_trace                             adapted/detect/llr.py:204-224
+//   P2 correct_for_plateau                             adapted/detect/llr.py:145-177
+//   P3 correct_for_split_peak                          adapted/detect/llr.py:180-201
+//   A1 first candidate -> adapter_end                  adapted/detect/combined.py:180-188
+//   P4 detect_full_polya_trace_peak_with_spike         adapted/detect/llr.py:406-479
+//
+// scipy.signal.find_peaks (third party, not in the reference tree) is restated from its
+// published algorithm: strict local maxima with plateau midpoints -> optional minimum
+// distance by descending height -> prominence (walk to the next higher sample on each side,
+// lowest point on the way) -> width at rel_height by linear interpolation.  Here the 64 lanes
+// of a wave evaluate 64 candidate maxima at once; the walks skip whole 64-point blocks using
+// the per-block max/min the gains kernel left behind, and the minimum-distance rule is solved
+// as its fixed point ("kept iff no kept higher neighbour within the distance") instead of a
+// global sort.
+#pragma once
+#include "common.h"
+
+#define DBLMAX 1.7976931348623157e308
+
+struct TraceView {
+    const double *x;     // trace of one read (full-trace coordinates)
+    const double *bmax;  // per-64 block max (NaN -> +inf) or nullptr
+    const double *bmin;  // per-64 block min or nullptr
+    int lo, hi;          // inclusive index bounds of the array find_peaks sees
+    int sanitize;        // apply np.nan_to_num(nan=0) on load
+};
+
+static __device__ __forceinline__ double tv_get(const TraceView &t, int i)
+{
+    double v = t.x[i];
+    if (t.sanitize) {
+        if (v != v) v = 0.0;
+        else if (__builtin_isinf(v)) v = v > 0 ? DBLMAX : -DBLMAX;
+    }
+    return v;
+}
+
+// Is full-trace index i the left edge of a strict local maximum (scipy _local_maxima_1d)?
+// Returns the plateau midpoint or -1.
+static __device__ __forceinline__ int tv_peak_at(const TraceView &t, int i)
+{
+    if (i <= t.lo || i >= t.hi) return -1;
+    double xi = tv_get(t, i);
+    if (!(tv_get(t, i - 1) < xi)) return -1;
+    int j = i + 1;
+    while (j < t.hi && tv_get(t, j) == xi) j++;
+    if (tv_get(t, j) < xi) return (i + j - 1) / 2;
+    return -1;
+}
+
+// prominence of the peak at p (scipy _peak_prominences, wlen = None)
+static __device__ double tv_prominence(const TraceView &t, int p)
+{
+    const double xp = tv_get(t, p);
+    double left_min = xp, right_min = xp;
+    int i = p;
+    while (i >= t.lo) {
+        if (t.bmax && (i & (SUMBLK - 1)) == SUMBLK - 1 && i - (SUMBLK - 1) >= t.lo) {
+            int b = i / SUMBLK;
+            if (t.bmax[b] <= xp) { double m = t.bmin[b]; if (m < left_min) left_min = m; i -= SUMBLK; continue; }
+        }
+        double v = tv_get(t, i);
+        if (!(v <= xp)) break;
+        if (v < left_min) left_min = v;
+        i--;
+    }
+    i = p;
+    while (i <= t.hi) {
+        if (t.bmax && (i & (SUMBLK - 1)) == 0 && i + (SUMBLK - 1) <= t.hi) {
+            int b = i / SUMBLK;
+            if (t.bmax[b] <= xp) { double m = t.bmin[b]; if (m < right_min) right_min = m; i += SUMBLK; continue; }
+        }
+        double v = tv_get(t, i);
+        if (!(v <= xp)) break;
+        if (v < right_min) right_min = v;
+        i++;
+    }
+    return xp - (left_min > right_min ? left_min : right_min);
+}
+
+// width of the peak at p at relative height rel (<= 1) (scipy _peak_widths).  For rel <= 1 the
+// walk stops by value at or before the prominence base, so the bases need not be carried.
+static __device__ double tv_width(const TraceView &t, int p, double prom, double rel)
+{
+    const double xp = tv_get(t, p);
+    const double height = xp - prom * rel;
+    int i = p;
+    while (i > t.lo) {
+        if (t.bmin && (i & (SUMBLK - 1)) == SUMBLK - 1 && i - (SUMBLK - 1) > t.lo) {
+            int b = i / SUMBLK;
+            if (t.bmin[b] > height && t.bmax[b] <= xp) { i -= SUMBLK; continue; }
+        }
+        if (!(height < tv_get(t, i))) break;
+        i--;
+    }
+    double left_ip = (double)i;
+    {
+        double xi = tv_get(t, i);
+        if (xi < height) left_ip += (height - xi) / (tv_get(t, i + 1) - xi);
+    }
+    i = p;
+    while (i < t.hi) {
+        if (t.bmin && (i & (SUMBLK - 1)) == 0 && i + (SUMBLK - 1) < t.hi) {
+            int b = i / SUMBLK;
+            if (t.bmin[b] > height && t.bmax[b] <= xp) { i += SUMBLK; continue; }
+        }
+        if (!(height < tv_get(t, i))) break;
+        i++;
+    }
+    double right_ip = (double)i;
+    {
+        double xi = tv_get(t, i);
+        if (xi < height) right_ip -= (height - xi) / (tv_get(t, i - 1) - xi);
+    }
+    return right_ip - left_ip;
+}
+
+// First peak (lowest index) of find_peaks(x[lo..hi], prominence=pmin, width=wmin, rel_height=rel),
+// in full-trace coordinates, or -1.  Wave-cooperative: call from uniform control flow.
+static __device__ int wave_first_peak(const TraceView &t, double pmin, double wmin, double rel)
+{
+    const int ln = lane_id();
+    for (int base = t.lo + 1; base < t.hi; base += 64) {
+        int i = base + ln;
+        int p = (i < t.hi) ? tv_peak_at(t, i) : -1;
+        bool ok = false;
+        if (p >= 0) {
+            double prom = tv_prominence(t, p);
+            if (pmin <= prom) ok = (wmin <= tv_width(t, p, prom, rel));
+        }
+        unsigned long long mk = __ballot(ok);
+        if (mk) return __shfl(p, __ffsll((long long)mk) - 1);
+    }
+    return -1;
+}
+
+// ---------------------------------------------------------------- adapter end (P1 + P2 + P3 + A1)
+// grid = n_reads waves.  adapter_idx[r] = candidate in pooled units, or -1.
+__global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
+                                                     const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
+                                                     const int2 *__restrict__ t1, int mbsize, const MbState *__restrict__ mbs,
+                                                     double prominence, double rel_height, int width,
+                                                     int32_t *__restrict__ adapter_idx)
+{
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    if (mbs[r / mbsize].status != ADP_MB_OK) { if (ln == 0) adapter_idx[r] = -1; return; }
+    const int n = nvalid[r];
+    int result = -1;
+    if (n >= 3) {
+        const double *g = trace + (size_t)r * Lp;
+        const int2 se = t1[r];
+        const int cn = se.y - se.x; // clip = g[start:end]
+        if (cn >= 3) {
+            // np.nanstd(clip): mean over the non-NaN points, then the mean squared deviation.
+            // (float64 tree reduction: not numpy's summation order; it only scales a threshold.)
+            double s = 0.0; int cnt = 0;
+            for (int i = se.x + ln; i < se.y; i += 64) { double v = g[i]; if (v == v) { s += v; cnt++; } }
+            s = wave_sum(s); cnt = wave_sum(cnt);
+            double mean = s / (double)cnt;
+            double q = 0.0;
+            for (int i = se.x + ln; i < se.y; i += 64) { double v = g[i]; if (v == v) { double d = v - mean; q += d * d; } }
+            q = wave_sum(q);
+            double sd = sqrt(q / (double)cnt);
+            TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, se.x, se.y - 1, 0};
+            int peak = wave_first_peak(tv, prominence * sd, (double)width, rel_height);
+            if (peak >= 0) {
+                // P2 correct_for_plateau(trace, peak, s=10, t=0.9, window=500)
+                {
+                    const int wn = min(peak + 500, n) - peak;
+                    const int nch = wn - 1;
+                    const double w0 = g[peak];
+                    int best = -1;
+                    for (int i = ln; i <= nch - 10; i += 64) {
+                        bool ok = g[peak + i + 9] > 0.9 * w0;
+                        for (int j = i; ok && j < i + 9; j++) ok = (g[peak + j + 1] - g[peak + j] >= 0.0);
+                        if (ok) best = i;
+                    }
+                    best = wave_max(best);
+                    if (best >= 0) peak += best + 9;
+                }
+                // P3 correct_for_split_peak: find_peaks(window, width=10, prominence=1.0)[0]
+                {
+                    const int wn = min(peak + 500, n) - peak;
+                    TraceView tw{g, nullptr, nullptr, peak, peak + wn - 1, 0};
+                    int pk = wave_first_peak(tw, 1.0, 10.0, 0.5);
+                    if (pk >= 0 && g[pk] >= 0.9 * g[peak]) peak = pk;
+                }
+                result = peak;
+            }
+        }
+    }
+    if (ln == 0) adapter_idx[r] = result;
+}
+
+// ---------------------------------------------------------------- poly(A) end (P4)
+#define ST_NONE 0
+#define ST_UNDECIDED 1
+#define ST_KEPT 2
+#define ST_REMOVED 3
+
+// persistent grid of waves; slot scratch: pk[Lp/2+1] int32, mk[Lp/2+1] uint32, state[Lp] bytes
+__global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
+                                                   const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
+                                                   const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
+                                                   const MbState *__restrict__ mbs, int32_t *__restrict__ pk_all,
+                                                   uint32_t *__restrict__ mk_all, uint8_t *__restrict__ st_all,
+                                                   int32_t *__restrict__ polya_idx)
+{
+    const int ln = lane_id();
+    const int half = Lp / 2 + 1;
+    int32_t *pk = pk_all + (size_t)blockIdx.x * half;
+    uint32_t *mk = mk_all + (size_t)blockIdx.x * half;
+    uint8_t *state = st_all + (size_t)blockIdx.x * Lp;
+    for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        int result = 0;
+        const int n = nvalid[r];
+        const bool active = mbs[r / mbsize].status == ADP_MB_OK && adapter_idx[r] >= 0 && n >= 3;
+        if (active) {
+            const double *g = trace + (size_t)r * Lp;
+            TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, 0, n - 1, 1};
+            // 1. all local maxima, in index order
+            int npk = 0;
+            for (int base = 0; base < n; base += 64) {
+                int i = base + ln;
+                int p = (i < n) ? tv_peak_at(tv, i) : -1;
+                if (i < n) state[i] = ST_NONE;
+                unsigned long long m = __ballot(p >= 0);
+                if (p >= 0) pk[npk + __popcll(m & ((1ull << ln) - 1ull))] = p;
+                npk += __popcll(m);
+            }
+            __syncthreads();
+            for (int k = ln; k < npk; k += 64) state[pk[k]] = ST_UNDECIDED;
+            __syncthreads();
+            // 2. per peak: which positions within +-9 hold a higher-priority peak
+            //    (scipy _select_by_peak_distance, distance = 10 -> |dp| < 10; equal heights: later index first)
+            for (int k = ln; k < npk; k += 64) {
+                int p = pk[k];
+                double xp = tv_get(tv, p);
+                uint32_t bits = 0;
+                for (int o = -9; o <= 9; o++) {
+                    int q = p + o;
+                    if (o == 0 || q < 0 || q >= n) continue;
+                    if (state[q] == ST_NONE) continue;
+                    double xq = tv_get(tv, q);
+                    if (xq > xp || (xq == xp && q > p)) bits |= 1u << (o + 9);
+                }
+                mk[k] = bits;
+            }
+            __syncthreads();
+            // 3. fixed point of "kept iff no kept higher-priority neighbour"
+            int nund = npk;
+            while (nund > 0) {
+                int w = 0;
+                for (int base = 0; base < nund; base += 64) {
+                    int k = base + ln;
+                    int p = -1; uint32_t bits = 0;
+                    bool pending = false;
+                    if (k < nund) {
+                        p = pk[k]; bits = mk[k];
+                        bool kept_nb = false;
+                        uint32_t b = bits;
+                        while (b) {
+                            int o = __ffs(b) - 1; b &= b - 1;
+                            uint8_t s = state[p + o - 9];
+                            if (s == ST_KEPT) kept_nb = true;
+                            else if (s == ST_UNDECIDED) pending = true;
+                        }
+                        if (kept_nb) { state[p] = ST_REMOVED; pending = false; }
+                        else if (!pending) state[p] = ST_KEPT;
+                    }
+                    unsigned long long m = __ballot(pending);
+                    if (pending) {
+                        int dst = w + __popcll(m & ((1ull << ln) - 1ull));
+                        pk[dst] = p; mk[dst] = bits;
+                    }
+                    w += __popcll(m);
+                    __syncthreads();
+                }
+                nund = w;
+            }
+            __syncthreads();
+            // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
+            int p0 = -1, p1 = -1;
+            for (int base = 0; base < n && p1 < 0; base += 64) {
+                int i = base + ln;
+                bool ok = false;
+                if (i < n && state[i] == ST_KEPT) {
+                    double prom = tv_prominence(tv, i);
+                    if (1.0 <= prom) ok = (10.0 <= tv_width(tv, i, prom, 0.5));
+                }
+                unsigned long long m = __ballot(ok);
+                while (m && p1 < 0) {
+                    int f = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    if (p0 < 0) p0 = base + f; else p1 = base + f;
+                }
+            }
+            // 5. spike heuristics on the UN-sanitised trace
+            if (p0 >= 0 && p1 < 0) result = p0;
+            else if (p0 >= 0) {
+                double h0 = g[p0], h1 = g[p1];
+                if (h1 > h0) result = p1;
+                else if (h1 < h0 * 0.5) result = p0;
+                else {
+                    // idx_min = argmin(g[p0:p1]) (first minimum; a NaN wins)
+                    double mv = __builtin_inf(); int mi = 0x7fffffff; int nan_i = 0x7fffffff;
+                    for (int i = p0 + ln; i < p1; i += 64) {
+                        double v = g[i];
+                        if (v != v) nan_i = min(nan_i, i);
+                        else if (v < mv) { mv = v; mi = i; }
+                    }
+                    nan_i = wave_min(nan_i);
+                    double gm = wave_min(mv);
+                    int cand = (mv == gm) ? mi : 0x7fffffff;
+                    cand = wave_min(cand);
+                    int idx_min = (nan_i != 0x7fffffff) ? nan_i : cand;
+                    if (idx_min == 0x7fffffff) idx_min = p0; // all +inf: np.argmin -> 0
+                    int cnt = p1 - idx_min;
+                    // scipy.stats.linregress r-value
+                    double sx = 0, sy = 0;
+                    for (int i = idx_min + ln; i < p1; i += 64) { sx += (double)i; sy += g[i]; }
+                    sx = wave_sum(sx); sy = wave_sum(sy);
+                    double xm = sx / cnt, ym = sy / cnt;
+                    double sxx = 0, sxy = 0, syy = 0;
+                    for (int i = idx_min + ln; i < p1; i += 64) {
+                        double dx = (double)i - xm, dy = g[i] - ym;
+                        sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+                    }
+                    sxx = wave_sum(sxx); sxy = wave_sum(sxy); syy = wave_sum(syy);
+                    double inv = 1.0 / (double)cnt;
+                    double ssxm = sxx * inv, ssxym = sxy * inv, ssym = syy * inv;
+                    double rr;
+                    if (ssxm == 0.0 || ssym == 0.0) rr = 0.0;
+                    else { rr = ssxym / sqrt(ssxm * ssym); if (rr > 1.0) rr = 1.0; else if (rr < -1.0) rr = -1.0; }
+                    result = (rr * rr >= 0.99) ? p1 : 0;
+                }
+            }
+            __syncthreads();
+        }
+        if (ln == 0) polya_idx[r] = result;
+    }
+}

@@ -1,0 +1,448 @@
+// validate.h -- V1 validate_boundaries and everything under it, one wave per read.
+//
+//   V1 validate_boundaries            reference adapted/detect/combined.py:358-631
+//   V2 find_open_pores                adapted/detect/anomalies.py:15-35
+//   V3 real_range_check               adapted/detect/real_range.py:33-63
+//   V4 mean_var_shift_polyA_check     adapted/detect/mvs.py:45-158   (bottleneck move_mean /
+//      move_var: float32 streaming recurrences, strictly sequential -> run by single lanes)
+//   S1 calc_partition_stats           adapted/partition/signal_partitions.py:81-96
+//   K2 start-peak decorations         adapted/detect/combined.py:333-347
+//
+// The kernel is a persistent grid of waves ("slots"); each slot owns scratch for the moving
+// mean / variance series of one poly(A) candidate.  All branches are per-read decisions and
+// therefore wave-uniform.
+#pragma once
+#include "common.h"
+#include "wave_stats.h"
+
+struct ValidateIn {
+    const float *sig;          // [n_reads, m]
+    const int32_t *full_len;   // [n_reads]
+    const int64_t *bounds;     // [n_reads, 1 + kmax]: adapter_end, candidates (0 terminates)
+    const int8_t *topk_none;   // [n_reads] 1 <=> polya_end_topk is None ; may be nullptr (all given)
+    int kmax;
+    int n_reads, m, mbsize;
+    const MbState *mbs;        // may be nullptr (no minibatch gating)
+    float *scratch;            // [slots, 2, scratch_stride]
+    int scratch_stride;
+};
+
+static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
+static __device__ __forceinline__ bool range_empty(const double *r)
+{
+    return __builtin_isinf(r[0]) && r[0] < 0 && __builtin_isinf(r[1]) && r[1] > 0;
+}
+
+struct RowW {
+    adp_row *row;
+    unsigned long long present;
+    __device__ void set(int c, double v) { if (lane_id() == 0) row->col[c] = v; present |= 1ull << c; }
+};
+
+// bottleneck.move_mean(a, window=w) for i >= w-1 (float32, NaN-free input) -- single lane
+static __device__ void bn_move_mean(const float *a, int n, int w, float *out)
+{
+    float asum = 0.f;
+    for (int i = 0; i < w; i++) asum += a[i];
+    out[0] = asum / (float)w;
+    const float inv = (float)(1.0 / (double)w);
+    for (int i = w; i < n; i++) {
+        asum += a[i] - a[i - w];
+        out[i - w + 1] = asum * inv;
+    }
+}
+
+// bottleneck.move_var(a, window=w, ddof=0) for i >= w-1 -- single lane
+static __device__ void bn_move_var(const float *a, int n, int w, float *out)
+{
+    float amean = 0.f, assqdm = 0.f;
+    int count = 0;
+    for (int i = 0; i < w; i++) {
+        float ai = a[i];
+        count++;
+        float delta = ai - amean;
+        amean += delta / (float)count;
+        assqdm += delta * (ai - amean);
+    }
+    if (assqdm < 0) assqdm = 0;
+    out[0] = assqdm / (float)count;
+    const float ddof_inv = (float)(1.0 / (double)count), count_inv = ddof_inv;
+    for (int i = w; i < n; i++) {
+        float ai = a[i], aold = a[i - w];
+        float delta = ai - aold;
+        aold -= amean;
+        amean += delta * count_inv;
+        ai -= amean;
+        assqdm += (ai + aold) * delta;
+        if (assqdm < 0) assqdm = 0;
+        out[i - w + 1] = assqdm * ddof_inv;
+    }
+}
+
+// calc_partition_stats -> (start, len, mean, std, med, mad)
+static __device__ void partition_stats(const float *sig, int S, long long start, long long end, RowW &rw, int c_start,
+                                       int c_len, WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
+{
+    rw.set(c_start, (double)start);
+    if (end <= start) return;
+    rw.set(c_len, (double)(end - start));
+    long long a = start < S ? start : S, b = end < S ? end : S;
+    int n = (int)(b - a);
+    float mean, sd, med, mad;
+    if (n <= 0) { mean = sd = med = mad = __builtin_nanf(""); }
+    else {
+        const float *x = sig + a;
+        float var = wave_np_var(x, n, ws, &mean);
+        sd = sqrtf(var);
+        if (have_medmad) { med = med_in; mad = mad_in; }
+        else { med = wave_median(x, n, 0, 0.f, ws); mad = wave_median(x, n, 1, med, ws); }
+    }
+    rw.set(c_len + 1, (double)mean);
+    rw.set(c_len + 2, (double)sd);
+    rw.set(c_len + 3, (double)med);
+    rw.set(c_len + 4, (double)mad);
+}
+
+struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
+
+static __device__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
+                                   double pr1, WaveScratch *ws, float *scr_mean, float *scr_var)
+{
+    MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
+    if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return o;
+    if ((long long)S < a_e + cfg.median_shift_window) return o;
+    const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
+    const int n = b - a;
+    const float *x = sig + a;
+    const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
+    if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) {
+        o.exc = ADP_F_EXC_MOVE_WINDOW; return o;
+    }
+    // the two sequential recurrences run side by side in lanes 0 and 1
+    __syncthreads();
+    if (lane_id() == 0 && wvar) bn_move_var(x, n, cfg.pA_var_window, scr_var);
+    if (lane_id() == 1 && wmean) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+    __threadfence_block();
+    __syncthreads();
+    float fvar, fmean;
+    if (wvar) fvar = wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws);
+    else fvar = wave_np_var(x, n, ws, nullptr);
+    if (wmean) fmean = wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws);
+    else fmean = wave_np_mean(x, n, ws);
+    float fmed = wave_median(x, n, 0, 0.f, ws);
+    double lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws) - wave_percentile(x, n, 15.0, ws) : (double)__builtin_nanf("");
+    long long r1 = a_e + cfg.median_shift_window; if (r1 > S) r1 = S;
+    long long l0 = a_e - cfg.median_shift_window; if (l0 < 0) l0 = 0;
+    float shift = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws);
+    o.mean = (double)fmean; o.var = (double)fvar; o.med = (double)fmed; o.lrange = lrange; o.shift = (double)shift;
+    int f = 0;
+    if (!in_range_d(o.mean, pr0, pr1)) f |= 1;
+    if (!in_range_d(o.var, cfg.pA_var_range[0], cfg.pA_var_range[1])) f |= 2;
+    if (!in_range_d(o.med, cfg.polyA_med_range[0], cfg.polyA_med_range[1])) f |= 4;
+    if (!in_range_d(o.lrange, cfg.polyA_local_range[0], cfg.polyA_local_range[1])) f |= 8;
+    if (!in_range_d(o.shift, cfg.median_shift_range[0], cfg.median_shift_range[1])) f |= 16;
+    o.vec_fail = f; o.ok = (f == 0);
+    return o;
+}
+
+static __device__ void row_clear(adp_row *row)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(row);
+    for (int i = lane_id(); i < (int)(sizeof(adp_row) / 4); i += 64) w[i] = 0;
+    __syncthreads();
+    if (lane_id() == 0) { row->n_cand = -1; row->n_open_pores = -1; }
+}
+
+static __device__ void row_exception(adp_row *row, int code)
+{
+    row_clear(row);
+    if (lane_id() == 0) { row->success = 0; row->fail_code = code; }
+}
+
+// persistent grid: blockIdx.x = slot, block = 64 threads
+__global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows)
+{
+    __shared__ WaveScratch ws_;
+    WaveScratch *ws = &ws_;
+    const int ln = lane_id();
+    float *scr_mean = in.scratch + (size_t)blockIdx.x * 2 * in.scratch_stride;
+    float *scr_var = scr_mean + in.scratch_stride;
+    for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
+        adp_row *row = rows + r;
+        row_clear(row);
+        if (in.mbs && in.mbs[r / in.mbsize].status != ADP_MB_OK) continue; // dropped minibatch: zero row
+        const float *sig = in.sig + (size_t)r * in.m;
+        const long long full_len = in.full_len[r];
+        const int S = (int)(full_len < in.m ? full_len : in.m);
+        const int64_t *bd = in.bounds + (size_t)r * (1 + in.kmax);
+        const long long a_in = bd[0];
+        const long long p_in = in.kmax > 0 ? bd[1] : 0;
+        const bool topk_none = in.topk_none ? in.topk_none[r] != 0 : false;
+        long long a_s = 0, a_e = a_in, p_best = p_in;
+        int success = 1, fail = ADP_F_NONE, mvs_mask = 0;
+        float adapter_med = 0.f, adapter_mad = 0.f;
+        bool have_med = false;
+        RowW rw{row, 0ull};
+        int n_open = -1;
+
+        if (a_e == 0) { success = 0; fail = ADP_F_NO_ADAPTER; }
+        else {
+            int b = (int)(a_e < S ? a_e : S);
+            adapter_med = wave_median(sig, b, 0, 0.f, ws);
+            adapter_mad = wave_median(sig, b, 1, adapter_med, ws);
+            have_med = true;
+        }
+        if (success && have_med && adapter_mad != 0.0f &&
+            !in_range_d((double)adapter_mad, cfg.adapter_mad_range[0], cfg.adapter_mad_range[1])) {
+            success = 0; fail = ADP_F_ADAPTER_MAD;
+        }
+        if (success && cfg.detect_open_pores) {
+            // V2: positions >= 200 pA; keep pos[i] (i >= 1) with a gap >= 10 to pos[i-1]; none kept -> [pos[-1]]
+            const int b = (int)(a_e < S ? a_e : S);
+            int npos = 0, nvalid = 0, prev_last = -1, lastpos = -1, lastvalid = -1;
+            for (int base = 0; base < b; base += 64) {
+                int i = base + ln;
+                bool f = (i < b) && (200.0f <= sig[i]);
+                unsigned long long mk = __ballot(f);
+                if (mk) {
+                    unsigned long long lower = mk & ((1ull << ln) - 1ull);
+                    int prev = lower ? (base + 63 - __clzll((long long)lower)) : prev_last;
+                    bool first_overall = (npos == 0) && (lower == 0);
+                    bool valid = f && !first_overall && (i - prev >= 10);
+                    unsigned long long vm = __ballot(valid);
+                    if (valid) {
+                        int slot = nvalid + __popcll(vm & ((1ull << ln) - 1ull));
+                        if (slot < ADP_MAX_OPEN_PORES) row->open_pores[slot] = i;
+                    }
+                    if (vm) lastvalid = base + 63 - __clzll((long long)vm);
+                    nvalid += __popcll(vm);
+                    npos += __popcll(mk);
+                    lastpos = base + 63 - __clzll((long long)mk);
+                    prev_last = lastpos;
+                }
+            }
+            long long last = -1;
+            if (npos == 0) n_open = 0;
+            else if (npos == 1 || nvalid == 0) { n_open = 1; last = lastpos; if (ln == 0) row->open_pores[0] = lastpos; }
+            else { n_open = nvalid; last = lastvalid; }
+            if (n_open > 0) {
+                a_s = last;
+                if (a_e - a_s < cfg.min_obs_adapter) { success = 0; fail = ADP_F_OPEN_PORE; }
+            }
+        }
+        if (success && cfg.real_signal_check) {
+            int a = (int)(a_s < S ? a_s : S), b = (int)(a_e < S ? a_e : S);
+            int n = b - a; if (n < 0) n = 0;
+            const float *x = sig + a;
+            bool ok = false;
+            if (n >= 2 * cfg.mean_window) {
+                float ms = wave_np_mean(x, cfg.mean_window, ws);
+                float me = wave_np_mean(x + n - cfg.mean_window, cfg.mean_window, ws);
+                rw.set(ADP_C_REAL_MEAN_START, (double)ms);
+                rw.set(ADP_C_REAL_MEAN_END, (double)me);
+                if (in_range_d((double)ms, cfg.mean_start_range[0], cfg.mean_start_range[1]) &&
+                    in_range_d((double)me, cfg.mean_end_range[0], cfg.mean_end_range[1])) {
+                    int k = n < cfg.max_obs_local_range ? n : cfg.max_obs_local_range;
+                    double lr = wave_percentile(x + n - k, k, 85.0, ws) - wave_percentile(x + n - k, k, 15.0, ws);
+                    rw.set(ADP_C_REAL_LOCAL_RANGE, lr);
+                    ok = in_range_d(lr, cfg.local_range[0], cfg.local_range[1]);
+                }
+            }
+            if (!ok) { success = 0; fail = ADP_F_REAL_RANGE; }
+        }
+        bool exception = false;
+        if (success && cfg.mvs_detect_check) {
+            if (p_best == 0) { success = 0; fail = ADP_F_NO_POLYA; }
+            else {
+                double pr0 = cfg.pA_mean_range[0], pr1 = cfg.pA_mean_range[1];
+                int exc = 0;
+                if (range_empty(cfg.pA_mean_range) && !range_empty(cfg.pA_mean_adapter_med_scale_range)) {
+                    pr0 = cfg.pA_mean_adapter_med_scale_range[0] * (double)adapter_med;
+                    pr1 = cfg.pA_mean_adapter_med_scale_range[1] * (double)adapter_med;
+                } else if (range_empty(cfg.pA_mean_range)) exc = ADP_F_EXC_PA_RANGE;
+                if (!exc && topk_none) exc = ADP_F_EXC_TOPK_NONE;
+                if (exc) { row_exception(row, exc); exception = true; }
+                for (int c = 0; !exception && c < in.kmax; c++) {
+                    long long p_e = bd[1 + c];
+                    if (p_e == 0) break;
+                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var);
+                    if (o.exc) { row_exception(row, o.exc); exception = true; break; }
+                    rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
+                    rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);
+                    rw.set(ADP_C_MVS_MED_SHIFT, o.shift);
+                    if (!o.ok) {
+                        success = 0; // never reset: later candidates only refresh the reported values
+                        if (o.mean == 0) { fail = ADP_F_MVS_NOT_ENOUGH; mvs_mask = 0; }
+                        else { fail = ADP_F_MVS_CHECKS; mvs_mask = o.vec_fail; }
+                    }
+                    if (success) { p_best = p_e; break; }
+                }
+            }
+        }
+        if (exception) continue;
+        if (success && cfg.detect_med_shift) {
+            long long w = cfg.med_shift_window;
+            long long r1 = a_e + w; if (r1 > full_len) r1 = full_len; if (r1 > S) r1 = S;
+            long long a = a_e < S ? a_e : S;
+            long long l0 = a_e - w; if (l0 < 0) l0 = 0; if (l0 > S) l0 = S;
+            float sh = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws);
+            rw.set(ADP_C_MED_SHIFT, (double)sh);
+            if (!in_range_d((double)sh, cfg.med_shift_range[0], cfg.med_shift_range[1])) { success = 0; fail = ADP_F_MED_SHIFT; }
+        }
+        partition_stats(sig, S, a_s, a_e, rw, ADP_C_ADAPTER_START, ADP_C_ADAPTER_LEN, ws, have_med && a_s == 0, adapter_med, adapter_mad);
+        partition_stats(sig, S, a_e, p_best, rw, ADP_C_POLYA_START, ADP_C_POLYA_LEN, ws, false, 0.f, 0.f);
+        partition_stats(sig, S, p_best, S, rw, ADP_C_RNA_START, ADP_C_RNA_LEN, ws, false, 0.f, 0.f);
+        rw.set(ADP_C_ADAPTER_END, (double)a_e);
+        rw.set(ADP_C_POLYA_END, (double)p_best);
+        rw.set(ADP_C_SIGNAL_LEN, (double)full_len);
+        rw.set(ADP_C_PRELOADED, (double)S);
+        rw.set(ADP_C_PRIMARY_ADAPTER_END, (double)a_in);
+        rw.set(ADP_C_PRIMARY_POLYA_END, (double)p_in);
+        if (ln == 0) {
+            if (!topk_none) {
+                int nc = in.kmax < ADP_MAX_CAND ? in.kmax : ADP_MAX_CAND;
+                row->n_cand = nc;
+                for (int c = 0; c < nc; c++) row->cand[c] = bd[1 + c];
+            }
+            row->n_open_pores = n_open;
+            row->present = rw.present;
+            row->success = success;
+            row->fail_code = fail;
+            row->mvs_fail_mask = mvs_mask;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K1 start peak
+struct SpOut {
+    int32_t valid, flagged_type, has_open_pore, pad;
+    int64_t start_peak_idx, next_greater_idx, open_pore_idx;
+    float start_peak_pa, next_greater_pa;
+};
+
+static __device__ __forceinline__ float sp_pooled(const float *row, int m, int ds, int j)
+{
+    // mean-pool of the RAW signal, zero padded tail, numpy order
+    const int b = j * ds;
+    return pw_leaf_f32(ds, [&](int k) { int i = b + k; return i < m ? row[i] : 0.0f; }) / (float)ds;
+}
+
+// detect_rna_start_peak (reference adapted/detect/start_peak.py:7-119); grid = n_reads waves
+__global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+                                                   int m, adp_cfg cfg, SpOut *__restrict__ out)
+{
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    const float *row = sigs + (size_t)r * m;
+    const int ds = cfg.sp_downscale_factor;
+    const int off1 = cfg.sp_offset1, spmax = cfg.start_peak_max_idx, off2 = cfg.sp_offset2;
+    const long long fl = full_len[r];
+    const int end_idx = (int)((fl < m ? fl : m) / ds);
+    const int L = (m + ds - 1) / ds;
+    SpOut o; memset(&o, 0, sizeof(o));
+    // open pore: first raw sample above the threshold among the first end_idx RAW samples
+    int op = 0x7fffffff;
+    const float thr = (float)cfg.open_pore_pa;
+    for (int base = 0; base < end_idx && base < m; base += 64) {
+        int i = base + ln;
+        bool f = i < end_idx && i < m && row[i] > thr;
+        unsigned long long mk = __ballot(f);
+        if (mk) { op = base + __ffsll((long long)mk) - 1; break; }
+    }
+    op = (op == 0x7fffffff) ? 0 : op / ds;
+    const bool has_op = op > 0;
+    const int a = min(off1, L), b = min(spmax, L);
+    bool valid = (b - a > 0);
+    float mx = 0.f; int max_idx = 0;
+    if (valid) {
+        float lm = -__builtin_inff(); bool anynan = false;
+        for (int j = a + ln; j < b; j += 64) { float v = sp_pooled(row, m, ds, j); if (v != v) anynan = true; else if (v > lm) lm = v; }
+        anynan = __any(anynan);
+        mx = anynan ? __builtin_nanf("") : wave_max(lm);
+        int first = 0x7fffffff;
+        for (int j = a + ln; j < b; j += 64) { if (sp_pooled(row, m, ds, j) == mx) first = min(first, j); }
+        first = wave_min(first);
+        max_idx = (first == 0x7fffffff ? 0 : first - a) + off1;
+    }
+    const int s0 = spmax + off2;
+    const int e0 = min(end_idx, L), a2 = min(s0, L);
+    if (valid && e0 - a2 <= 0) valid = false;
+    int nxt = 0;
+    if (valid) {
+        int hit = 0x7fffffff;
+        for (int base = a2; base < e0; base += 64) {
+            int j = base + ln;
+            bool f = j < e0 && sp_pooled(row, m, ds, j) > mx;
+            unsigned long long mk = __ballot(f);
+            if (mk) { hit = base + __ffsll((long long)mk) - 1; break; }
+        }
+        nxt = (hit == 0x7fffffff ? 0 : hit - a2) + s0;
+        if (nxt >= L) valid = false;
+    }
+    if (valid) {
+        o.valid = 1;
+        o.start_peak_idx = (int64_t)max_idx * ds; o.start_peak_pa = mx;
+        o.next_greater_idx = (int64_t)nxt * ds; o.next_greater_pa = sp_pooled(row, m, ds, nxt);
+        if (has_op) {
+            if (fabs((double)nxt - (double)op) <= 2.0 + 0.01 * fabs((double)op)) o.flagged_type = 1;
+            else if (max_idx < op && op < nxt) o.flagged_type = 2;
+            if (o.flagged_type) { o.has_open_pore = 1; o.open_pore_idx = (int64_t)op * ds; }
+        }
+    }
+    if (ln == 0) out[r] = o;
+}
+
+// start-peak columns into rows written by k_validate; mode 0: LLR extension (decorate only),
+// mode 1: combined_detect_start_peak semantics (flag => failure), any_none => slice TypeError for all
+__global__ void k_sp_decorate(const SpOut *__restrict__ sp, adp_row *__restrict__ rows, int n_reads, int mode,
+                              const int32_t *__restrict__ any_none)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    adp_row *o = rows + r;
+    if (mode == 1 && any_none && any_none[0]) {
+        memset(o, 0, sizeof(*o)); o->n_cand = -1; o->n_open_pores = -1; o->success = 0; o->fail_code = ADP_F_EXC_SLICE;
+        return;
+    }
+    if (o->fail_code >= ADP_F_EXC_TOPK_NONE) return;
+    SpOut s = sp[r];
+    if (!s.valid) return;
+    if (mode == 0 && o->present == 0) return; // dropped minibatch
+    o->col[ADP_C_SP_IDX] = (double)s.start_peak_idx;
+    o->col[ADP_C_SP_PA] = (double)s.start_peak_pa;
+    o->col[ADP_C_SP_NEXT_IDX] = (double)s.next_greater_idx;
+    o->col[ADP_C_SP_NEXT_PA] = (double)s.next_greater_pa;
+    unsigned long long pres = o->present | (1ull << ADP_C_SP_IDX) | (1ull << ADP_C_SP_PA) | (1ull << ADP_C_SP_NEXT_IDX) |
+                              (1ull << ADP_C_SP_NEXT_PA);
+    if (s.has_open_pore) { o->col[ADP_C_SP_OPEN_PORE_IDX] = (double)s.open_pore_idx; pres |= 1ull << ADP_C_SP_OPEN_PORE_IDX; }
+    o->present = pres;
+    o->start_peak_type = s.flagged_type;
+    if (mode == 1 && s.flagged_type) o->success = 0;
+}
+
+// bounds for the start-peak primary: adapter_end = polya_end = next_greater_idx; topk None
+__global__ void k_sp_bounds(const SpOut *__restrict__ sp, int n_reads, int64_t *__restrict__ bounds, int8_t *__restrict__ topk_none,
+                            int32_t *__restrict__ any_none)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    SpOut s = sp[r];
+    bounds[2 * r] = s.valid ? s.next_greater_idx : 0;
+    bounds[2 * r + 1] = s.valid ? s.next_greater_idx : 0;
+    topk_none[r] = 1;
+    if (!s.valid) atomicExch(any_none, 1);
+}
+
+// bounds for the LLR primary from pooled-unit indices
+__global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int32_t *__restrict__ polya_idx, int n_reads, int ds,
+                             int off, int64_t *__restrict__ bounds, int8_t *__restrict__ topk_none)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int a = adapter_idx[r], p = polya_idx[r];
+    int64_t ae = (a > 0) ? (int64_t)a * ds + off : 0;
+    int64_t pe = (a >= 0 && p > 0) ? (int64_t)p * ds + off : 0;
+    bounds[2 * r] = ae;
+    bounds[2 * r + 1] = pe;
+    topk_none[r] = (pe > 0) ? 0 : 1; // polya_end_topk is only assigned when a poly(A) end was found
+}

@@ -1,0 +1,223 @@
+// wave_stats.h -- exact order statistics and numpy-ordered float32 reductions over a segment
+// of one read, cooperatively by the 64 lanes of one wave (blockDim.x == 64).
+//
+// These restate what the reference obtains from numpy on float32 slices (np.median,
+// np.percentile(linear), np.mean/np.var/np.std: reference adapted/partition/
+// signal_partitions.py:81-96, adapted/detect/mvs.py:88-129, adapted/detect/real_range.py:46-58)
+// so that the device reproduces the same float32 values:
+//   * selection: MSB-first 8-bit radix select on order-preserving keys, 4 passes over the
+//     segment (L2/MALL resident between passes), 256-bin histogram in LDS with a wave-uniform
+//     fast path (one add when all 64 lanes hit the same bin, the common case for the top byte).
+//     The (k-1)-th value comes out of the same 4 passes (needed for even-count medians and for
+//     percentile interpolation).
+//   * sums: numpy's add.reduce order (8192-element chunks accumulated in sequence; each chunk a
+//     balanced pairwise tree over 128-element leaves summed with 8 interleaved accumulators).
+//     A full chunk is staged through LDS in two halves; lane l sums leaf l and the tree is a
+//     xor-butterfly.  Ragged tail chunks follow the same recursion generically.
+#pragma once
+#include "common.h"
+
+#define WS_STAGE_FLOATS (32 * 129)
+#define WS_LEAFBUF 160
+
+struct WaveScratch {
+    uint32_t hist[256];
+    float stage[WS_STAGE_FLOATS];
+    float leaf[WS_LEAFBUF];
+};
+
+// transform applied on load: mode 0: x; mode 1: |x - c| (float32); mode 2: (x - c)^2 (float32)
+static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
+{
+    if (mode == 0) return x;
+    float d = x - c;
+    return mode == 1 ? fabsf(d) : d * d;
+}
+
+// ---------------------------------------------------------------- selection
+// x_(k) and x_(k-1) of xform(x[0..n)), 0 <= k < n.  All lanes return the same values.
+static __device__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, WaveScratch *ws,
+                                    float &vk, float &vkm1)
+{
+    const int ln = lane_id();
+    uint32_t prefix = 0, below = 0;
+    int krem = k;
+    int rank_in_bin = 0, lowbin = -1;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 24 - 8 * pass;
+        for (int i = ln; i < 256; i += 64) ws->hist[i] = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int i = base + u * 64 + ln;
+                uint32_t key = f2key(ws_xform(v[u], mode, c));
+                bool act = i < n;
+                if (pass > 0) {
+                    uint32_t top = key >> (shift + 8);
+                    if (pass == 3 && act && top < prefix && key > below) below = key;
+                    act = act && (top == prefix);
+                }
+                uint32_t digit = (key >> shift) & 255u;
+                unsigned long long m = __ballot(act);
+                if (m) {
+                    int f = __ffsll((long long)m) - 1;
+                    uint32_t d0 = __shfl(digit, f);
+                    bool same = !act || digit == d0;
+                    if (__all(same)) { if (ln == f) ws->hist[d0] += (uint32_t)__popcll(m); }
+                    else if (act) atomicAdd(&ws->hist[digit], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // locate the bin of rank krem: each lane owns 4 consecutive bins
+        uint32_t h0 = ws->hist[4 * ln], h1 = ws->hist[4 * ln + 1], h2 = ws->hist[4 * ln + 2], h3 = ws->hist[4 * ln + 3];
+        int s = (int)(h0 + h1 + h2 + h3);
+        int incl = wave_scan_incl(s);
+        int excl = incl - s;
+        bool mine = krem >= excl && krem < incl;
+        int bin = 0, before = 0;
+        if (mine) {
+            int cacc = excl;
+            if (krem < cacc + (int)h0) { bin = 4 * ln; before = cacc; }
+            else { cacc += h0;
+                if (krem < cacc + (int)h1) { bin = 4 * ln + 1; before = cacc; }
+                else { cacc += h1;
+                    if (krem < cacc + (int)h2) { bin = 4 * ln + 2; before = cacc; }
+                    else { cacc += h2; bin = 4 * ln + 3; before = cacc; } } }
+        }
+        unsigned long long mm = __ballot(mine);
+        int src = __ffsll((long long)mm) - 1;
+        bin = __shfl(bin, src);
+        before = __shfl(before, src);
+        if (pass == 3) {
+            rank_in_bin = krem - before;
+            int cand = -1; // largest non-empty bin below `bin` among this lane's four
+            if (4 * ln < bin && h0) cand = 4 * ln;
+            if (4 * ln + 1 < bin && h1) cand = 4 * ln + 1;
+            if (4 * ln + 2 < bin && h2) cand = 4 * ln + 2;
+            if (4 * ln + 3 < bin && h3) cand = 4 * ln + 3;
+            lowbin = wave_max(cand);
+        }
+        prefix = (prefix << 8) | (uint32_t)bin;
+        krem -= before;
+        __syncthreads();
+    }
+    vk = key2f(prefix);
+    vkm1 = vk;
+    if (rank_in_bin == 0 && k > 0) {
+        below = wave_max(below);
+        uint32_t k0 = below;
+        if (lowbin >= 0) { uint32_t ka = (prefix & ~255u) | (uint32_t)lowbin; if (ka > k0) k0 = ka; }
+        vkm1 = key2f(k0);
+    }
+}
+
+// np.median(xform(x[0..n))) for a NaN-free float32 segment
+static __device__ float wave_median(const float *x, int n, int mode, float c, WaveScratch *ws)
+{
+    if (n <= 0) return __builtin_nanf("");
+    float vk, vkm1;
+    wave_select2(x, n, n / 2, mode, c, ws, vk, vkm1);
+    if (n & 1) return vk;
+    return (vkm1 + vk) / 2.0f;
+}
+
+// one np.percentile(x, q) value (linear method): virtual index (n-1)*q/100 in float64,
+// diff in float32, interpolation in float64 (numpy/lib/_function_base_impl.py _lerp)
+static __device__ double wave_percentile(const float *x, int n, double q100, WaveScratch *ws)
+{
+    double q = q100 / 100.0;
+    double vi = (double)(n - 1) * q;
+    int lo = (int)floor(vi);
+    if (lo < 0) lo = 0;
+    if (lo > n - 1) lo = n - 1;
+    int hi = min(lo + 1, n - 1);
+    double g = vi - (double)lo;
+    float vk, vkm1;
+    wave_select2(x, n, hi, 0, 0.0f, ws, vk, vkm1);
+    float a = (hi == lo) ? vk : vkm1;
+    float b = vk;
+    float diff = b - a;
+    double r = (double)a + (double)diff * g;
+    if (g >= 0.5) r = (double)b - (double)diff * (1.0 - g);
+    return r;
+}
+
+// ---------------------------------------------------------------- numpy-ordered sums
+static __device__ void ws_enum_leaves(const float *x, int off, int len, int mode, float c, WaveScratch *ws, int &id)
+{
+    if (len <= 128) {
+        if ((id & 63) == lane_id()) {
+            const float *p = x + off;
+            ws->leaf[id] = pw_leaf_f32(len, [&](int i) { return ws_xform(p[i], mode, c); });
+        }
+        id++;
+        return;
+    }
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    ws_enum_leaves(x, off, n2, mode, c, ws, id);
+    ws_enum_leaves(x, off + n2, len - n2, mode, c, ws, id);
+}
+
+static __device__ float ws_eval_tree(int len, const WaveScratch *ws, int &id)
+{
+    if (len <= 128) return ws->leaf[id++];
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    float a = ws_eval_tree(n2, ws, id);
+    float b = ws_eval_tree(len - n2, ws, id);
+    return a + b;
+}
+
+// np.add.reduce(xform(x[0..n))) in float32 with numpy's association
+static __device__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, WaveScratch *ws)
+{
+    const int ln = lane_id();
+    float total = 0.0f;
+    for (int s = 0; s < n; s += 8192) {
+        const int len = min(8192, n - s);
+        float chunk;
+        if (len == 8192) {
+            float leafsum = 0.0f;
+            for (int half = 0; half < 2; half++) {
+                __syncthreads();
+                const float *p = x + s + half * 4096;
+                for (int t = 0; t < 64; t++) {
+                    int e = t * 64 + ln;
+                    ws->stage[(e >> 7) * 129 + (e & 127)] = ws_xform(p[e], mode, c);
+                }
+                __syncthreads();
+                if ((ln >> 5) == half) {
+                    const float *q = ws->stage + (ln & 31) * 129;
+                    leafsum = pw_leaf_f32(128, [&](int i) { return q[i]; });
+                }
+            }
+            for (int o = 1; o < 64; o <<= 1) leafsum = leafsum + __shfl_xor(leafsum, o);
+            chunk = leafsum;
+        } else {
+            int id = 0;
+            __syncthreads();
+            ws_enum_leaves(x + s, 0, len, mode, c, ws, id);
+            __syncthreads();
+            int id2 = 0;
+            chunk = ws_eval_tree(len, ws, id2); // every lane evaluates the same small tree
+        }
+        total += chunk;
+    }
+    return total;
+}
+
+static __device__ float wave_np_mean(const float *x, int n, WaveScratch *ws) { return wave_np_sum(x, n, 0, 0.0f, ws) / (float)n; }
+
+// np.var: mean in float32, squared deviations in float32, sum / n
+static __device__ float wave_np_var(const float *x, int n, WaveScratch *ws, float *mean_out)
+{
+    float mu = wave_np_mean(x, n, ws);
+    if (mean_out) *mean_out = mu;
+    return wave_np_sum(x, n, 2, mu, ws) / (float)n;
+}

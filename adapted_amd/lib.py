@@ -1,0 +1,361 @@
+"""ctypes binding of libadapted_hip.so (include/adapted_hip.h) and the row <-> DetectResults
+conversion shared by the operators and the CSV writer.
+
+There is no CPU fallback: if the HIP library cannot be loaded the import of this module's
+``load()`` fails loudly, and every operator of the package goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import build as _build
+from .container_types import DetectResults
+
+_LIB = None
+
+NCOL = 38
+MAX_CAND = 16
+MAX_OPEN_PORES = 16
+
+ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK = 1, 2, 4
+MB_OK, MB_MAD_ZERO, MB_EMPTY_TRACE = 0, 1, 2
+
+COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len", "adapter_mean",
+        "adapter_std", "adapter_med", "adapter_mad", "polya_start", "polya_end", "polya_len",
+        "polya_mean", "polya_std", "polya_med", "polya_mad", "rna_preloaded_start",
+        "rna_preloaded_len", "rna_preloaded_mean", "rna_preloaded_std", "rna_preloaded_med",
+        "rna_preloaded_mad", "start_peak_idx", "start_peak_pa", "start_peak_next_max_idx",
+        "start_peak_next_max_pa", "start_peak_open_pore_idx", "adapter_rna_median_shift",
+        "{primary}_adapter_end", "{primary}_polya_end", "mvs_detect_mean_at_loc",
+        "mvs_detect_var_at_loc", "mvs_detect_polya_med", "mvs_detect_polya_local_range",
+        "mvs_detect_med_shift", "real_adapter_mean_start", "real_adapter_mean_end",
+        "real_adapter_local_range"]
+assert len(COLS) == NCOL
+_INT_COLS = {0, 1, 2, 3, 4, 9, 10, 11, 16, 17, 22, 24, 26, 28, 29}
+# columns the reference holds as numpy float32 scalars (kept as float32 so that the CSV
+# writer rounds them like pandas does)
+_F32_COLS = {23, 25, 27}
+
+ROW_DTYPE = np.dtype([("col", "<f8", (NCOL,)), ("present", "<u8"), ("success", "<i4"), ("fail_code", "<i4"),
+                      ("mvs_fail_mask", "<i4"), ("start_peak_type", "<i4"), ("n_cand", "<i4"),
+                      ("n_open_pores", "<i4"), ("cand", "<i8", (MAX_CAND,)), ("open_pores", "<i4", (MAX_OPEN_PORES,))])
+
+FAIL_REASONS = {
+    0: None,
+    1: "No adapter detected (primary)",
+    2: "adapter MAD check failed",
+    3: "Open pore too close to boundary",
+    4: "Real signal check failed",
+    5: "No polya detected (primary)",
+    6: "MVS polya check failed: not enough signal",
+    7: "MVS polya check failed: ",
+    8: "Median shift check failed",
+    9: "'NoneType' object is not iterable",
+    10: "slice indices must be integers or None or have an __index__ method",
+    11: "Moving window must between 1 and n, inclusive",
+    12: "pA_mean_range is not specified",
+}
+_MVS_NAMES = ["mean", "var", "med", "range", "shift"]
+START_PEAK_TYPES = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
+PRIMARY_CODE = {"llr": 0, "cnn": 1, "start_peak": 2}
+
+
+class AdpCfg(C.Structure):
+    _fields_ = [
+        ("min_obs_adapter", C.c_int32), ("max_obs_adapter", C.c_int32), ("min_obs_polya", C.c_int32),
+        ("downscale_factor", C.c_int32), ("max_obs_trace", C.c_int32), ("primary_method", C.c_int32),
+        ("sig_norm_outlier_thresh", C.c_double),
+        ("adapter_peak_prominence", C.c_double), ("adapter_peak_rel_height", C.c_double),
+        ("adapter_peak_width", C.c_int32),
+        ("mvs_detect_check", C.c_int32), ("mvs_detect_overwrite", C.c_int32), ("search_window", C.c_int32),
+        ("pA_mean_window", C.c_int32), ("pA_var_window", C.c_int32), ("median_shift_window", C.c_int32),
+        ("polyA_window", C.c_int32),
+        ("pA_mean_range", C.c_double * 2), ("pA_var_range", C.c_double * 2),
+        ("median_shift_range", C.c_double * 2), ("polyA_med_range", C.c_double * 2),
+        ("polyA_local_range", C.c_double * 2), ("pA_mean_adapter_med_scale_range", C.c_double * 2),
+        ("detect_open_pores", C.c_int32), ("real_signal_check", C.c_int32), ("mean_window", C.c_int32),
+        ("max_obs_local_range", C.c_int32),
+        ("mean_start_range", C.c_double * 2), ("mean_end_range", C.c_double * 2),
+        ("local_range", C.c_double * 2), ("adapter_mad_range", C.c_double * 2),
+        ("detect_med_shift", C.c_int32), ("med_shift_window", C.c_int32), ("med_shift_range", C.c_double * 2),
+        ("sp_downscale_factor", C.c_int32), ("start_peak_max_idx", C.c_int32), ("sp_offset1", C.c_int32),
+        ("sp_offset2", C.c_int32), ("open_pore_pa", C.c_double),
+        ("polya_cand_k", C.c_int32), ("fallback_to_llr_short_reads", C.c_int32),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (building if needed) libadapted_hip.so.  Raises HipLibraryError if impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    try:
+        path = _build.build()
+        lib = C.CDLL(path)
+    except Exception as e:  # no CPU fallback by design
+        raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
+    if lib.adp_sizeof_cfg() != C.sizeof(AdpCfg) or lib.adp_sizeof_row() != ROW_DTYPE.itemsize:
+        raise HipLibraryError("ABI mismatch between adapted_amd/lib.py and libadapted_hip.so")
+    lib.adp_last_error.restype = C.c_char_p
+    lib.adp_stream.restype = C.c_void_p
+    _LIB = lib
+    return lib
+
+
+EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_error", "adp_device_count", "adp_create",
+           "adp_destroy", "adp_set_config", "adp_stream", "adp_synchronize", "adp_detect_llr", "adp_detect_start_peak",
+           "adp_cnn_prepare", "adp_validate_candidates", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
+           "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
+           "adp_debug_llr_upto"]
+
+
+def _rng(r):
+    lo = -np.inf if r is None or r[0] is None else float(r[0])
+    hi = np.inf if r is None or r[1] is None else float(r[1])
+    return (C.c_double * 2)(lo, hi)
+
+
+def make_cfg(spc) -> AdpCfg:
+    c = AdpCfg()
+    co = spc.core
+    c.min_obs_adapter, c.max_obs_adapter, c.min_obs_polya = int(co.min_obs_adapter), int(co.max_obs_adapter), int(co.min_obs_polya)
+    c.downscale_factor, c.max_obs_trace = int(co.downscale_factor), int(co.max_obs_trace)
+    c.primary_method = PRIMARY_CODE[spc.primary_method]
+    c.sig_norm_outlier_thresh = float(co.sig_norm_outlier_thresh)
+    L = spc.llr_boundaries
+    c.adapter_peak_prominence, c.adapter_peak_rel_height = float(L.adapter_peak_prominence), float(L.adapter_peak_rel_height)
+    c.adapter_peak_width = int(L.adapter_peak_width)
+    M = spc.mvs_polya
+    for k in ("mvs_detect_check", "mvs_detect_overwrite", "search_window", "pA_mean_window", "pA_var_window",
+              "median_shift_window", "polyA_window"):
+        setattr(c, k, int(getattr(M, k)))
+    for k in ("pA_mean_range", "pA_var_range", "median_shift_range", "polyA_med_range", "polyA_local_range",
+              "pA_mean_adapter_med_scale_range"):
+        setattr(c, k, _rng(getattr(M, k)))
+    R = spc.real_range
+    for k in ("detect_open_pores", "real_signal_check", "mean_window", "max_obs_local_range"):
+        setattr(c, k, int(getattr(R, k)))
+    for k in ("mean_start_range", "mean_end_range", "local_range", "adapter_mad_range"):
+        setattr(c, k, _rng(getattr(R, k)))
+    c.detect_med_shift, c.med_shift_window = int(spc.med_shift.detect_med_shift), int(spc.med_shift.med_shift_window)
+    c.med_shift_range = _rng(spc.med_shift.med_shift_range)
+    S = spc.rna_start_peak
+    c.sp_downscale_factor, c.start_peak_max_idx = int(S.downscale_factor), int(S.start_peak_max_idx)
+    c.sp_offset1, c.sp_offset2, c.open_pore_pa = int(S.offset1), int(S.offset2), float(S.open_pore_pa)
+    c.polya_cand_k = int(spc.cnn_boundaries.polya_cand_k)
+    c.fallback_to_llr_short_reads = int(spc.cnn_boundaries.fallback_to_llr_short_reads)
+    return c
+
+
+def fail_reason_of(row) -> Optional[str]:
+    fc = int(row["fail_code"])
+    fr = FAIL_REASONS[fc]
+    if fc == 7:
+        fr += " ".join(n for b, n in enumerate(_MVS_NAMES) if int(row["mvs_fail_mask"]) >> b & 1)
+    return fr
+
+
+def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
+    """adp_row[] -> DetectResults, value for value what the reference's validate_boundaries
+    returns (types: python int / float, np.float32 where the reference keeps numpy scalars)."""
+    out = []
+    names = [c.format(primary=primary) for c in COLS]
+    for r in rows:
+        fc = int(r["fail_code"])
+        if fc >= 9:  # the reference raised inside its per-read try block
+            out.append(DetectResults(success=False, fail_reason=fail_reason_of(r)))
+            continue
+        d = DetectResults(success=bool(r["success"]))
+        pres = int(r["present"])
+        col = r["col"]
+        for i, name in enumerate(names):
+            if pres >> i & 1:
+                v = col[i]
+                if i in _INT_COLS:
+                    v = int(v)
+                elif i in _F32_COLS:
+                    v = np.float32(v)
+                else:
+                    v = float(v)
+                setattr(d, name, v)
+        nc = int(r["n_cand"])
+        if nc >= 0:
+            d.polya_candidates = np.asarray(r["cand"][:nc], dtype=np.int64)
+        no = int(r["n_open_pores"])
+        if no >= 0:
+            d.open_pores = np.asarray(r["open_pores"][:min(no, MAX_OPEN_PORES)], dtype=np.int64)
+        d.mvs_llr_polya_end_adjust_ignored = False
+        d.mvs_llr_polya_end_to_early_stop = False
+        fr = fail_reason_of(r)
+        spt = START_PEAK_TYPES[int(r["start_peak_type"])]
+        d.start_peak_open_pore_type = spt
+        if primary == "start_peak":
+            if fr is not None and spt is not None:
+                fr = fr + "+" + spt
+        else:
+            d.llr_detect_log = "" if primary == "llr" else None
+        d.fail_reason = fr
+        out.append(d)
+    return out
+
+
+class Engine:
+    """One GPU's detect engine: a handle of libadapted_hip.so sized for (max_reads, m)."""
+
+    def __init__(self, spc, max_reads: int, m: int, device: int = 0):
+        self.lib = load()
+        self.spc = spc
+        self.cfg = make_cfg(spc)
+        self.max_reads, self.m, self.device = int(max_reads), int(m), int(device)
+        self._h = C.c_void_p()
+        self._check(self.lib.adp_create(self.device, C.byref(self.cfg), self.max_reads, self.m, C.byref(self._h)))
+
+    # -- plumbing ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc < 0:
+            raise HipLibraryError("libadapted_hip: error %d: %s" % (rc, self.lib.adp_last_error().decode()))
+        return rc
+
+    def close(self):
+        if self._h:
+            self.lib.adp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, spc):
+        self.spc = spc
+        self.cfg = make_cfg(spc)
+        self._check(self.lib.adp_set_config(self._h, C.byref(self.cfg)))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.adp_stream(self._h) or 0)
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.adp_set_profiling(self._h, int(on)))
+
+    def kernel_times(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        k = self._check(self.lib.adp_kernel_times(self._h, names, ms, cap))
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    # -- device memory ------------------------------------------------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.adp_dev_alloc(self._h, C.c_uint64(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def dev_free(self, ptr: int):
+        self._check(self.lib.adp_dev_free(self._h, C.c_void_p(ptr)))
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        self._check(self.lib.adp_memcpy_h2d(self._h, C.c_void_p(dst), a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
+
+    def d2h(self, arr: np.ndarray, src: int):
+        assert arr.flags.c_contiguous
+        self._check(self.lib.adp_memcpy_d2h(self._h, arr.ctypes.data_as(C.c_void_p), C.c_void_p(src), C.c_uint64(arr.nbytes)))
+
+    def synth_fill(self, dev_signals: int, dev_full_len: Optional[int], n: int, seed: int, first_read: int,
+                   decorate: bool = True):
+        self._check(self.lib.adp_synth_fill(self._h, C.c_void_p(dev_signals), C.c_void_p(dev_full_len or 0), int(n), self.m,
+                                            C.c_uint32(seed), C.c_uint32(first_read), int(decorate)))
+
+    # -- operators ------------------------------------------------------------------------
+    def _in_ptrs(self, signals, full_lens, n, device_ptrs):
+        if device_ptrs:
+            return C.c_void_p(int(signals)), C.c_void_p(int(full_lens)), ADP_IN_DEVICE, None
+        sig = np.ascontiguousarray(signals, dtype=np.float32)
+        lens = np.ascontiguousarray(full_lens, dtype=np.int32)
+        if sig.ndim != 2 or sig.shape != (n, self.m) or lens.shape != (n,):
+            raise ValueError("signals must be float32 [n, %d] and full_lens int32 [n]" % self.m)
+        return sig.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), 0, (sig, lens)
+
+    def detect_llr_rows(self, signals, full_lens, n: int, minibatch: int, with_start_peak: bool = False,
+                        device_ptrs: bool = False, rows_dev: Optional[int] = None):
+        """-> (rows ndarray[ROW_DTYPE] or None when rows_dev is given, mb_status int32[n_mb])"""
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        if with_start_peak:
+            flags |= ADP_WITH_START_PEAK
+        n_mb = (n + minibatch - 1) // minibatch
+        mbs = np.zeros(n_mb, dtype=np.int32)
+        if rows_dev is not None:
+            flags |= ADP_OUT_DEVICE
+            rows, rp = None, C.c_void_p(rows_dev)
+        else:
+            rows = np.zeros(n, dtype=ROW_DTYPE)
+            rp = rows.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.adp_detect_llr(self._h, sp, lp, int(n), self.m, int(minibatch), flags, rp,
+                                            mbs.ctypes.data_as(C.c_void_p)))
+        del keep
+        return rows, mbs
+
+    def detect_start_peak_rows(self, signals, full_lens, n: int, minibatch: int, device_ptrs: bool = False):
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        self._check(self.lib.adp_detect_start_peak(self._h, sp, lp, int(n), self.m, int(minibatch), flags,
+                                                   rows.ctypes.data_as(C.c_void_p)))
+        del keep
+        return rows
+
+    def validate_rows(self, signals, full_lens, n: int, bounds: np.ndarray, device_ptrs: bool = False):
+        """bounds int64 [n, 1+k] (host) -> rows"""
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        b = np.ascontiguousarray(bounds, dtype=np.int64)
+        k = b.shape[1] - 1
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        if device_ptrs:
+            # bounds stay on the host: stage them through a device buffer
+            nb = self.dev_alloc(b.nbytes)
+            try:
+                self.h2d(nb, b)
+                self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, C.c_void_p(nb), int(k), flags,
+                                                             rows.ctypes.data_as(C.c_void_p)))
+            finally:
+                self.dev_free(nb)
+        else:
+            self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, b.ctypes.data_as(C.c_void_p), int(k),
+                                                         flags, rows.ctypes.data_as(C.c_void_p)))
+        del keep
+        return rows
+
+    # -- debug (tests) ------------------------------------------------------------------------
+    def debug_llr_upto(self, signals, full_lens, n, minibatch, stage):
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, False)
+        self._check(self.lib.adp_debug_llr_upto(self._h, sp, lp, int(n), self.m, int(minibatch), flags, int(stage)))
+        del keep
+
+    def debug_fetch(self, what: int, n: int):
+        lp = np.zeros(1, dtype=np.int32)
+        self._check(self.lib.adp_debug_fetch(self._h, 6, lp.ctypes.data_as(C.c_void_p), C.c_uint64(4)))
+        Lp = int(lp[0])
+        if what == 6:
+            return Lp
+        shapes = {1: ((n,), np.int32), 2: ((n, Lp), np.float32), 3: ((n, Lp), np.float64), 4: ((n,), np.int32),
+                  5: ((n,), np.int32), 7: ((n, 2), np.int32)}
+        if what == 0:
+            raise ValueError("use debug_norm_params")
+        shp, dt = shapes[what]
+        a = np.zeros(shp, dtype=dt)
+        self._check(self.lib.adp_debug_fetch(self._h, what, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
+        return a
+
+    def debug_norm_params(self, n_mb: int):
+        a = np.zeros((n_mb, 4), dtype=np.float64)
+        self._check(self.lib.adp_debug_fetch(self._h, 0, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
+        return a

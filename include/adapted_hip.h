@@ -1,0 +1,194 @@
+/*
+ * adapted_hip.h -- C ABI of libadapted_hip.so: the MI355X (gfx950) implementation of the
+ * `adapted detect` signal-segmentation hot path.
+ *
+ * Drop-in boundary.  The reference (KleistLab/ADAPTed v0.2.4) exposes this path as Python
+ * operators over one dense minibatch; each entry point below replaces one of them
+ * (file:line under the reference tree):
+ *
+ *   adp_detect_llr          <- combined_detect_llr2(batch f32[N,m], full_lens i32[N], spc)
+ *                              adapted/detect/combined.py:122-227   (called from
+ *                              adapted/file_proc.py:230-235), which itself wraps the only
+ *                              native code of the reference, adapted/detect/_c_llr.pyx:
+ *                              c_llr_trace :202-236, c_llr_trace_gains :176-199, _gains :67-88
+ *   adp_detect_start_peak   <- combined_detect_start_peak(...)   adapted/detect/combined.py:312-355
+ *                              (detect_rna_start_peak, adapted/detect/start_peak.py:7-119)
+ *   adp_cnn_prepare         <- prepare_data(...)                 adapted/detect/cnn.py:70-82
+ *   adp_validate_candidates <- the validate_boundaries loop of combined_detect_cnn
+ *                              adapted/detect/combined.py:243-305 (the conv net itself runs
+ *                              in PyTorch-ROCm, as BASELINE.json:north_star prescribes)
+ *   adp_cfg                 <- SigProcConfig                     adapted/config/sig_proc.py:161-221
+ *   adp_row                 <- DetectResults                     adapted/container_types.py:23-92
+ *
+ * Conventions: plain C, caller-allocated outputs, no exceptions.  Every function returns 0
+ * or a negative ADP_ERR_* code.  A handle owns one device, one HIP stream and its workspace;
+ * it is not thread-safe, distinct handles are independent.  `signals` is the reference's
+ * minibatch layout (adapted/file_proc.py:143-190): row-major float32 [n_reads, m], NaN from
+ * each read's end to m; full_len[i] is the read's true length (may exceed m).  A call may
+ * carry several minibatches: reads [k*minibatch, (k+1)*minibatch) form minibatch k, and the
+ * LLR path normalises with ONE median/MAD per minibatch exactly as the reference does
+ * (adapted/detect/normalize.py:15-22 on the 2-D array).
+ */
+#ifndef ADAPTED_HIP_H
+#define ADAPTED_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADP_ABI_VERSION 1
+
+/* error codes */
+#define ADP_OK 0
+#define ADP_ERR_INVALID (-1)       /* bad argument */
+#define ADP_ERR_HIP (-2)           /* a HIP runtime call failed (see adp_last_error) */
+#define ADP_ERR_CAPACITY (-3)      /* n_reads / m exceed what the handle was created for */
+#define ADP_ERR_UNSUPPORTED (-4)   /* config outside the implemented surface */
+/* per-minibatch status (mb_status[]): the reference raises and drops the minibatch */
+#define ADP_MB_OK 0
+#define ADP_MB_MAD_ZERO 1          /* "MAD normalization failed: scale is 0" normalize.py:56-59 */
+#define ADP_MB_EMPTY_TRACE 2       /* a read has no valid pooled block: np.argmin of an empty
+                                      trace, adapted/detect/llr.py:136 */
+
+/* memory-kind flags */
+#define ADP_IN_DEVICE 1            /* signals / full_len are device pointers */
+#define ADP_OUT_DEVICE 2           /* rows_out is a device pointer */
+#define ADP_WITH_START_PEAK 4      /* LLR path: also fill the start_peak_* columns (extension) */
+
+/* SigProcConfig, flattened.  Ranges are [lo, hi] with -inf/+inf for "None". */
+typedef struct adp_cfg {
+    int32_t min_obs_adapter, max_obs_adapter, min_obs_polya, downscale_factor, max_obs_trace;
+    int32_t primary_method;            /* 0 llr, 1 cnn, 2 start_peak: names the *_adapter_end columns */
+    double sig_norm_outlier_thresh;
+    double adapter_peak_prominence, adapter_peak_rel_height;
+    int32_t adapter_peak_width;
+    int32_t mvs_detect_check, mvs_detect_overwrite, search_window;
+    int32_t pA_mean_window, pA_var_window, median_shift_window, polyA_window;
+    double pA_mean_range[2], pA_var_range[2], median_shift_range[2];
+    double polyA_med_range[2], polyA_local_range[2], pA_mean_adapter_med_scale_range[2];
+    int32_t detect_open_pores, real_signal_check, mean_window, max_obs_local_range;
+    double mean_start_range[2], mean_end_range[2], local_range[2], adapter_mad_range[2];
+    int32_t detect_med_shift, med_shift_window;
+    double med_shift_range[2];
+    int32_t sp_downscale_factor, start_peak_max_idx, sp_offset1, sp_offset2;
+    double open_pore_pa;
+    int32_t polya_cand_k, fallback_to_llr_short_reads;
+} adp_cfg;
+
+/* numeric columns of a result row, in DetectResults field order */
+enum adp_col {
+    ADP_C_SIGNAL_LEN, ADP_C_PRELOADED,
+    ADP_C_ADAPTER_START, ADP_C_ADAPTER_END, ADP_C_ADAPTER_LEN, ADP_C_ADAPTER_MEAN, ADP_C_ADAPTER_STD,
+    ADP_C_ADAPTER_MED, ADP_C_ADAPTER_MAD,
+    ADP_C_POLYA_START, ADP_C_POLYA_END, ADP_C_POLYA_LEN, ADP_C_POLYA_MEAN, ADP_C_POLYA_STD,
+    ADP_C_POLYA_MED, ADP_C_POLYA_MAD,
+    ADP_C_RNA_START, ADP_C_RNA_LEN, ADP_C_RNA_MEAN, ADP_C_RNA_STD, ADP_C_RNA_MED, ADP_C_RNA_MAD,
+    ADP_C_SP_IDX, ADP_C_SP_PA, ADP_C_SP_NEXT_IDX, ADP_C_SP_NEXT_PA, ADP_C_SP_OPEN_PORE_IDX,
+    ADP_C_MED_SHIFT, ADP_C_PRIMARY_ADAPTER_END, ADP_C_PRIMARY_POLYA_END,
+    ADP_C_MVS_MEAN, ADP_C_MVS_VAR, ADP_C_MVS_POLYA_MED, ADP_C_MVS_LOCAL_RANGE, ADP_C_MVS_MED_SHIFT,
+    ADP_C_REAL_MEAN_START, ADP_C_REAL_MEAN_END, ADP_C_REAL_LOCAL_RANGE,
+    ADP_NCOL
+};
+
+/* fail codes <-> the reference's fail_reason strings (adapted/detect/combined.py:396-580) */
+enum adp_fail {
+    ADP_F_NONE = 0,
+    ADP_F_NO_ADAPTER = 1,       /* "No adapter detected (primary)" */
+    ADP_F_ADAPTER_MAD = 2,      /* "adapter MAD check failed" */
+    ADP_F_OPEN_PORE = 3,        /* "Open pore too close to boundary" */
+    ADP_F_REAL_RANGE = 4,       /* "Real signal check failed" */
+    ADP_F_NO_POLYA = 5,         /* "No polya detected (primary)" */
+    ADP_F_MVS_NOT_ENOUGH = 6,   /* "MVS polya check failed: not enough signal" */
+    ADP_F_MVS_CHECKS = 7,       /* "MVS polya check failed: " + names from mvs_fail_mask */
+    ADP_F_MED_SHIFT = 8,        /* "Median shift check failed" */
+    /* >= 9: the reference raised inside the per-read try block; the row is all-None */
+    ADP_F_EXC_TOPK_NONE = 9,    /* "'NoneType' object is not iterable" (combined.py:464) */
+    ADP_F_EXC_SLICE = 10,       /* "slice indices must be integers or None or have an __index__ method" */
+    ADP_F_EXC_MOVE_WINDOW = 11, /* bottleneck: moving window larger than the slice */
+    ADP_F_EXC_PA_RANGE = 12     /* "pA_mean_range is not specified" (combined.py:462) */
+};
+
+#define ADP_MAX_CAND 16
+#define ADP_MAX_OPEN_PORES 16
+
+/* one read's result: fixed width so that rows can be gathered across GPUs as bytes */
+typedef struct adp_row {
+    double col[ADP_NCOL];      /* ints exactly, float32 statistics widened exactly */
+    uint64_t present;          /* bit c set <=> col[c] is not None */
+    int32_t success;
+    int32_t fail_code;         /* enum adp_fail */
+    int32_t mvs_fail_mask;     /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift failed */
+    int32_t start_peak_type;   /* 0 None, 1 "open pore in adapter", 2 "potential concatemer adapter-only read" */
+    int32_t n_cand;            /* polya_candidates length; -1 <=> None */
+    int32_t n_open_pores;      /* open_pores length (may exceed ADP_MAX_OPEN_PORES); -1 <=> None */
+    int64_t cand[ADP_MAX_CAND];
+    int32_t open_pores[ADP_MAX_OPEN_PORES];
+} adp_row;
+
+typedef struct adp_handle adp_handle;
+
+int adp_abi_version(void);
+int adp_sizeof_cfg(void);
+int adp_sizeof_row(void);
+const char *adp_last_error(void);
+
+/* Number of visible HIP devices, or a negative error. */
+int adp_device_count(void);
+
+/* Create a handle on `device` able to process up to max_reads reads of m samples per call. */
+int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle **out);
+int adp_destroy(adp_handle *h);
+int adp_set_config(adp_handle *h, const adp_cfg *cfg);
+/* The handle's HIP stream (hipStream_t as void*); all work of a call is ordered on it. */
+void *adp_stream(adp_handle *h);
+int adp_synchronize(adp_handle *h);
+
+/* LLR primary + validation (+ optional start-peak columns) over n_reads reads.
+ * rows_out: adp_row[n_reads]; mb_status: int32[ceil(n_reads/minibatch)] (host, may be NULL).
+ * Rows of a dropped minibatch are zeroed with fail_code = 0 and success = 0. */
+int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
+                   int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
+
+/* Start-peak primary + validation. */
+int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads,
+                          int m, int minibatch, int flags, adp_row *rows_out);
+
+/* CNN head, device-side pre/post-processing around the PyTorch conv stack.
+ * prepared_out: float32 [n_reads, Lc] with Lc = ceil((m - min_obs_adapter)/downscale_factor). */
+int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out);
+/* Validate with explicit primary boundaries: bounds int64 [n_reads, 1 + k] = adapter_end, k poly(A)
+ * candidates (0 terminates), exactly what cnn_detect_boundaries hands to validate_boundaries. */
+int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
+                            const int64_t *bounds, int k, int flags, adp_row *rows_out);
+
+/* Synthetic squiggles generated on the device (bit-identical to adapted_amd/synth.py).
+ * dev_signals: device float32 [n, m]; dev_full_len: device int32 [n] or NULL (=> all m). */
+int adp_synth_fill(adp_handle *h, float *dev_signals, const int32_t *dev_full_len, int n, int m,
+                   uint32_t seed, uint32_t first_read, int decorate);
+
+/* Device memory helpers so callers need no HIP binding of their own. */
+int adp_dev_alloc(adp_handle *h, uint64_t bytes, void **out);
+int adp_dev_free(adp_handle *h, void *p);
+int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes);
+int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes);
+
+/* Per-kernel timing of the LAST detect call, measured with HIP events on the handle's stream.
+ * Enable with adp_set_profiling(h, 1).  names_out: up to cap pointers to static strings. */
+int adp_set_profiling(adp_handle *h, int on);
+int adp_kernel_times(adp_handle *h, const char **names_out, float *ms_out, int cap);
+
+/* Debug/inspection of intermediate stages of the last LLR call (tests only).
+ * what: 0 norm params double[4*n_minibatch]; 1 n_valid int32[n]; 2 pooled float32[n*Lp];
+ *       3 trace float64[n*Lp] (pass-2 trace after a full call); 4 adapter idx int32[n];
+ *       5 polya idx int32[n]; 6 Lp (int32[1]) */
+int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes);
+/* Run the LLR pipeline only up to a stage (1 N1, 2 pool, 3 cumsum, 4 gains1, 5 adapter, 6 gains2, 7 polya) */
+int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
+                       int minibatch, int flags, int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPTED_HIP_H */

@@ -1,0 +1,131 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden rows.
+
+Bars (BASELINE.json north_star): integer boundary indices bit-exact; float statistics within
+1e-5 relative (they are in fact expected to be bit-identical: float32 statistics are computed
+in numpy's order on the device); LLR trace values within 1e-9 relative (device log vs glibc log).
+"""
+import numpy as np
+import pytest
+
+from golden_cases import CASES
+from util import INDEX_FIELDS, load_case, row_diffs
+
+pytestmark = pytest.mark.gpu
+
+LLR_CASES = [k for k, c in CASES.items() if c["primary"] == "llr"]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from adapted_amd import lib
+
+    L = lib.load()
+    assert L.adp_device_count() >= 1, L.adp_last_error()
+    return lib
+
+
+def _engine(hip, spc, n, m):
+    return hip.Engine(spc, n, m, device=0)
+
+
+def test_synth_device_matches_host(hip):
+    from adapted_amd import synth
+    from util import make_spc
+
+    spc = make_spc(CASES["rna004_llr_default"])
+    m = spc.sig_preload_size
+    n = 24
+    eng = _engine(hip, spc, n, m)
+    lens = np.array([m, 9000, m + 10, 1500] * 6, dtype=np.int32)
+    dsig = eng.dev_alloc(n * m * 4)
+    dlen = eng.dev_alloc(n * 4)
+    eng.h2d(dlen, lens)
+    eng.synth_fill(dsig, dlen, n, seed=7, first_read=123)
+    got = np.zeros((n, m), dtype=np.float32)
+    eng.d2h(got, dsig)
+    want, _ = synth.synth_batch(7, 123, n, m, lens)
+    assert np.array_equal(got, want, equal_nan=True)
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna002_llr_default", "rna004_llr_200k"])
+def test_llr_stages_vs_oracle(hip, oracle_mod, name):
+    case, spc, sig, lens, _ = load_case(name)
+    mb = case["minibatch"]
+    n = mb
+    sig, lens = sig[:n], lens[:n]
+    m = sig.shape[1]
+    eng = _engine(hip, spc, n, m)
+    # N1
+    eng.debug_llr_upto(sig, lens, n, mb, 1)
+    rc, np4 = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    got = eng.debug_norm_params(1)[0]
+    assert list(got) == list(np4), (got, np4)
+    # D1 + n_valid
+    eng.debug_llr_upto(sig, lens, n, mb, 2)
+    nvalid = eng.debug_fetch(1, n)
+    down = eng.debug_fetch(2, n)
+    stages = [oracle_mod.llr_stages(sig[k], spc, np4) for k in range(n)]
+    for k in range(n):
+        assert nvalid[k] == stages[k]["n_valid"], k
+        assert np.array_equal(down[k, : nvalid[k]], stages[k]["down"]), k
+    # G1
+    eng.debug_llr_upto(sig, lens, n, mb, 4)
+    g1 = eng.debug_fetch(3, n)
+    t1 = eng.debug_fetch(7, n)
+    for k in range(n):
+        a, b = g1[k, : nvalid[k]], stages[k]["g1"]
+        fin = np.isfinite(b)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isposinf(a), np.isposinf(b)), k
+        assert np.allclose(a[fin], b[fin], rtol=1e-9, atol=1e-9), (k, np.max(np.abs(a[fin] - b[fin])))
+        st, en = oracle_start_end(b)
+        assert (int(t1[k, 0]), int(t1[k, 1])) == (st, en), k
+    # adapter candidate
+    eng.debug_llr_upto(sig, lens, n, mb, 5)
+    aidx = eng.debug_fetch(4, n)
+    for k in range(n):
+        assert int(aidx[k]) == stages[k]["cand"], (k, int(aidx[k]), stages[k]["cand"], stages[k]["raw_first"])
+    # G2 + poly(A)
+    eng.debug_llr_upto(sig, lens, n, mb, 7)
+    g2 = eng.debug_fetch(3, n)
+    pidx = eng.debug_fetch(5, n)
+    for k in range(n):
+        if stages[k]["cand"] < 0:
+            assert int(pidx[k]) == 0
+            continue
+        a, b = g2[k, : nvalid[k]], stages[k]["g2"]
+        fin = np.isfinite(b) & np.isfinite(a)
+        # the point next to the boundary is cumulative-sum rounding noise: +-inf / NaN must agree
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b)), k
+        assert np.allclose(a[fin], b[fin], rtol=1e-9, atol=1e-9), k
+        assert int(pidx[k]) == max(stages[k]["polya_idx"], 0), (k, int(pidx[k]), stages[k]["polya_idx"])
+    eng.close()
+
+
+def oracle_start_end(g):
+    pos = ~(g <= 0)
+    if not pos.any():
+        return 0, g.size - 1
+    idx = np.flatnonzero(pos)
+    return int(idx[0]), int(idx[-1])
+
+
+@pytest.mark.parametrize("name", LLR_CASES)
+def test_llr_rows_vs_golden_and_oracle(hip, oracle_mod, name):
+    case, spc, sig, lens, want = load_case(name)
+    n, m = sig.shape
+    eng = _engine(hip, spc, n, m)
+    rows, mbs = eng.detect_llr_rows(sig, lens, n, case["minibatch"])
+    assert (mbs == 0).all()
+    got = hip.rows_to_results(rows, "llr")
+    # integer fields bit-exact, floats within 1e-5 (count the non-identical ones)
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in row_diffs(g, w, float_rel=1e-5)]
+    assert not bad, bad[:10]
+    inexact = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in row_diffs(g, w, float_rel=0.0)]
+    print("%s: %d float fields differ in the last bits" % (name, len(inexact)), inexact[:5])
+    for i, (g, w) in enumerate(zip(got, want)):
+        for f in INDEX_FIELDS:
+            assert getattr(g, f, None) == w.get(f), (i, f)
+    eng.close()
