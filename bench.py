@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/sec through adapter + poly(A) detect on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic RNA004 reads, 200 000-sample trace window
+(--max_obs_trace 200000 -> preload m = 201 500 float32 samples = 806 000 B per read), LLR
+primary detector + start-peak scan + boundary validation, minibatches of 1000 reads
+(normalisation is per minibatch, as in the reference).  A "step" is one pass of the hot path
+over one HBM-resident batch of --reads reads per GPU; inputs are generated on the device
+before the timed region (bit-identical host twin: adapted_amd/synth.py).
+
+    python bench.py --gpus 1 --steps 8 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, each owns a contiguous block of whole minibatches (weak scaling,
+no data-path collective); the fixed-width result rows are gathered to rank 0 over RCCL at the
+end of every step (inside the timed region).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def make_spc(max_obs_trace: int):
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect = True
+    spc.cnn_boundaries.cnn_detect = False
+    spc.core.max_obs_trace = max_obs_trace
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    return spc
+
+
+def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows):
+    """Time the CPU oracle (a single-threaded C port of the reference path) on the first
+    n_sample reads of the resident batch, as ONE minibatch, and check the GPU rows of an
+    identically composed minibatch against it."""
+    from adapted_amd import lib
+    from oracle import oracle
+
+    oracle.lib()
+    sig = np.zeros((n_sample, m), dtype=np.float32)
+    eng.d2h(sig, dsig)
+    lens = np.full(n_sample, m, dtype=np.int32)
+    t0 = time.perf_counter()
+    want = oracle.detect_llr(sig, lens, spc, with_start_peak=True)
+    dt = time.perf_counter() - t0
+    rows, _ = eng.detect_llr_rows(sig, lens, n_sample, n_sample, with_start_peak=True)
+    got = lib.rows_to_results(rows, "llr")
+    mism = 0
+    for g, w in zip(got, want):
+        for k, v in w.items():
+            if k.startswith("_"):
+                continue
+            a = getattr(g, k, None)
+            if hasattr(a, "tolist"):
+                a = a.tolist()
+            if isinstance(v, float) and isinstance(a, (float, np.floating)):
+                if not (a == v or (np.isnan(a) and np.isnan(v))):
+                    mism += 1
+            elif a != v:
+                mism += 1
+    return {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "%d reads (one minibatch) of the same synthetic workload, oracle/adapted_oracle.c, "
+                      "1 thread, %.1f s; GPU rows of the same minibatch differ from it in %d fields"
+                      % (n_sample, dt, mism)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=16000, help="reads per step per GPU (whole minibatches)")
+    ap.add_argument("--minibatch", type=int, default=1000)
+    ap.add_argument("--max_obs_trace", type=int, default=200000)
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-start-peak", action="store_true")
+    ap.add_argument("--seed", type=int, default=2024)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from adapted_amd import lib
+
+    spc = make_spc(args.max_obs_trace)
+    m = spc.sig_preload_size
+    R, mb = args.reads, args.minibatch
+    assert R % mb == 0, "--reads must be a whole number of minibatches"
+    eng = lib.Engine(spc, R, m, device=local)
+    sig_t = torch.empty((R, m), dtype=torch.float32, device=dev)
+    len_t = torch.full((R,), m, dtype=torch.int32, device=dev)
+    rows_t = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    # rank r owns reads [r*R, (r+1)*R) of the global stream: contiguous whole minibatches
+    eng.synth_fill(sig_t.data_ptr(), len_t.data_ptr(), R, seed=args.seed, first_read=rank * R, decorate=True)
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(rows_t) for _ in range(world)]
+
+    def step():
+        eng.detect_llr_rows(sig_t.data_ptr(), len_t.data_ptr(), R, mb, with_start_peak=not args.no_start_peak,
+                            device_ptrs=True, rows_dev=rows_t.data_ptr())
+        if world > 1:
+            dist.gather(rows_t, gathered, dst=0)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_profiling(True)
+    ktimes = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for name, ms in eng.kernel_times():  # HIP events recorded on the engine's stream
+            ktimes.setdefault(name, []).append(ms)
+    sync()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_reads = R * world * args.steps
+    value = total_reads / dt
+
+    if rank == 0:
+        rows = np.zeros(R, dtype=lib.ROW_DTYPE)
+        eng.d2h(rows, rows_t.data_ptr())
+        n_ok = int(rows["success"].sum())
+        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        dom = max(kavg, key=kavg.get)
+        b_alg = 4.0 * m * R  # 4*m input bytes per read, each launch covers R reads
+        achieved = b_alg / (kavg[dom] * 1e-3) / 1e9
+        ksum = sum(kavg.values())
+        out = {
+            "metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 samples/statistics, f64 cumulative sums + LLR trace", "data": "synthetic (device-generated, adapted_amd/synth.py twin)",
+            "config": {"workload": "BASELINE configs[1]: RNA004 LLR + start_peak + validate, max_obs_trace=%d (m=%d), "
+                                   "minibatch=%d, %d reads/step/GPU resident in HBM" % (args.max_obs_trace, m, mb, R),
+                       "reads_per_step_per_gpu": R, "minibatch": mb, "m": m, "pass_rate": n_ok / R},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": kavg[dom], "algorithmic_bytes_per_launch": b_alg,
+                         "whole_path_frac": (b_alg / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS},
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
+            "kernel_ms_sum": ksum,
+        }
+        if world == 1:
+            n_s = min(args.cpu_sample, R)
+            out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
