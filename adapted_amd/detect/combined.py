@@ -88,20 +88,15 @@ def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_si
     m = sig.shape[1]
     eng = get_engine(spc, 1, m, device)
     topk = boundaries.polya_end_topk
-    if topk is None:
-        if spc.mvs_polya.mvs_detect_check and boundaries.adapter_end and boundaries.polya_end:
-            # would reach `for polya_end in None` unless an earlier gate fails: let the device decide
-            rows = eng.detect_rows_topk_none(sig, full_signal_len, boundaries)
-            return lib.rows_to_results(rows, spc.primary_method)[0]
-        topk = [boundaries.polya_end or 0]
-    b = np.zeros((1, 1 + max(1, len(topk))), dtype=np.int64)
+    none = topk is None
+    cands = [int(boundaries.polya_end or 0)] if none else [int(x) for x in np.asarray(topk).ravel()]
+    b = np.zeros((1, 1 + max(1, len(cands))), dtype=np.int64)
     b[0, 0] = int(boundaries.adapter_end or 0)
-    b[0, 1:1 + len(topk)] = np.asarray(topk, dtype=np.int64)
-    rows = eng.validate_rows(sig, np.array([full_signal_len], dtype=np.int32), 1, b)
-    res = lib.rows_to_results(rows, spc.primary_method)[0]
-    if boundaries.polya_end_topk is None:
-        res.polya_candidates = None
-    return res
+    b[0, 1:1 + len(cands)] = cands
+    if not none and len(cands) and cands[0] != int(boundaries.polya_end or 0):
+        raise ValueError("polya_end_topk[0] must equal polya_end")
+    rows = eng.validate_rows(sig, np.array([full_signal_len], dtype=np.int32), 1, b, topk_none=none)
+    return lib.rows_to_results(rows, spc.primary_method)[0]
 
 
 def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, model, spc,

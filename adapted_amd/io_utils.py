@@ -1,0 +1,94 @@
+"""Input discovery and minibatch assembly for the `adapted detect` driver.
+
+The reference reads .pod5 files (adapted/file_proc.py:143-190, adapted/io_utils.py:107-129).
+pod5 is an optional dependency here: when it is importable .pod5 inputs are read the same
+way; independently of it, ``.npz`` signal bundles are accepted (keys: ``signals`` float32
+[n, >=preload] NaN padded or ``signal_<i>`` ragged arrays, ``full_lengths``, ``read_ids``)
+so that the pipeline can be driven and tested without pod5.
+Both produce the reference's minibatch layout: float32 [N, preload] NaN padded, int32 true
+lengths, object read ids.
+"""
+from __future__ import annotations
+
+import os
+import re
+from typing import Generator, Iterable, List, Optional, Set, Tuple
+
+import numpy as np
+
+EXTS = (".pod5", ".npz")
+
+
+def _num_suffix_key(path: str):
+    base = os.path.splitext(path)[0]
+    m = re.search(r"(\d+)$", base)
+    return (base[: m.start()], int(m.group())) if m else (base, 0.0)
+
+
+def input_to_filelist(inputs: Iterable[str], endswiths=EXTS) -> List[str]:
+    files: List[str] = []
+    for path in inputs:
+        if not path or path == " ":
+            continue
+        if os.path.isdir(path):
+            for root, _, names in os.walk(path):
+                files.extend(os.path.join(root, f) for f in names if f.endswith(tuple(endswiths)))
+        elif path.endswith(tuple(endswiths)) and os.path.isfile(path):
+            files.append(path)
+        else:
+            raise ValueError("not a valid input file: %s" % path)
+    return sorted(files, key=_num_suffix_key)
+
+
+def _iter_reads(filename: str, selection: Optional[List[str]]):
+    """yield (read_id, n_samples, signal_pa[:] accessor)"""
+    if filename.endswith(".npz"):
+        z = np.load(filename, allow_pickle=True)
+        ids = [str(x) for x in z["read_ids"]]
+        lens = z["full_lengths"]
+        for i, rid in enumerate(ids):
+            if selection is not None and rid not in selection:
+                continue
+            sig = z["signals"][i] if "signals" in z else z["signal_%d" % i]
+            yield rid, int(lens[i]), sig
+    else:
+        try:
+            from pod5 import Reader
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
+        with Reader(filename) as fh:
+            for rec in fh.reads(selection=selection, missing_ok=True):
+                yield str(rec.read_id), int(rec.num_samples), rec.signal_pa
+
+
+def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
+                      preload_size: int) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
+    if read_ids_incl and read_ids_excl:
+        read_ids_incl = read_ids_incl.difference(read_ids_excl)
+        read_ids_excl = set()
+    selection = list(read_ids_incl) if read_ids_incl else None
+    N, m = batch_size, preload_size
+    sig = np.empty((N, m), dtype=np.float32)
+    lens = np.empty(N, dtype=np.int32)
+    ids = np.empty(N, dtype=object)
+    k = 0
+    for fn in files:
+        for rid, n_samples, signal in _iter_reads(fn, selection):
+            if rid in read_ids_excl:
+                continue
+            s = np.asarray(signal[:m], dtype=np.float32)
+            take = min(m, n_samples, s.size)
+            sig[k, :take] = s[:take]
+            if take < m:
+                sig[k, take:] = np.nan
+            lens[k] = n_samples
+            ids[k] = rid
+            k += 1
+            if k == N:
+                yield sig, lens, ids
+                sig = np.empty((N, m), dtype=np.float32)
+                lens = np.empty(N, dtype=np.int32)
+                ids = np.empty(N, dtype=object)
+                k = 0
+    if k:
+        yield sig[:k], lens[:k], ids[:k]

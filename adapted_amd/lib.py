@@ -21,7 +21,7 @@ NCOL = 38
 MAX_CAND = 16
 MAX_OPEN_PORES = 16
 
-ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK = 1, 2, 4
+ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK, ADP_TOPK_NONE = 1, 2, 4, 8
 MB_OK, MB_MAD_ZERO, MB_EMPTY_TRACE = 0, 1, 2
 
 COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len", "adapter_mean",
@@ -313,9 +313,12 @@ class Engine:
         del keep
         return rows
 
-    def validate_rows(self, signals, full_lens, n: int, bounds: np.ndarray, device_ptrs: bool = False):
+    def validate_rows(self, signals, full_lens, n: int, bounds: np.ndarray, device_ptrs: bool = False,
+                      topk_none: bool = False):
         """bounds int64 [n, 1+k] (host) -> rows"""
         sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        if topk_none:
+            flags |= ADP_TOPK_NONE
         b = np.ascontiguousarray(bounds, dtype=np.int64)
         k = b.shape[1] - 1
         rows = np.zeros(n, dtype=ROW_DTYPE)

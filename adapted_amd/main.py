@@ -1,0 +1,228 @@
+"""`adapted detect` / `adapted continue` on MI355X.
+
+Keeps the reference's command line (adapted/parser.py:37-269), run-directory layout
+(adapted_<ver>_<uuid8>/{command.json, config.toml, adapted.log, boundaries/detected_boundaries_<k>.csv,
+failed_reads/failed_reads_<k>.csv}) and CSV columns, but replaces the process pool and manager
+queues of adapted/file_proc.py:612-823 with: one process per GPU, minibatches streamed into the
+GPU engine, rows written in output batches of `-b` reads.  Launch under torchrun for several
+GPUs: ranks own contiguous blocks of whole minibatches and rank 0 writes after one gather.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import shutil
+import sys
+import time
+import uuid
+from typing import List, Set
+
+import numpy as np
+
+from . import lib, parallel
+from ._version import __version__
+from .config import get_chemistry_specific_config, load_nested_config_from_file
+from .container_types import ReadResult
+from .io_utils import input_to_filelist, yield_minibatches
+from .output import save_detected_boundaries
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="adapted", formatter_class=argparse.RawTextHelpFormatter,
+                                description="ADAPTed detect on MI355X: adapter and poly(A) boundaries in raw dRNA-seq signals.")
+    sub = p.add_subparsers(dest="mode", required=True)
+    d = sub.add_parser("detect", help="Detect adapter and poly(A) signal boundaries and calculate statistics.")
+    c = sub.add_parser("continue", help="Continue processing from a previous incomplete run.")
+    c.add_argument("continue_from", type=str)
+    d.add_argument("-i", "--input", type=str, nargs="+", required=True, help="input files / directories (.pod5 or .npz bundles)")
+    d.add_argument("-o", "--output", type=str, default=None)
+    d.add_argument("--config", type=str, default=None, help="config TOML (overrides --chemistry)")
+    d.add_argument("-c", "--chemistry", type=str, choices=["RNA002", "RNA004"], default=None)
+    d.add_argument("--max_obs_trace", type=int, default=None)
+    d.add_argument("--read_id_csv", type=str, default=None)
+    d.add_argument("--read_id_csv_colname", type=str, default="read_id")
+    d.add_argument("-j", "--num_proc", type=int, default=None, help="accepted for compatibility; the GPU engine does not use a process pool")
+    d.add_argument("-b", "--batch_size", type=int, default=4000, help="Number of reads per output file.")
+    d.add_argument("-s", "--minibatch_size", type=int, default=1000, help="Number of reads per minibatch (normalisation unit).")
+    d.add_argument("--start_peak", action="store_true", help="(extension) also fill the start_peak_* columns on the LLR path")
+    d.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    return p
+
+
+def scan_processed_reads(run_dir: str):
+    done: Set[str] = set()
+    mx = {"failed_reads": -1, "boundaries": -1}
+    for sub, prefix in (("failed_reads", "failed_reads_"), ("boundaries", "detected_boundaries_")):
+        d = os.path.join(run_dir, sub)
+        if not os.path.isdir(d):
+            continue
+        for f in os.listdir(d):
+            if f.startswith(prefix) and f.endswith(".csv"):
+                mx[sub] = max(mx[sub], int(f.split("_")[-1].split(".")[0]))
+                with open(os.path.join(d, f)) as fh:
+                    done.update(line.split(",")[0] for line in fh.readlines()[1:])
+    return done, mx["boundaries"], mx["failed_reads"]
+
+
+class _Writer:
+    """Accumulates pass / fail results and flushes CSV files of `batch` reads each."""
+
+    def __init__(self, run_dir: str, batch: int, bidx_pass: int = 0, bidx_fail: int = 0):
+        self.dirs = {True: os.path.join(run_dir, "boundaries"), False: os.path.join(run_dir, "failed_reads")}
+        for d in self.dirs.values():
+            os.makedirs(d, exist_ok=True)
+        self.names = {True: "detected_boundaries", False: "failed_reads"}
+        self.bidx = {True: bidx_pass, False: bidx_fail}
+        self.pending = {True: [], False: []}
+        self.batch = batch
+        self.n = {True: 0, False: 0}
+
+    def add(self, results: List[ReadResult]):
+        for r in results:
+            self.pending[bool(r.success)].append(r)
+        for ok in (True, False):
+            while len(self.pending[ok]) >= self.batch:
+                self._flush(ok, self.pending[ok][: self.batch])
+                self.pending[ok] = self.pending[ok][self.batch:]
+
+    def _flush(self, ok: bool, items: List[ReadResult]):
+        fn = os.path.join(self.dirs[ok], "%s_%d.csv" % (self.names[ok], self.bidx[ok]))
+        save_detected_boundaries(items, fn, save_fail_reasons=not ok)
+        self.bidx[ok] += 1
+        self.n[ok] += len(items)
+
+    def close(self):
+        for ok in (True, False):
+            if self.pending[ok]:
+                self._flush(ok, self.pending[ok])
+                self.pending[ok] = []
+
+
+def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, batch_out, device, start_peak=False,
+               bidx_pass=0, bidx_fail=0):
+    rank, ws, local = parallel.world()
+    if device is None:
+        device = local
+    if ws > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl")
+    primary = spc.primary_method
+    if primary == "cnn":
+        from .detect import cnn as _cnn
+
+        model = _cnn.load_cnn_model(spc.cnn_boundaries.model_name)
+    m = spc.sig_preload_size
+    eng = lib.Engine(spc, minibatch, m, device=device)
+    writer = _Writer(run_dir, batch_out, bidx_pass, bidx_fail) if rank == 0 else None
+    t0 = time.time()
+    n_total = 0
+    my_rows, my_ids = [], []
+    for i, (sig, lens, ids) in enumerate(yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch, m)):
+        if ws > 1 and i % ws != rank:
+            continue  # round-robin whole minibatches (the stream length is unknown up front)
+        n = sig.shape[0]
+        try:
+            if primary == "llr":
+                rows, mbs = eng.detect_llr_rows(sig, lens, n, n, with_start_peak=start_peak)
+                if mbs[0] != lib.MB_OK:
+                    logging.error("minibatch %d dropped: %s", i, {1: "MAD normalization failed: scale is 0",
+                                                                  2: "a read has no signal after min_obs_adapter"}[int(mbs[0])])
+                    continue
+            elif primary == "start_peak":
+                rows = eng.detect_start_peak_rows(sig, lens, n, n)
+            else:
+                rows = _cnn.detect_rows(eng, sig, lens, model, spc)
+        except lib.HipLibraryError:
+            raise
+        n_total += n
+        if ws > 1:
+            my_rows.append(rows)
+            my_ids.extend(ids.tolist())
+        else:
+            res = lib.rows_to_results(rows, primary)
+            writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
+                        for rid, r in zip(ids, res)])
+    if ws > 1:
+        import torch.distributed as dist
+
+        rows = np.concatenate(my_rows) if my_rows else np.zeros(0, dtype=lib.ROW_DTYPE)
+        allrows = parallel.gather_rows(rows, dst=0)
+        idlists = [None] * ws if rank == 0 else None
+        dist.gather_object(my_ids, idlists, dst=0)
+        if rank == 0:
+            ids = [x for part in idlists for x in part]
+            res = lib.rows_to_results(allrows, primary)
+            writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
+                        for rid, r in zip(ids, res)])
+    if writer is not None:
+        writer.close()
+        tot = writer.n[True] + writer.n[False]
+        logging.info("Processed %d reads in %.2f s (%.0f reads/s on %d GPU(s))", tot, time.time() - t0,
+                     tot / max(time.time() - t0, 1e-9), ws)
+        if tot:
+            logging.info("Pass: %d (%.2f%%), fail: %d", writer.n[True], 100.0 * writer.n[True] / tot, writer.n[False])
+    eng.close()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.mode == "continue":
+        run_dir = args.continue_from
+        try:
+            with open(os.path.join(run_dir, "command.json")) as fh:
+                cmd = json.load(fh)
+        except FileNotFoundError:
+            raise SystemExit("No command.json file found in the continue_from directory.")
+        shutil.copy(os.path.join(run_dir, "command.json"), os.path.join(run_dir, "command_previous.json"))
+        for k, v in cmd.items():
+            if not hasattr(args, k):
+                setattr(args, k, v)
+    else:
+        args.output = args.output or os.getcwd()
+        run_dir = os.path.join(args.output, "adapted_" + __version__.replace(".", "_") + "_" + str(uuid.uuid4())[:8])
+    if not args.config and not args.chemistry:
+        raise SystemExit("Either --config or --chemistry must be provided.")
+    read_ids: List[str] = []
+    if args.read_id_csv:
+        import pandas as pd
+
+        read_ids = pd.read_csv(args.read_id_csv)[args.read_id_csv_colname].astype(str).tolist()
+    files = input_to_filelist(args.input)
+    if not files:
+        print("No valid input files found.\nProvided path: {}".format(args.input))
+        raise SystemExit(1)
+    spc = load_nested_config_from_file(args.config) if args.config else get_chemistry_specific_config(args.chemistry)
+    if args.max_obs_trace:
+        spc.core.max_obs_trace = args.max_obs_trace
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    rank = parallel.world()[0]
+    os.makedirs(run_dir, exist_ok=True)
+    if rank == 0:
+        with open(os.path.join(run_dir, "command.json"), "w") as fh:
+            json.dump(vars(args), fh, indent=2)
+        spc.to_toml(os.path.join(run_dir, "config.toml"))
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(levelname)s %(message)s",
+                        handlers=[logging.StreamHandler(sys.stdout)] +
+                        ([logging.FileHandler(os.path.join(run_dir, "adapted.log"))] if rank == 0 else []))
+    logging.info("Command: %s", " ".join(sys.argv))
+    logging.info("Saving output to: %s", run_dir)
+    excl: Set[str] = set()
+    bp = bf = 0
+    if args.mode == "continue":
+        excl, mp, mf = scan_processed_reads(run_dir)
+        bp, bf = mp + 1, mf + 1
+        logging.info("Found %d previously processed reads.", len(excl))
+    run_detect(files, set(read_ids), excl, spc, run_dir, args.minibatch_size, args.batch_size, args.device,
+               start_peak=getattr(args, "start_peak", False), bidx_pass=bp, bidx_fail=bf)
+    logging.info("Done.")
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,7 @@ extern "C" {
 #define ADP_IN_DEVICE 1            /* signals / full_len are device pointers */
 #define ADP_OUT_DEVICE 2           /* rows_out is a device pointer */
 #define ADP_WITH_START_PEAK 4      /* LLR path: also fill the start_peak_* columns (extension) */
+#define ADP_TOPK_NONE 8            /* adp_validate_candidates: polya_end_topk is None (k must be 1) */
 
 /* SigProcConfig, flattened.  Ranges are [lo, hi] with -inf/+inf for "None". */
 typedef struct adp_cfg {

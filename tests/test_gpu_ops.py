@@ -1,0 +1,90 @@
+"""GPU parity of the remaining operators: start-peak primary, the single-read validator, error
+behaviour of the batch API, the CLI end to end (CSV text equal to the reference's)."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_cases import CASES
+from util import GOLD, load_case, row_diffs
+
+pytestmark = pytest.mark.gpu
+
+SP_CASES = [k for k, c in CASES.items() if c["primary"] == "start_peak"]
+
+
+@pytest.mark.parametrize("name", SP_CASES)
+def test_start_peak_rows_vs_golden(name):
+    from adapted_amd.detect.combined import combined_detect_start_peak
+
+    case, spc, sig, lens, want = load_case(name)
+    got = combined_detect_start_peak(sig, lens, spc)
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in row_diffs(g, w, float_rel=0.0)]
+    assert not bad, bad[:10]
+
+
+def test_llr_with_start_peak_columns_vs_oracle(oracle_mod):
+    from adapted_amd.detect.combined import combined_detect_llr2
+
+    case, spc, sig, lens, _ = load_case("rna004_llr_default")
+    got = combined_detect_llr2(sig, lens, spc, with_start_peak=True)
+    want = oracle_mod.detect_llr(sig, lens, spc, with_start_peak=True)
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want))
+           for d in row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")}, float_rel=0.0)]
+    assert not bad, bad[:10]
+    assert any(g.start_peak_idx is not None for g in got)
+
+
+def test_batch_errors_match_reference():
+    from adapted_amd.detect.combined import combined_detect_llr2
+    from util import make_spc
+
+    spc = make_spc(CASES["rna004_llr_default"])
+    m = spc.sig_preload_size
+    flat = np.full((4, m), 80.0, dtype=np.float32)
+    with pytest.raises(ValueError, match="MAD normalization failed: scale is 0"):
+        combined_detect_llr2(flat, np.full(4, m, dtype=np.int32), spc)
+    # a read shorter than min_obs_adapter + one pool block sinks the reference's minibatch
+    from adapted_amd import synth
+
+    sig, lens = synth.synth_batch(1, 0, 4, m, np.array([m, 900, m, m], dtype=np.int32))
+    with pytest.raises(ValueError, match="argmin of an empty sequence"):
+        combined_detect_llr2(sig, lens, spc)
+
+
+def test_single_read_validator_equals_batch_rows():
+    from adapted_amd.container_types import Boundaries
+    from adapted_amd.detect.combined import combined_detect_llr2, validate_boundaries
+
+    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    for i in (0, 1, 7, 9, 13):
+        w = want[i]
+        topk = np.array(w["polya_candidates"]) if w["polya_candidates"] is not None else None
+        b = Boundaries(adapter_start=0, adapter_end=w["llr_adapter_end"], polya_end=w["llr_polya_end"], polya_end_topk=topk)
+        got = validate_boundaries(sig[i][: lens[i]], b, spc, int(lens[i]))
+        assert not row_diffs(got, w, float_rel=0.0), (i, row_diffs(got, w))
+
+
+def test_cli_detect_writes_reference_csv(tmp_path):
+    from adapted_amd import main as cli
+
+    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    ids = np.array(["read_%04d" % i for i in range(case["n"])], dtype=object)
+    bundle = tmp_path / "reads_0.npz"
+    np.savez(bundle, signals=sig, full_lengths=lens, read_ids=ids)
+    cfg = tmp_path / "cfg.toml"
+    spc.to_toml(str(cfg))
+    out = tmp_path / "out"
+    cli.main(["detect", "-i", str(bundle), "-o", str(out), "--config", str(cfg), "-s", str(case["minibatch"]), "-b", "4000"])
+    run = [d for d in os.listdir(out) if d.startswith("adapted_0_2_4_")]
+    assert len(run) == 1
+    rd = out / run[0]
+    for f in ("command.json", "config.toml", "adapted.log"):
+        assert (rd / f).exists()
+    with open(os.path.join(GOLD, "rna004_llr_default.pass.csv")) as fh:
+        assert (rd / "boundaries" / "detected_boundaries_0.csv").read_text() == fh.read()
+    with open(os.path.join(GOLD, "rna004_llr_default.fail.csv")) as fh:
+        assert (rd / "failed_reads" / "failed_reads_0.csv").read_text() == fh.read()
+    # `continue` finds every read already processed and writes nothing new
+    cli.main(["continue", str(rd)])
+    assert sorted(os.listdir(rd / "boundaries")) == ["detected_boundaries_0.csv"]
