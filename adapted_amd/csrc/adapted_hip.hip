@@ -320,7 +320,8 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
             hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
-                               minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>());
+                               minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
+                               (const int32_t *)nullptr);
         }
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);
@@ -333,7 +334,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<1>");
             hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>());
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0);
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
@@ -346,7 +347,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>());
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0);
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
@@ -455,9 +456,97 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
 
 int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out)
 {
-    (void)h; (void)signals; (void)n_reads; (void)m; (void)flags; (void)prepared_out;
-    g_err = "adp_cnn_prepare: not implemented yet";
-    return ADP_ERR_UNSUPPORTED;
+    if (!h || !signals || !prepared_out || n_reads < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (m != h->m) { g_err = "m differs from the handle's"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
+    if (m <= off) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
+    const int Lc = (m - off + ds - 1) / ds;
+    const float *dsig = signals;
+    if (!(flags & ADP_IN_DEVICE)) {
+        if (h->sig_stage.ensure((size_t)n_reads * m * 4)) { g_err = "staging allocation failed"; return ADP_ERR_HIP; }
+        HIPCHK(hipMemcpyAsync(h->sig_stage.p, signals, (size_t)n_reads * m * 4, hipMemcpyHostToDevice, h->stream));
+        dsig = h->sig_stage.as<float>();
+    }
+    float *dout = prepared_out;
+    if (!(flags & ADP_OUT_DEVICE)) {
+        if (h->bounds_stage.ensure((size_t)n_reads * Lc * 4)) { g_err = "staging allocation failed"; return ADP_ERR_HIP; }
+        dout = h->bounds_stage.as<float>();
+    }
+    { Scope s(h, "k_cnn_prepare");
+      hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, h->stream, dsig, n_reads, m, off, ds, Lc, dout); }
+    if (!(flags & ADP_OUT_DEVICE))
+        HIPCHK(hipMemcpyAsync(prepared_out, dout, (size_t)n_reads * Lc * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+__global__ void k_refine_out(const MbState *mbs, const int32_t *nvalid, const int32_t *polya_idx, const int64_t *ranges, int n,
+                             int ds, int64_t *out, int32_t *status)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int st = 0;
+    if (mbs[r].status == ADP_MB_MAD_ZERO) st = ADP_F_EXC_MAD_ZERO;
+    else if (nvalid[r] <= 0) st = ADP_F_EXC_EMPTY_TRACE;
+    int p = polya_idx[r];
+    out[r] = (st == 0 && p > 0) ? (int64_t)p * ds + ranges[2 * r] : 0;
+    status[r] = st;
+}
+
+int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, const int64_t *ranges,
+                         int flags, int64_t *polya_out, int32_t *status_out)
+{
+    if (!h || !signals || !full_len || !ranges || !polya_out || !status_out || n < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    hipStream_t st = h->stream;
+    if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) ||
+        h->bounds_stage.ensure((size_t)n * 16 + (size_t)n * 12)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    int64_t *drng = h->bounds_stage.as<int64_t>();
+    int64_t *dout = drng + 2 * (size_t)n;
+    int32_t *dstat = reinterpret_cast<int32_t *>(dout + n);
+    HIPCHK(hipMemcpyAsync(drng, ranges, (size_t)n * 16, (flags & ADP_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    MbState *mbs = h->mbs.as<MbState>();
+    HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n * sizeof(MbState), st));
+    HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n * N1_BINS * 4, st));
+    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n * 4, st));
+    HIPCHK(hipMemsetAsync(h->adapter_idx.p, 0, (size_t)n * 4, st));
+    uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
+    dim3 hg(4, n);
+    const double thr = h->cfg.sig_norm_outlier_thresh;
+    for (int mode = 0; mode < 2; mode++) { // per-read normalisation: every read is its own minibatch
+        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
+        hipLaunchKernelGGL(k_n1_pick<0>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
+        hipLaunchKernelGGL(k_n1_pick<1>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+        hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
+        hipLaunchKernelGGL(k_n1_pick<2>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
+    }
+    hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
+                       h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
+    hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
+                       h->ck.as<double2>(), h->tail.as<double2>());
+    hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+                       h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1);
+    int grid = n < h->pslots ? n : h->pslots;
+    hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,
+                       h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->st.as<uint8_t>(), h->polya_idx.as<int32_t>());
+    hipLaunchKernelGGL(k_refine_out, dim3((n + 255) / 256), dim3(256), 0, st, mbs, h->nvalid.as<int32_t>(), h->polya_idx.as<int32_t>(),
+                       (const int64_t *)drng, n, h->ds, dout, dstat);
+    HIPCHK(hipMemcpyAsync(polya_out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(status_out, dstat, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
 }
 
 int adp_synth_fill(adp_handle *h, float *dev_signals, const int32_t *dev_full_len, int n, int m, uint32_t seed,

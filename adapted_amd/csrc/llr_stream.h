@@ -19,9 +19,11 @@
 
 // ---------------------------------------------------------------- D1
 // grid = n_reads blocks of 256 threads; dynamic LDS = 256 * ds floats
+// ranges != nullptr (CNN fallback C4): per-read pooled region [ranges[2r], min(ranges[2r+1], T, full_len))
 __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
-                                                   float *__restrict__ down, int32_t *__restrict__ nvalid)
+                                                   float *__restrict__ down, int32_t *__restrict__ nvalid,
+                                                   const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len)
 {
     extern __shared__ float tile[];
     __shared__ int s_nan;
@@ -29,8 +31,17 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
     const MbState st = mbs[r / mbsize];
     if (st.status != ADP_MB_OK) { if (threadIdx.x == 0) nvalid[r] = 0; return; }
     const float med = st.med, mad = st.mad, lo = st.lo, hi = st.hi;
+    int Lseg = T - off; // > 0 guaranteed by the host
+    if (ranges) {
+        long long a = ranges[2 * r], b = ranges[2 * r + 1];
+        long long lim = full_len[r] < T ? full_len[r] : T;
+        if (b > lim) b = lim;
+        off = (int)a;
+        Lseg = (int)(b > a ? b - a : 0);
+        L = (Lseg + ds - 1) / ds;
+        if (L > Lp) L = Lp;
+    }
     const float *row = sig + (size_t)r * m + off;
-    const int Lseg = T - off; // > 0 guaranteed by the host
     if (threadIdx.x == 0) s_nan = 0;
     int my_nan = 0;
     const int tile_n = 256 * ds;
@@ -103,7 +114,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                                               const int32_t *__restrict__ adapter_idx, int mbsize,
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
-                                              int2 *__restrict__ t1)
+                                              int2 *__restrict__ t1, int sanitize)
 {
     __shared__ float sd[64 * (CK + 1)];
     __shared__ double sg[64 * (CK + 1)];
@@ -164,8 +175,8 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                     double tl = (double)(E - i) * log(vt);
                     gi = vs - (h + tl);
                 }
-                if (PASS == 1) {
-                    if (!(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }
+                if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }
+                if (PASS == 1 && !sanitize) {
                     double m1 = (gi != gi) ? __builtin_inf() : gi;
                     mx = m1 > mx ? m1 : mx;
                     if (gi == gi) mn = gi < mn ? gi : mn;

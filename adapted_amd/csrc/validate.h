@@ -446,3 +446,38 @@ __global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int3
     bounds[2 * r + 1] = pe;
     topk_none[r] = (pe > 0) ? 0 : 1; // polya_end_topk is only assigned when a poly(A) end was found
 }
+
+// ---------------------------------------------------------------- C1 prepare_data (CNN head input)
+// reference adapted/detect/cnn.py:70-82: mean-pool the RAW signal from min_obs_adapter on, per-read
+// nanmedian / MAD of the pooled values, (x - med) / mad, NaN -> -5.0 (torch.nan_to_num: +-inf ->
+// +-FLT_MAX).  One wave per read; pooled NaNs form a tail (minibatch layout B0).
+__global__ void __launch_bounds__(64) k_cnn_prepare(const float *__restrict__ sigs, int n_reads, int m, int off, int ds, int Lc,
+                                                    float *__restrict__ out)
+{
+    __shared__ WaveScratch ws_;
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    const float *row = sigs + (size_t)r * m + off;
+    const int Lseg = m - off;
+    float *o = out + (size_t)r * Lc;
+    int nan_cnt = 0;
+    for (int j = ln; j < Lc; j += 64) {
+        const int b = j * ds;
+        float v = pw_leaf_f32(ds, [&](int k) { int i = b + k; return i < Lseg ? row[i] : 0.0f; }) / (float)ds;
+        o[j] = v;
+        if (v != v) nan_cnt++;
+    }
+    nan_cnt = wave_sum(nan_cnt);
+    __threadfence_block();
+    __syncthreads();
+    const int n = Lc - nan_cnt;
+    float med = wave_median(o, n, 0, 0.f, &ws_);
+    float mad = wave_median(o, n, 1, med, &ws_);
+    __syncthreads();
+    for (int j = ln; j < Lc; j += 64) {
+        float v = (o[j] - med) / mad;
+        if (v != v) v = -5.0f;
+        else if (__builtin_isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+        o[j] = v;
+    }
+}

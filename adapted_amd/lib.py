@@ -58,6 +58,8 @@ FAIL_REASONS = {
     10: "slice indices must be integers or None or have an __index__ method",
     11: "Moving window must between 1 and n, inclusive",
     12: "pA_mean_range is not specified",
+    13: "attempt to get argmin of an empty sequence",
+    14: "MAD normalization failed: scale is 0",
 }
 _MVS_NAMES = ["mean", "var", "med", "range", "shift"]
 START_PEAK_TYPES = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
@@ -112,7 +114,7 @@ def load():
 
 EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_error", "adp_device_count", "adp_create",
            "adp_destroy", "adp_set_config", "adp_stream", "adp_synchronize", "adp_detect_llr", "adp_detect_start_peak",
-           "adp_cnn_prepare", "adp_validate_candidates", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
+           "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto"]
 
@@ -336,6 +338,22 @@ class Engine:
                                                          flags, rows.ctypes.data_as(C.c_void_p)))
         del keep
         return rows
+
+    def cnn_prepare(self, signals: np.ndarray, n: int, out_dev_ptr: int):
+        """C1 into a device buffer float32 [n, Lc] (e.g. a torch tensor's data_ptr)."""
+        sig = np.ascontiguousarray(signals, dtype=np.float32)
+        self._check(self.lib.adp_cnn_prepare(self._h, sig.ctypes.data_as(C.c_void_p), int(n), self.m, ADP_OUT_DEVICE,
+                                             C.c_void_p(int(out_dev_ptr))))
+
+    def llr_refine_polya(self, signals, full_lens, n: int, ranges: np.ndarray):
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, False)
+        rg = np.ascontiguousarray(ranges, dtype=np.int64)
+        out = np.zeros(n, dtype=np.int64)
+        st = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.adp_llr_refine_polya(self._h, sp, lp, int(n), self.m, rg.ctypes.data_as(C.c_void_p), flags,
+                                                  out.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)))
+        del keep
+        return out, st
 
     # -- debug (tests) ------------------------------------------------------------------------
     def debug_llr_upto(self, signals, full_lens, n, minibatch, stage):

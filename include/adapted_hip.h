@@ -108,7 +108,9 @@ enum adp_fail {
     ADP_F_EXC_TOPK_NONE = 9,    /* "'NoneType' object is not iterable" (combined.py:464) */
     ADP_F_EXC_SLICE = 10,       /* "slice indices must be integers or None or have an __index__ method" */
     ADP_F_EXC_MOVE_WINDOW = 11, /* bottleneck: moving window larger than the slice */
-    ADP_F_EXC_PA_RANGE = 12     /* "pA_mean_range is not specified" (combined.py:462) */
+    ADP_F_EXC_PA_RANGE = 12,    /* "pA_mean_range is not specified" (combined.py:462) */
+    ADP_F_EXC_EMPTY_TRACE = 13, /* "attempt to get argmin of an empty sequence" (CNN fallback, llr.py:136) */
+    ADP_F_EXC_MAD_ZERO = 14     /* "MAD normalization failed: scale is 0" (CNN fallback, normalize.py:56-59) */
 };
 
 #define ADP_MAX_CAND 16
@@ -163,6 +165,12 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
  * candidates (0 terminates), exactly what cnn_detect_boundaries hands to validate_boundaries. */
 int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                             const int64_t *bounds, int k, int flags, adp_row *rows_out);
+
+/* CNN fallback for short reads (adapted/detect/combined.py:251-301): per-read normalisation, LLR trace
+ * (offsets 5/5) over [ranges[2i], ranges[2i+1]) and P4 on it.  polya_out[i] = new poly(A) end in samples or 0;
+ * status_out[i] = 0 or the ADP_F_EXC_* code of the exception the reference would have raised. */
+int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
+                         const int64_t *ranges, int flags, int64_t *polya_out, int32_t *status_out);
 
 /* Synthetic squiggles generated on the device (bit-identical to adapted_amd/synth.py).
  * dev_signals: device float32 [n, m]; dev_full_len: device int32 [n] or NULL (=> all m). */

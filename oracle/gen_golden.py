@@ -222,6 +222,18 @@ def gen_bottleneck():
     np.savez_compressed(os.path.join(GOLD, "bn_move.npz"), **arrs)
 
 
+def export_weights():
+    """The reference's trained CNN parameters (a data asset, CC BY-NC 4.0, (c) W. K. van der Toorn) as a
+    neutral .npz with the same state-dict keys."""
+    import torch
+
+    src = os.path.join(ref_harness.REF_ROOT, "adapted", "models", "rna004_130bps@v0.2.4.pth")
+    sd = torch.load(src, weights_only=True, map_location="cpu")
+    dst = os.path.join(ROOT, "adapted_amd", "models", "rna004_130bps@v0.2.4.npz")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    np.savez(dst, **{k: v.numpy() for k, v in sd.items()})
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "llr"
     os.makedirs(GOLD, exist_ok=True)
@@ -237,6 +249,7 @@ def main():
                 gen_csv(results, lens, name)
         gen_start_peak_table()
     elif what == "cnn":
+        export_weights()
         for name, case in CASES.items():
             if case["primary"] != "cnn":
                 continue
