@@ -1084,3 +1084,75 @@ int orc_detect_start_peak_minibatch(const float *batch, const int32_t *full_len,
     free(sp);
     return 0;
 }
+
+/* ------------------------------------------------------------------ CNN path (C1, C4) */
+
+/* C1 prepare_data for one read (adapted/detect/cnn.py:70-82): pooled raw signal from min_obs_adapter,
+ * per-read nanmedian / MAD, (x - med)/mad, torch.nan_to_num(-5.0).  out[Lc], Lc = ceil((m-off)/ds). */
+long orc_cnn_prepare_row(const float *row, long m, const orc_cfg *cfg, float *out)
+{
+    long off = cfg->min_obs_adapter; int ds = cfg->downscale_factor;
+    long Lc = orc_pool_row(row + off, m - off, ds, 0, 0, 1, 0, 0, out);
+    float med = orc_np_nanmedian_f32(out, Lc, NULL);
+    float *t = (float *)malloc(sizeof(float) * (Lc > 0 ? Lc : 1));
+    for (long j = 0; j < Lc; j++) t[j] = fabsf(out[j] - med);
+    float mad = orc_np_nanmedian_f32(t, Lc, NULL);
+    free(t);
+    for (long j = 0; j < Lc; j++) {
+        float v = (out[j] - med) / mad;
+        if (v != v) v = -5.0f;
+        else if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+        out[j] = v;
+    }
+    return Lc;
+}
+
+/* C4 "hail mary" (adapted/detect/combined.py:259-298): per-read normalisation of signal[:min(T, full_len)],
+ * pooling of [adapter_end:polya_end], LLR trace with offsets 5/5, P4.  Returns the new polya_end in samples
+ * (0 if none); *status = 0, 13 (empty trace: np.argmin raises) or 14 (MAD == 0). */
+long orc_cnn_fallback(const float *row, long m, long full_len, long a_e, long p_e, const orc_cfg *cfg, int *status)
+{
+    long S = full_len < m ? full_len : m;
+    long T = cfg->max_obs_trace < S ? cfg->max_obs_trace : S;
+    double np4[4];
+    *status = 0;
+    if (orc_norm_params(row, 1, m, T, cfg->sig_norm_outlier_thresh, np4)) { *status = 14; return 0; }
+    long b = p_e < T ? p_e : T;
+    long Lseg = b > a_e ? b - a_e : 0;
+    int ds = cfg->downscale_factor;
+    long L = (Lseg + ds - 1) / ds;
+    float *down = (float *)malloc(sizeof(float) * (L > 0 ? L : 1));
+    orc_pool_row(row + a_e, Lseg, ds, 1, (float)np4[0], (float)np4[1], (float)np4[2], (float)np4[3], down);
+    long n_nan = 0;
+    for (long j = 0; j < L; j++) if (down[j] != down[j]) n_nan++;
+    long n = L - n_nan;
+    if (n <= 0) { free(down); *status = 13; return 0; }
+    double *c = (double *)malloc(sizeof(double) * n), *c2 = (double *)malloc(sizeof(double) * n), *g = (double *)malloc(sizeof(double) * n);
+    orc_cumsum(down, n, c, c2);
+    orc_gains(0, n - 1, c, c2, n, 5, 5, g);
+    long pe = orc_polya_peak(g, n);
+    free(down); free(c); free(c2); free(g);
+    return pe > 0 ? pe * ds + a_e : 0;
+}
+
+/* combined_detect_cnn given the CNN's predictions preds[N][1+k] (adapted/detect/combined.py:243-305) */
+void orc_detect_cnn_from_preds(const float *batch, const int32_t *full_len, long N, long m, const int64_t *preds, int k,
+                               const orc_cfg *cfg, orc_row *rows)
+{
+    for (long r = 0; r < N; r++) {
+        const float *row = batch + r * m;
+        const int64_t *p = preds + r * (1 + k);
+        orc_validate(row, m, full_len[r], (long)p[0], (long)p[1], p + 1, k, cfg, &rows[r]);
+        if (!rows[r].success && rows[r].fail_code < F_EXC_TOPK_NONE && p[0] > 0 && p[1] > 0 && p[1] - p[0] > 1000 &&
+            full_len[r] < 2 * (long)cfg->max_obs_adapter && cfg->fallback_to_llr_short_reads) {
+            int st;
+            long pe = orc_cnn_fallback(row, m, full_len[r], (long)p[0], (long)p[1], cfg, &st);
+            if (st) {
+                memset(&rows[r], 0, sizeof(orc_row)); rows[r].n_cand = -1; rows[r].n_open_pores = -1; rows[r].fail_code = st;
+            } else if (pe > 0) {
+                int64_t c1 = pe;
+                orc_validate(row, m, full_len[r], (long)p[0], pe, &c1, 1, cfg, &rows[r]);
+            }
+        }
+    }
+}

@@ -46,7 +46,9 @@ FAIL_STR = {0: None, 1: "No adapter detected (primary)", 2: "adapter MAD check f
             9: "'NoneType' object is not iterable",
             10: "slice indices must be integers or None or have an __index__ method",
             11: "Moving window (=%d) must between 1 and %d, inclusive",
-            12: "pA_mean_range is not specified"}
+            12: "pA_mean_range is not specified",
+            13: "attempt to get argmin of an empty sequence",
+            14: "MAD normalization failed: scale is 0"}
 SP_TYPES = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
 PRIMARY = {"llr": 0, "cnn": 1, "start_peak": 2}
 
@@ -97,7 +99,7 @@ def lib():
         for f in ("orc_np_sum_f64", "orc_np_nanstd_f64", "orc_np_percentile_diff_f32"):
             getattr(_LIB, f).restype = C.c_double
         for f in ("orc_find_peaks", "orc_correct_plateau", "orc_correct_split", "orc_adapter_candidate",
-                  "orc_polya_peak", "orc_pool_row"):
+                  "orc_polya_peak", "orc_pool_row", "orc_cnn_prepare_row", "orc_cnn_fallback"):
             getattr(_LIB, f).restype = C.c_long
     return _LIB
 
@@ -276,3 +278,96 @@ def find_peaks(x, distance=None, prominence=None, width=None, rel_height=0.5, ca
                          int(width is not None), C.c_double(width or 0.0), C.c_double(rel_height),
                          out.ctypes.data_as(C.POINTER(C.c_long)), C.c_long(cap))
     return out[:min(k, cap)]
+
+
+# ---------------------------------------------------------------------------- CNN path
+def cnn_prepare(batch, spc):
+    """C1 prepare_data -> float32 [N, Lc]"""
+    L = lib()
+    b, _ = _f32c(batch)
+    n, m = b.shape
+    cfg = make_cfg(spc)
+    ds, off = cfg.downscale_factor, cfg.min_obs_adapter
+    Lc = (m - off + ds - 1) // ds
+    out = np.zeros((n, Lc), dtype=np.float32)
+    for r in range(n):
+        L.orc_cnn_prepare_row(b[r].ctypes.data_as(C.POINTER(C.c_float)), C.c_long(m), C.byref(cfg),
+                              out[r].ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def _conv1d(x, w, b, stride, pad):
+    """float32 cross-correlation, x [N, Cin, L], w [Cout, Cin, K] (plain numpy restatement of torch Conv1d)"""
+    n, cin, L = x.shape
+    cout, _, K = w.shape
+    xp = np.zeros((n, cin, L + 2 * pad), dtype=np.float32)
+    xp[:, :, pad:pad + L] = x
+    Lo = (L + 2 * pad - K) // stride + 1
+    cols = np.stack([xp[:, :, k:k + stride * (Lo - 1) + 1:stride] for k in range(K)], axis=2)  # [N, Cin, K, Lo]
+    y = np.einsum("nckl,ock->nol", cols, w, optimize=True).astype(np.float32)
+    return y + b[None, :, None]
+
+
+def _conv_transpose1d(x, w, b, stride, pad):
+    """x [N, Cin, L], w [Cin, Cout, K] (torch ConvTranspose1d)"""
+    n, cin, L = x.shape
+    _, cout, K = w.shape
+    Lfull = (L - 1) * stride + K
+    y = np.zeros((n, cout, Lfull), dtype=np.float32)
+    contrib = np.einsum("ncl,cok->nokl", x, w, optimize=True).astype(np.float32)  # [N, Cout, K, L]
+    for k in range(K):
+        y[:, :, k:k + stride * (L - 1) + 1:stride] += contrib[:, :, k, :]
+    y = y[:, :, pad:Lfull - pad]
+    return y + b[None, :, None]
+
+
+def cnn_forward(x, weights):
+    """BoundariesCNN forward in numpy float32 (adapted/detect/cnn.py:16-52); x [N, Lc] -> scores [N, 2, Lo]"""
+    h = x[:, None, :].astype(np.float32)
+    h = np.maximum(_conv1d(h, weights["0.weight"], weights["0.bias"], 3, 3), 0)
+    h = np.maximum(_conv1d(h, weights["2.weight"], weights["2.bias"], 1, 3), 0)
+    h = np.maximum(_conv1d(h, weights["4.weight"], weights["4.bias"], 1, 3), 0)
+    return _conv_transpose1d(h, weights["6.weight"], weights["6.bias"], 3, 3)
+
+
+def cnn_predict(scores, spc):
+    """C3 cnn_predict + cnn_detect scaling (adapted/detect/cnn.py:101-182) on numpy scores"""
+    from scipy.signal import find_peaks
+
+    scores = scores.copy()
+    co = spc.core
+    n, _, Lo = scores.shape
+    na = (co.max_obs_adapter - co.min_obs_adapter) // co.downscale_factor
+    a = np.argmax(scores[:, 0, :na], axis=1)
+    k = spc.cnn_boundaries.polya_cand_k
+    ar = np.arange(Lo)[None, :]
+    scores[:, 1, :][ar < a[:, None]] = -5.0
+    p = np.argmax(scores[:, 1, :], axis=1)
+    scores[:, 1, :][ar > p[:, None]] = -5.0
+    flat = scores[:, 1, :].reshape(-1)
+    cand, _ = find_peaks(flat, distance=5)
+    rid = cand // Lo
+    order = np.lexsort((-flat[cand], rid))
+    cand = cand[order]
+    groups = np.split(np.mod(cand, Lo), np.where(np.diff(rid) != 0)[0] + 1)
+    top = np.zeros((n, k), dtype=np.int64)
+    for i, g in enumerate(groups):
+        top[i, :len(g)] = g[:k]
+    preds = (np.column_stack((a[:, None], top)) * co.downscale_factor + co.min_obs_adapter).astype(int)
+    preds[preds == co.min_obs_adapter] = 0
+    return preds
+
+
+def detect_cnn_from_preds(batch, full_lens, preds, spc):
+    """validate + short-read fallback given the CNN's predictions -> dict rows"""
+    L = lib()
+    b, bp = _f32c(batch)
+    n, m = b.shape
+    lens = np.ascontiguousarray(full_lens, dtype=np.int32)
+    pr = np.ascontiguousarray(preds, dtype=np.int64)
+    cfg = make_cfg(spc)
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    L.orc_detect_cnn_from_preds(bp, lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_long(n), C.c_long(m),
+                                pr.ctypes.data_as(C.c_void_p), int(pr.shape[1] - 1), C.byref(cfg),
+                                rows.ctypes.data_as(C.c_void_p))
+    return rows_to_dicts(rows, "cnn")

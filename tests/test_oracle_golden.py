@@ -85,3 +85,26 @@ def test_mad_zero_raises(oracle_mod):
     sig = np.full((4, spc.sig_preload_size), 80.0, dtype=np.float32)
     with pytest.raises(ValueError, match="scale is 0"):
         oracle_mod.detect_llr(sig, np.full(4, spc.sig_preload_size, dtype=np.int32), spc)
+
+
+def test_cnn_oracle_vs_golden(oracle_mod):
+    """C1 bit-exact, C2 (numpy conv) within 1e-4, C3 indices identical, rows (V1 with k candidates
+    + C4 fallback) bit-exact given the reference's predictions."""
+    import os
+
+    from util import GOLD
+
+    case, spc, sig, lens, want = load_case("rna004_cnn_default")
+    st = load_stages("rna004_cnn_default")
+    x = oracle_mod.cnn_prepare(sig, spc)
+    for k in st["dump_idx"]:
+        assert np.array_equal(x[int(k)], st["prep_%d" % int(k)])
+    w = np.load(os.path.join(os.path.dirname(GOLD), "..", "adapted_amd", "models", "rna004_130bps@v0.2.4.npz"))
+    sc = oracle_mod.cnn_forward(x, w)
+    for k in st["dump_idx"]:
+        assert np.max(np.abs(sc[int(k)] - st["scores_%d" % int(k)])) < 1e-4
+    preds = oracle_mod.cnn_predict(sc, spc)
+    assert np.array_equal(preds, st["preds"])
+    got = oracle_mod.detect_cnn_from_preds(sig, lens, st["preds"], spc)
+    bad = [(i, d) for i, (g, w_) in enumerate(zip(got, want)) for d in row_diffs(g, w_)]
+    assert not bad, bad[:10]
