@@ -53,7 +53,7 @@ struct adp_handle {
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
     DevBuf mbs, ghist, gbelow, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
-    DevBuf bounds, topk_none, rows, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
+    DevBuf bounds, topk_none, rows, preq, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -99,6 +99,7 @@ static int alloc_all(adp_handle *h)
     bad |= h->bounds.ensure(R * (1 + ADP_MAX_CAND) * 8);
     bad |= h->topk_none.ensure(R);
     bad |= h->rows.ensure(R * sizeof(adp_row));
+    bad |= h->preq.ensure(R * sizeof(PartReq));
     bad |= h->sp.ensure(R * sizeof(SpOut));
     bad |= h->any_none.ensure(64);
     h->vslots = (int)(R < 2048 ? R : 2048);
@@ -150,7 +151,7 @@ int adp_destroy(adp_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
-                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->vscratch, &h->pk,
+                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->vscratch, &h->pk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -271,8 +272,11 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
     in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
     int grid = n < h->vslots ? n : h->vslots;
-    Scope s(h, "k_validate");
-    hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>());
+    { Scope s(h, "k_validate");
+      hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+    { Scope s(h, "k_partition_stats");
+      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
+                         h->rows.as<adp_row>()); }
     return 0;
 }
 

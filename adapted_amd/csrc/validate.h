@@ -14,6 +14,7 @@
 #pragma once
 #include "common.h"
 #include "wave_stats.h"
+#include "block_stats.h"
 
 struct ValidateIn {
     const float *sig;          // [n_reads, m]
@@ -40,7 +41,7 @@ struct RowW {
 };
 
 // bottleneck.move_mean(a, window=w) for i >= w-1 (float32, NaN-free input) -- single lane
-static __device__ void bn_move_mean(const float *a, int n, int w, float *out)
+static __device__ __noinline__ void bn_move_mean(const float *a, int n, int w, float *out)
 {
     float asum = 0.f;
     for (int i = 0; i < w; i++) asum += a[i];
@@ -53,7 +54,7 @@ static __device__ void bn_move_mean(const float *a, int n, int w, float *out)
 }
 
 // bottleneck.move_var(a, window=w, ddof=0) for i >= w-1 -- single lane
-static __device__ void bn_move_var(const float *a, int n, int w, float *out)
+static __device__ __noinline__ void bn_move_var(const float *a, int n, int w, float *out)
 {
     float amean = 0.f, assqdm = 0.f;
     int count = 0;
@@ -105,7 +106,7 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
 
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
-static __device__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
+static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
                                    double pr1, WaveScratch *ws, float *scr_mean, float *scr_var)
 {
     MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
@@ -160,7 +161,8 @@ static __device__ void row_exception(adp_row *row, int code)
 }
 
 // persistent grid: blockIdx.x = slot, block = 64 threads
-__global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows)
+__global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows,
+                                                 PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;
     WaveScratch *ws = &ws_;
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
     for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
         adp_row *row = rows + r;
         row_clear(row);
+        if (ln == 0) preq[r].valid = 0;
         if (in.mbs && in.mbs[r / in.mbsize].status != ADP_MB_OK) continue; // dropped minibatch: zero row
         const float *sig = in.sig + (size_t)r * in.m;
         const long long full_len = in.full_len[r];
@@ -289,9 +292,14 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
             rw.set(ADP_C_MED_SHIFT, (double)sh);
             if (!in_range_d((double)sh, cfg.med_shift_range[0], cfg.med_shift_range[1])) { success = 0; fail = ADP_F_MED_SHIFT; }
         }
-        partition_stats(sig, S, a_s, a_e, rw, ADP_C_ADAPTER_START, ADP_C_ADAPTER_LEN, ws, have_med && a_s == 0, adapter_med, adapter_mad);
-        partition_stats(sig, S, a_e, p_best, rw, ADP_C_POLYA_START, ADP_C_POLYA_LEN, ws, false, 0.f, 0.f);
-        partition_stats(sig, S, p_best, S, rw, ADP_C_RNA_START, ADP_C_RNA_LEN, ws, false, 0.f, 0.f);
+        // S1 partition statistics are computed by k_partition_stats (one 256-thread block per read)
+        if (ln == 0) {
+            PartReq q;
+            q.valid = 1; q.S = S; q.a_s = a_s; q.a_e = a_e; q.p_e = p_best;
+            q.adapter_med = adapter_med; q.adapter_mad = adapter_mad;
+            q.have_adapter_medmad = (have_med && a_s == 0) ? 1 : 0; q.pad = 0;
+            preq[r] = q;
+        }
         rw.set(ADP_C_ADAPTER_END, (double)a_e);
         rw.set(ADP_C_POLYA_END, (double)p_best);
         rw.set(ADP_C_SIGNAL_LEN, (double)full_len);

@@ -20,6 +20,18 @@
 #define WS_STAGE_FLOATS (32 * 129)
 #define WS_LEAFBUF 160
 
+// barrier among the lanes of ONE wave that orders LDS traffic: a real s_barrier when the workgroup is a
+// single wave, otherwise a wave-level fence (LDS operations of one wave execute in order)
+static __device__ __forceinline__ void ws_sync()
+{
+    if (blockDim.x == 64) ws_sync();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 struct WaveScratch {
     uint32_t hist[256];
     float stage[WS_STAGE_FLOATS];
@@ -36,7 +48,7 @@ static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 
 // ---------------------------------------------------------------- selection
 // x_(k) and x_(k-1) of xform(x[0..n)), 0 <= k < n.  All lanes return the same values.
-static __device__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, WaveScratch *ws,
+static __device__ __noinline__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, WaveScratch *ws,
                                     float &vk, float &vkm1)
 {
     const int ln = lane_id();
@@ -46,7 +58,7 @@ static __device__ void wave_select2(const float *__restrict__ x, int n, int k, i
     for (int pass = 0; pass < 4; pass++) {
         const int shift = 24 - 8 * pass;
         for (int i = ln; i < 256; i += 64) ws->hist[i] = 0;
-        __syncthreads();
+        ws_sync();
         for (int base = 0; base < n; base += 256) {
             float v[4];
 #pragma unroll
@@ -72,7 +84,7 @@ static __device__ void wave_select2(const float *__restrict__ x, int n, int k, i
                 }
             }
         }
-        __syncthreads();
+        ws_sync();
         // locate the bin of rank krem: each lane owns 4 consecutive bins
         uint32_t h0 = ws->hist[4 * ln], h1 = ws->hist[4 * ln + 1], h2 = ws->hist[4 * ln + 2], h3 = ws->hist[4 * ln + 3];
         int s = (int)(h0 + h1 + h2 + h3);
@@ -104,7 +116,7 @@ static __device__ void wave_select2(const float *__restrict__ x, int n, int k, i
         }
         prefix = (prefix << 8) | (uint32_t)bin;
         krem -= before;
-        __syncthreads();
+        ws_sync();
     }
     vk = key2f(prefix);
     vkm1 = vk;
@@ -117,7 +129,7 @@ static __device__ void wave_select2(const float *__restrict__ x, int n, int k, i
 }
 
 // np.median(xform(x[0..n))) for a NaN-free float32 segment
-static __device__ float wave_median(const float *x, int n, int mode, float c, WaveScratch *ws)
+static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, WaveScratch *ws)
 {
     if (n <= 0) return __builtin_nanf("");
     float vk, vkm1;
@@ -128,7 +140,7 @@ static __device__ float wave_median(const float *x, int n, int mode, float c, Wa
 
 // one np.percentile(x, q) value (linear method): virtual index (n-1)*q/100 in float64,
 // diff in float32, interpolation in float64 (numpy/lib/_function_base_impl.py _lerp)
-static __device__ double wave_percentile(const float *x, int n, double q100, WaveScratch *ws)
+static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, WaveScratch *ws)
 {
     double q = q100 / 100.0;
     double vi = (double)(n - 1) * q;
@@ -148,34 +160,53 @@ static __device__ double wave_percentile(const float *x, int n, double q100, Wav
 }
 
 // ---------------------------------------------------------------- numpy-ordered sums
-static __device__ void ws_enum_leaves(const float *x, int off, int len, int mode, float c, WaveScratch *ws, int &id)
+// numpy's pairwise recursion, iteratively: a node longer than 128 splits into (n2, len - n2) with
+// n2 = (len/2) rounded down to a multiple of 8.  Leaves are visited left to right.
+static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int len0, int mode, float c, WaveScratch *ws, int &id)
 {
-    if (len <= 128) {
+    int st_off[16], st_len[16];
+    int sp = 0;
+    st_off[0] = off0; st_len[0] = len0; sp = 1;
+    while (sp > 0) {
+        sp--;
+        int off = st_off[sp], len = st_len[sp];
+        while (len > 128) {
+            int n2 = len / 2;
+            n2 -= n2 % 8;
+            st_off[sp] = off + n2; st_len[sp] = len - n2; sp++; // right child later
+            len = n2;                                           // descend left
+        }
         if ((id & 63) == lane_id()) {
             const float *p = x + off;
             ws->leaf[id] = pw_leaf_f32(len, [&](int i) { return ws_xform(p[i], mode, c); });
         }
         id++;
-        return;
     }
-    int n2 = len / 2;
-    n2 -= n2 % 8;
-    ws_enum_leaves(x, off, n2, mode, c, ws, id);
-    ws_enum_leaves(x, off + n2, len - n2, mode, c, ws, id);
 }
 
-static __device__ float ws_eval_tree(int len, const WaveScratch *ws, int &id)
+// post-order evaluation of the same tree over the leaf sums (every lane computes the same value)
+static __device__ __noinline__ float ws_eval_tree(int len0, const WaveScratch *ws, int &id)
 {
-    if (len <= 128) return ws->leaf[id++];
-    int n2 = len / 2;
-    n2 -= n2 % 8;
-    float a = ws_eval_tree(n2, ws, id);
-    float b = ws_eval_tree(len - n2, ws, id);
-    return a + b;
+    // explicit stack of (len, state, left value): state 0 = visit left, 1 = visit right, 2 = combine
+    int st_len[16]; int st_state[16]; float st_left[16];
+    int sp = 0;
+    st_len[0] = len0; st_state[0] = 0; sp = 1;
+    float ret = 0.0f;
+    while (sp > 0) {
+        int t = sp - 1;
+        int len = st_len[t];
+        if (len <= 128) { ret = ws->leaf[id++]; sp--; continue; }
+        int n2 = len / 2;
+        n2 -= n2 % 8;
+        if (st_state[t] == 0) { st_state[t] = 1; st_len[sp] = n2; st_state[sp] = 0; sp++; }
+        else if (st_state[t] == 1) { st_left[t] = ret; st_state[t] = 2; st_len[sp] = len - n2; st_state[sp] = 0; sp++; }
+        else { ret = st_left[t] + ret; sp--; }
+    }
+    return ret;
 }
 
 // np.add.reduce(xform(x[0..n))) in float32 with numpy's association
-static __device__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, WaveScratch *ws)
+static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, WaveScratch *ws)
 {
     const int ln = lane_id();
     float total = 0.0f;
@@ -185,13 +216,13 @@ static __device__ float wave_np_sum(const float *__restrict__ x, int n, int mode
         if (len == 8192) {
             float leafsum = 0.0f;
             for (int half = 0; half < 2; half++) {
-                __syncthreads();
+                ws_sync();
                 const float *p = x + s + half * 4096;
                 for (int t = 0; t < 64; t++) {
                     int e = t * 64 + ln;
                     ws->stage[(e >> 7) * 129 + (e & 127)] = ws_xform(p[e], mode, c);
                 }
-                __syncthreads();
+                ws_sync();
                 if ((ln >> 5) == half) {
                     const float *q = ws->stage + (ln & 31) * 129;
                     leafsum = pw_leaf_f32(128, [&](int i) { return q[i]; });
@@ -201,9 +232,9 @@ static __device__ float wave_np_sum(const float *__restrict__ x, int n, int mode
             chunk = leafsum;
         } else {
             int id = 0;
-            __syncthreads();
+            ws_sync();
             ws_enum_leaves(x + s, 0, len, mode, c, ws, id);
-            __syncthreads();
+            ws_sync();
             int id2 = 0;
             chunk = ws_eval_tree(len, ws, id2); // every lane evaluates the same small tree
         }
