@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -274,8 +275,11 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     int grid = n < h->vslots ? n : h->vslots;
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
     { Scope s(h, "k_partition_stats");
-      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
+      const char *sm = getenv("ADP_PART_SMEM"); size_t smb = sm ? (size_t)atoi(sm) : 0;
+      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), smb, h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
     return 0;
 }

@@ -5,6 +5,9 @@
 
 #include "adapted_hip.h"
 
+// pointers into LDS keep their address space across (non-inlined) function boundaries, so that
+// accesses stay ds_* instructions instead of degrading to flat_* ones
+#define LDS __attribute__((address_space(3)))
 #define WAVE 64
 #define CK 16          // cumulative-sum checkpoint spacing (pooled samples)
 #define TRACE_TILE 1024 // pooled samples handled per wave iteration in the gains kernel (64 lanes x CK)

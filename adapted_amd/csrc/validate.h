@@ -82,7 +82,7 @@ static __device__ __noinline__ void bn_move_var(const float *a, int n, int w, fl
 
 // calc_partition_stats -> (start, len, mean, std, med, mad)
 static __device__ void partition_stats(const float *sig, int S, long long start, long long end, RowW &rw, int c_start,
-                                       int c_len, WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
+                                       int c_len, LDS WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
 {
     rw.set(c_start, (double)start);
     if (end <= start) return;
@@ -107,7 +107,7 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
 static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
-                                   double pr1, WaveScratch *ws, float *scr_mean, float *scr_var)
+                                   double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var)
 {
     MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
     if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return o;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
                                                  PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;
-    WaveScratch *ws = &ws_;
+    LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
     const int ln = lane_id();
     float *scr_mean = in.scratch + (size_t)blockIdx.x * 2 * in.scratch_stride;
     float *scr_var = scr_mean + in.scratch_stride;
@@ -479,8 +479,9 @@ __global__ void __launch_bounds__(64) k_cnn_prepare(const float *__restrict__ si
     __threadfence_block();
     __syncthreads();
     const int n = Lc - nan_cnt;
-    float med = wave_median(o, n, 0, 0.f, &ws_);
-    float mad = wave_median(o, n, 1, med, &ws_);
+    LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
+    float med = wave_median(o, n, 0, 0.f, ws);
+    float mad = wave_median(o, n, 1, med, ws);
     __syncthreads();
     for (int j = ln; j < Lc; j += 64) {
         float v = (o[j] - med) / mad;

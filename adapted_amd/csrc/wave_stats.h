@@ -48,7 +48,7 @@ static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 
 // ---------------------------------------------------------------- selection
 // x_(k) and x_(k-1) of xform(x[0..n)), 0 <= k < n.  All lanes return the same values.
-static __device__ __noinline__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, WaveScratch *ws,
+static __device__ __noinline__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                     float &vk, float &vkm1)
 {
     const int ln = lane_id();
@@ -80,7 +80,7 @@ static __device__ __noinline__ void wave_select2(const float *__restrict__ x, in
                     uint32_t d0 = __shfl(digit, f);
                     bool same = !act || digit == d0;
                     if (__all(same)) { if (ln == f) ws->hist[d0] += (uint32_t)__popcll(m); }
-                    else if (act) atomicAdd(&ws->hist[digit], 1u);
+                    else if (act) __hip_atomic_fetch_add(&ws->hist[digit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -129,7 +129,7 @@ static __device__ __noinline__ void wave_select2(const float *__restrict__ x, in
 }
 
 // np.median(xform(x[0..n))) for a NaN-free float32 segment
-static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, WaveScratch *ws)
+static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, LDS WaveScratch *ws)
 {
     if (n <= 0) return __builtin_nanf("");
     float vk, vkm1;
@@ -140,7 +140,7 @@ static __device__ __noinline__ float wave_median(const float *x, int n, int mode
 
 // one np.percentile(x, q) value (linear method): virtual index (n-1)*q/100 in float64,
 // diff in float32, interpolation in float64 (numpy/lib/_function_base_impl.py _lerp)
-static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, WaveScratch *ws)
+static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, LDS WaveScratch *ws)
 {
     double q = q100 / 100.0;
     double vi = (double)(n - 1) * q;
@@ -162,7 +162,7 @@ static __device__ __noinline__ double wave_percentile(const float *x, int n, dou
 // ---------------------------------------------------------------- numpy-ordered sums
 // numpy's pairwise recursion, iteratively: a node longer than 128 splits into (n2, len - n2) with
 // n2 = (len/2) rounded down to a multiple of 8.  Leaves are visited left to right.
-static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int len0, int mode, float c, WaveScratch *ws, int &id)
+static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int len0, int mode, float c, LDS WaveScratch *ws, int &id)
 {
     int st_off[16], st_len[16];
     int sp = 0;
@@ -185,7 +185,7 @@ static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int
 }
 
 // post-order evaluation of the same tree over the leaf sums (every lane computes the same value)
-static __device__ __noinline__ float ws_eval_tree(int len0, const WaveScratch *ws, int &id)
+static __device__ __noinline__ float ws_eval_tree(int len0, const LDS WaveScratch *ws, int &id)
 {
     // explicit stack of (len, state, left value): state 0 = visit left, 1 = visit right, 2 = combine
     int st_len[16]; int st_state[16]; float st_left[16];
@@ -206,7 +206,7 @@ static __device__ __noinline__ float ws_eval_tree(int len0, const WaveScratch *w
 }
 
 // np.add.reduce(xform(x[0..n))) in float32 with numpy's association
-static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, WaveScratch *ws)
+static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, LDS WaveScratch *ws)
 {
     const int ln = lane_id();
     float total = 0.0f;
@@ -224,7 +224,7 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
                 }
                 ws_sync();
                 if ((ln >> 5) == half) {
-                    const float *q = ws->stage + (ln & 31) * 129;
+                    const LDS float *q = ws->stage + (ln & 31) * 129;
                     leafsum = pw_leaf_f32(128, [&](int i) { return q[i]; });
                 }
             }
@@ -243,10 +243,10 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
     return total;
 }
 
-static __device__ float wave_np_mean(const float *x, int n, WaveScratch *ws) { return wave_np_sum(x, n, 0, 0.0f, ws) / (float)n; }
+static __device__ float wave_np_mean(const float *x, int n, LDS WaveScratch *ws) { return wave_np_sum(x, n, 0, 0.0f, ws) / (float)n; }
 
 // np.var: mean in float32, squared deviations in float32, sum / n
-static __device__ float wave_np_var(const float *x, int n, WaveScratch *ws, float *mean_out)
+static __device__ float wave_np_var(const float *x, int n, LDS WaveScratch *ws, float *mean_out)
 {
     float mu = wave_np_mean(x, n, ws);
     if (mean_out) *mean_out = mu;
