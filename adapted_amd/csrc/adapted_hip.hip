@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "adapted_hip.h"
+__device__ int g_ablate = 0;
 #include "common.h"
 #include "llr_stream.h"
 #include "n1_select.h"
@@ -54,7 +55,7 @@ struct adp_handle {
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
     DevBuf mbs, ghist, gbelow, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
-    DevBuf bounds, topk_none, rows, preq, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
+    DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -71,6 +72,7 @@ static int geom(adp_handle *h)
     }
     if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
     if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
+    if ((c.max_obs_trace - c.min_obs_adapter) / c.downscale_factor > 150000) { g_err = "max_obs_trace too large for the LDS state of k_polya_peak"; return ADP_ERR_UNSUPPORTED; }
     h->T = c.max_obs_trace < h->m ? c.max_obs_trace : h->m;
     h->off = c.min_obs_adapter;
     h->ds = c.downscale_factor;
@@ -101,15 +103,16 @@ static int alloc_all(adp_handle *h)
     bad |= h->topk_none.ensure(R);
     bad |= h->rows.ensure(R * sizeof(adp_row));
     bad |= h->preq.ensure(R * sizeof(PartReq));
+    bad |= h->series.ensure(R * 2 * MVS_CAP * 4);
+    bad |= h->have_series.ensure(R);
     bad |= h->sp.ensure(R * sizeof(SpOut));
     bad |= h->any_none.ensure(64);
     h->vslots = (int)(R < 2048 ? R : 2048);
     h->vstride = ((h->m + 63) / 64) * 64;
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
-    h->pslots = (int)(R < 4096 ? R : 4096);
+    h->pslots = (int)(R < 2048 ? R : 2048);
     bad |= h->pk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
-    bad |= h->st.ensure((size_t)h->pslots * Lp);
     if (bad) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     return 0;
 }
@@ -152,7 +155,7 @@ int adp_destroy(adp_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
-                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->vscratch, &h->pk,
+                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -272,7 +275,17 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     in.kmax = kmax; in.n_reads = n; in.m = m; in.mbsize = mbsize;
     in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
     in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
+    in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>();
+    if (h->cfg.mvs_detect_check) {
+        Scope s(h, "k_mvs_series");
+        hipLaunchKernelGGL(k_mvs_series, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                           h->series.as<float>(), h->have_series.as<int8_t>());
+    } else {
+        (void)hipMemsetAsync(h->have_series.p, 0, (size_t)n, h->stream);
+    }
     int grid = n < h->vslots ? n : h->vslots;
+    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
     { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
@@ -301,6 +314,8 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         g_err = "device allocation failed"; return ADP_ERR_HIP;
     }
     hipStream_t st = h->stream;
+    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
+      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, st); }
     MbState *mbs = h->mbs.as<MbState>();
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
@@ -360,9 +375,9 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
             int grid = n < h->pslots ? n : h->pslots;
-            hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+            hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
-                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->st.as<uint8_t>(), h->polya_idx.as<int32_t>());
+                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>());
         }
     }
     if (upto >= 8) {
@@ -545,9 +560,9 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1);
     int grid = n < h->pslots ? n : h->pslots;
-    hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+    hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,
-                       h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->st.as<uint8_t>(), h->polya_idx.as<int32_t>());
+                       h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>());
     hipLaunchKernelGGL(k_refine_out, dim3((n + 255) / 256), dim3(256), 0, st, mbs, h->nvalid.as<int32_t>(), h->polya_idx.as<int32_t>(),
                        (const int64_t *)drng, n, h->ds, dout, dstat);
     HIPCHK(hipMemcpyAsync(polya_out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, st));

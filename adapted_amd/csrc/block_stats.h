@@ -24,7 +24,8 @@
 #define BS_BINS 2048
 #define BS_COLLECT 2048
 
-__device__ int g_ablate = 0; // timing experiments only (ADP_ABLATE); results are wrong when non-zero
+// (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
+extern __device__ int g_ablate;
 
 struct BlockScratch {
     union {
@@ -256,7 +257,7 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs,
     if (tid < 64) {
         // the staging area doubles as the wave scratch; the bucket lives in bs->collect (LDS, generic pointer)
         float vk, vkm1;
-        wave_select2((const float *)bs->collect, bs->ncollect, rk, 0, 0.f, &bs->u.ws, vk, vkm1);
+        wave_select2_lds(bs->collect, bs->ncollect, rk, 0, 0.f, &bs->u.ws, vk, vkm1);
         float res = vk;
         if ((n & 1) == 0) {
             float lo = (rk >= 1) ? vkm1 : key2f(below_key);

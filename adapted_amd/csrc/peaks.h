@@ -19,6 +19,7 @@
 #include "common.h"
 
 #define DBLMAX 1.7976931348623157e308
+extern __device__ int g_ablate;
 
 struct TraceView {
     const double *x;     // trace of one read (full-trace coordinates)
@@ -202,19 +203,20 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
 #define ST_KEPT 2
 #define ST_REMOVED 3
 
-// persistent grid of waves; slot scratch: pk[Lp/2+1] int32, mk[Lp/2+1] uint32, state[Lp] bytes
+// persistent grid of waves; slot scratch in HBM: pk[Lp/2+1] int32, mk[Lp/2+1] uint32; the per-position
+// state bytes live in dynamic LDS (Lp bytes per wave)
 __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
                                                    const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                    const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
                                                    const MbState *__restrict__ mbs, int32_t *__restrict__ pk_all,
-                                                   uint32_t *__restrict__ mk_all, uint8_t *__restrict__ st_all,
-                                                   int32_t *__restrict__ polya_idx)
+                                                   uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx)
 {
+    extern __shared__ uint8_t state_raw[];
+    LDS uint8_t *state = (LDS uint8_t *)state_raw;
     const int ln = lane_id();
     const int half = Lp / 2 + 1;
     int32_t *pk = pk_all + (size_t)blockIdx.x * half;
     uint32_t *mk = mk_all + (size_t)blockIdx.x * half;
-    uint8_t *state = st_all + (size_t)blockIdx.x * Lp;
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
         int result = 0;
         const int n = nvalid[r];
@@ -222,37 +224,71 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
         if (active) {
             const double *g = trace + (size_t)r * Lp;
             TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, 0, n - 1, 1};
-            // 1. all local maxima, in index order
+            // 1. all local maxima, in index order: one load per lane, neighbours by shuffle
             int npk = 0;
-            for (int base = 0; base < n; base += 64) {
-                int i = base + ln;
-                int p = (i < n) ? tv_peak_at(tv, i) : -1;
-                if (i < n) state[i] = ST_NONE;
-                unsigned long long m = __ballot(p >= 0);
-                if (p >= 0) pk[npk + __popcll(m & ((1ull << ln) - 1ull))] = p;
-                npk += __popcll(m);
+            double carry = 0.0; // value at base - 1
+            __syncthreads();
+            for (int base0 = 0; base0 < n; base0 += 256) {
+                double vv[4], ee[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { // four tiles in flight
+                    const int i = base0 + u * 64 + ln;
+                    vv[u] = (i < n) ? tv_get(tv, i) : 0.0;
+                    ee[u] = (ln == 63 && i + 1 < n) ? tv_get(tv, i + 1) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int base = base0 + u * 64;
+                    if (base >= n) break;
+                    const int i = base + ln;
+                    const double v = vv[u];
+                    double prev = __shfl_up(v, 1);
+                    if (ln == 0) prev = carry;
+                    double next = __shfl_down(v, 1);
+                    if (ln == 63) next = ee[u];
+                    carry = __shfl(v, 63);
+                    int p = -1;
+                    if (i > 0 && i < n - 1 && prev < v) {
+                        if (next < v) p = i;
+                        else if (next == v) { // plateau: walk to its end (rare on float64 traces)
+                            int j = i + 1;
+                            while (j < n - 1 && tv_get(tv, j) == v) j++;
+                            if (tv_get(tv, j) < v) p = (i + j - 1) / 2;
+                        }
+                    }
+                    if (i < n) state[i] = ST_NONE;
+                    unsigned long long m = __ballot(p >= 0);
+                    if (p >= 0) pk[npk + __popcll(m & ((1ull << ln) - 1ull))] = p;
+                    npk += __popcll(m);
+                }
             }
             __syncthreads();
+            if (g_ablate & 256) npk = 0;
             for (int k = ln; k < npk; k += 64) state[pk[k]] = ST_UNDECIDED;
             __syncthreads();
             // 2. per peak: which positions within +-9 hold a higher-priority peak
             //    (scipy _select_by_peak_distance, distance = 10 -> |dp| < 10; equal heights: later index first)
             for (int k = ln; k < npk; k += 64) {
-                int p = pk[k];
-                double xp = tv_get(tv, p);
-                uint32_t bits = 0;
+                const int p = pk[k];
+                const double xp = tv_get(tv, p);
+                uint32_t nb = 0;
+#pragma unroll
                 for (int o = -9; o <= 9; o++) {
                     int q = p + o;
-                    if (o == 0 || q < 0 || q >= n) continue;
-                    if (state[q] == ST_NONE) continue;
-                    double xq = tv_get(tv, q);
-                    if (xq > xp || (xq == xp && q > p)) bits |= 1u << (o + 9);
+                    if (o != 0 && q >= 0 && q < n && state[q] != ST_NONE) nb |= 1u << (o + 9);
                 }
+                double xq[19];
+#pragma unroll
+                for (int o = 0; o < 19; o++) xq[o] = (nb >> o & 1u) ? tv_get(tv, p + o - 9) : 0.0; // independent loads
+                uint32_t bits = 0;
+#pragma unroll
+                for (int o = 0; o < 19; o++)
+                    if ((nb >> o & 1u) && (xq[o] > xp || (xq[o] == xp && o > 9))) bits |= 1u << o;
                 mk[k] = bits;
             }
             __syncthreads();
             // 3. fixed point of "kept iff no kept higher-priority neighbour"
-            int nund = npk;
+            int nund = (g_ablate & 512) ? 0 : npk;
             while (nund > 0) {
                 int w = 0;
                 for (int base = 0; base < nund; base += 64) {
@@ -285,7 +321,7 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
             __syncthreads();
             // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
             int p0 = -1, p1 = -1;
-            for (int base = 0; base < n && p1 < 0; base += 64) {
+            for (int base = 0; base < n && p1 < 0 && !(g_ablate & 1024); base += 64) {
                 int i = base + ln;
                 bool ok = false;
                 if (i < n && state[i] == ST_KEPT) {

@@ -26,6 +26,8 @@ struct ValidateIn {
     const MbState *mbs;        // may be nullptr (no minibatch gating)
     float *scratch;            // [slots, 2, scratch_stride]
     int scratch_stride;
+    const float *series;       // [n_reads, 2, MVS_CAP] moving mean / var of candidate 0 (k_mvs_series) or nullptr
+    const int8_t *have_series; // [n_reads]
 };
 
 static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
@@ -107,7 +109,8 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
 static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
-                                   double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var)
+                                   double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
+                                   const float *pre_mean, const float *pre_var)
 {
     MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
     if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return o;
@@ -121,20 +124,25 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     }
     // the two sequential recurrences run side by side in lanes 0 and 1
     __syncthreads();
-    if (lane_id() == 0 && wvar) bn_move_var(x, n, cfg.pA_var_window, scr_var);
-    if (lane_id() == 1 && wmean) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
-    __threadfence_block();
+    if (pre_mean) { scr_mean = const_cast<float *>(pre_mean); scr_var = const_cast<float *>(pre_var); }
+    else {
+        if (lane_id() == 0 && wvar && !(g_ablate & 128)) bn_move_var(x, n, cfg.pA_var_window, scr_var);
+        if (lane_id() == 1 && wmean && !(g_ablate & 128)) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (sc && lane_id() == 0) sc->n = 0; // the scratch series were rewritten: drop any mirror of them
     __syncthreads();
     float fvar, fmean;
-    if (wvar) fvar = wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws);
+    if (wvar) fvar = wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws, sc);
     else fvar = wave_np_var(x, n, ws, nullptr);
-    if (wmean) fmean = wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws);
+    if (wmean) fmean = wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws, sc);
     else fmean = wave_np_mean(x, n, ws);
-    float fmed = wave_median(x, n, 0, 0.f, ws);
-    double lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws) - wave_percentile(x, n, 15.0, ws) : (double)__builtin_nanf("");
+    float fmed = wave_median(x, n, 0, 0.f, ws, sc);
+    double lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws, sc) - wave_percentile(x, n, 15.0, ws, sc) : (double)__builtin_nanf("");
     long long r1 = a_e + cfg.median_shift_window; if (r1 > S) r1 = S;
     long long l0 = a_e - cfg.median_shift_window; if (l0 < 0) l0 = 0;
-    float shift = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws);
+    float shift = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws, sc) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws, sc);
     o.mean = (double)fmean; o.var = (double)fvar; o.med = (double)fmed; o.lrange = lrange; o.shift = (double)shift;
     int f = 0;
     if (!in_range_d(o.mean, pr0, pr1)) f |= 1;
@@ -144,6 +152,35 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     if (!in_range_d(o.shift, cfg.median_shift_range[0], cfg.median_shift_range[1])) f |= 16;
     o.vec_fail = f; o.ok = (f == 0);
     return o;
+}
+
+// ---------------------------------------------------------------- V4 moving mean / variance series, ahead of time
+// The bottleneck recurrences are strictly sequential per read; inside k_validate they would occupy one
+// lane of a wave.  They only depend on (adapter_end, first poly(A) candidate), which are known before
+// validation starts, so this kernel runs them for candidate 0 with one LANE per read (64 reads per wave).
+#define MVS_CAP 8192
+__global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+                                                   int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
+                                                   float *__restrict__ series, int8_t *__restrict__ have)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_reads) return;
+    have[r] = 0;
+    const long long fl = full_len[r];
+    const int S = (int)(fl < m ? fl : m);
+    const long long a_e = bounds[(size_t)r * (1 + kmax)], p_e = kmax > 0 ? bounds[(size_t)r * (1 + kmax) + 1] : 0;
+    if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return;
+    if ((long long)S < a_e + cfg.median_shift_window) return;
+    const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
+    const int n = b - a;
+    const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
+    if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) return;
+    if (n > MVS_CAP) return;
+    const float *x = sigs + (size_t)r * m + a;
+    float *smean = series + (size_t)r * 2 * MVS_CAP, *svar = smean + MVS_CAP;
+    if (wvar) bn_move_var(x, n, cfg.pA_var_window, svar);
+    if (wmean) bn_move_mean(x, n, cfg.pA_mean_window, smean);
+    have[r] = 1;
 }
 
 static __device__ void row_clear(adp_row *row)
@@ -166,13 +203,14 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
 {
     __shared__ WaveScratch ws_;
     LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
+    LDS SegCache *sc = nullptr; // LDS mirror of the slice: measured slower (occupancy), kept switchable
     const int ln = lane_id();
     float *scr_mean = in.scratch + (size_t)blockIdx.x * 2 * in.scratch_stride;
     float *scr_var = scr_mean + in.scratch_stride;
     for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
         adp_row *row = rows + r;
         row_clear(row);
-        if (ln == 0) preq[r].valid = 0;
+        if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = nullptr; sc->n = 0; } }
         if (in.mbs && in.mbs[r / in.mbsize].status != ADP_MB_OK) continue; // dropped minibatch: zero row
         const float *sig = in.sig + (size_t)r * in.m;
         const long long full_len = in.full_len[r];
@@ -191,15 +229,15 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
         if (a_e == 0) { success = 0; fail = ADP_F_NO_ADAPTER; }
         else {
             int b = (int)(a_e < S ? a_e : S);
-            adapter_med = wave_median(sig, b, 0, 0.f, ws);
-            adapter_mad = wave_median(sig, b, 1, adapter_med, ws);
+            adapter_med = wave_median(sig, b, 0, 0.f, ws, sc);
+            adapter_mad = wave_median(sig, b, 1, adapter_med, ws, sc);
             have_med = true;
         }
         if (success && have_med && adapter_mad != 0.0f &&
             !in_range_d((double)adapter_mad, cfg.adapter_mad_range[0], cfg.adapter_mad_range[1])) {
             success = 0; fail = ADP_F_ADAPTER_MAD;
         }
-        if (success && cfg.detect_open_pores) {
+        if (success && cfg.detect_open_pores && !(g_ablate & 16)) {
             // V2: positions >= 200 pA; keep pos[i] (i >= 1) with a gap >= 10 to pos[i-1]; none kept -> [pos[-1]]
             const int b = (int)(a_e < S ? a_e : S);
             int npos = 0, nvalid = 0, prev_last = -1, lastpos = -1, lastvalid = -1;
@@ -233,7 +271,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
                 if (a_e - a_s < cfg.min_obs_adapter) { success = 0; fail = ADP_F_OPEN_PORE; }
             }
         }
-        if (success && cfg.real_signal_check) {
+        if (success && cfg.real_signal_check && !(g_ablate & 32)) {
             int a = (int)(a_s < S ? a_s : S), b = (int)(a_e < S ? a_e : S);
             int n = b - a; if (n < 0) n = 0;
             const float *x = sig + a;
@@ -246,7 +284,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
                 if (in_range_d((double)ms, cfg.mean_start_range[0], cfg.mean_start_range[1]) &&
                     in_range_d((double)me, cfg.mean_end_range[0], cfg.mean_end_range[1])) {
                     int k = n < cfg.max_obs_local_range ? n : cfg.max_obs_local_range;
-                    double lr = wave_percentile(x + n - k, k, 85.0, ws) - wave_percentile(x + n - k, k, 15.0, ws);
+                    double lr = wave_percentile(x + n - k, k, 85.0, ws, sc) - wave_percentile(x + n - k, k, 15.0, ws, sc);
                     rw.set(ADP_C_REAL_LOCAL_RANGE, lr);
                     ok = in_range_d(lr, cfg.local_range[0], cfg.local_range[1]);
                 }
@@ -254,7 +292,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
             if (!ok) { success = 0; fail = ADP_F_REAL_RANGE; }
         }
         bool exception = false;
-        if (success && cfg.mvs_detect_check) {
+        if (success && cfg.mvs_detect_check && !(g_ablate & 64)) {
             if (p_best == 0) { success = 0; fail = ADP_F_NO_POLYA; }
             else {
                 double pr0 = cfg.pA_mean_range[0], pr1 = cfg.pA_mean_range[1];
@@ -268,7 +306,9 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
                 for (int c = 0; !exception && c < in.kmax; c++) {
                     long long p_e = bd[1 + c];
                     if (p_e == 0) break;
-                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var);
+                    const bool pre = (c == 0) && in.series && in.have_series[r];
+                    const float *pm = pre ? in.series + (size_t)r * 2 * MVS_CAP : nullptr;
+                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pm ? pm + MVS_CAP : nullptr);
                     if (o.exc) { row_exception(row, o.exc); exception = true; break; }
                     rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
                     rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);
@@ -288,7 +328,7 @@ __global__ void __launch_bounds__(64) k_validate(ValidateIn in, adp_cfg cfg, adp
             long long r1 = a_e + w; if (r1 > full_len) r1 = full_len; if (r1 > S) r1 = S;
             long long a = a_e < S ? a_e : S;
             long long l0 = a_e - w; if (l0 < 0) l0 = 0; if (l0 > S) l0 = S;
-            float sh = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws);
+            float sh = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws, sc) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws, sc);
             rw.set(ADP_C_MED_SHIFT, (double)sh);
             if (!in_range_d((double)sh, cfg.med_shift_range[0], cfg.med_shift_range[1])) { success = 0; fail = ADP_F_MED_SHIFT; }
         }

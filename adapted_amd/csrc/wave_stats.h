@@ -38,6 +38,15 @@ struct WaveScratch {
     float leaf[WS_LEAFBUF];
 };
 
+// Optional LDS copy of the segment under analysis (k_validate): the many order statistics taken from
+// one adapter / poly(A) slice then cost ONE pass over global memory instead of four each.
+#define WS_SEG_CAP 6144
+struct SegCache {
+    float seg[WS_SEG_CAP];
+    const float *src; // global range currently mirrored: [src, src + n)
+    int n;
+};
+
 // transform applied on load: mode 0: x; mode 1: |x - c| (float32); mode 2: (x - c)^2 (float32)
 static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 {
@@ -48,8 +57,9 @@ static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 
 // ---------------------------------------------------------------- selection
 // x_(k) and x_(k-1) of xform(x[0..n)), 0 <= k < n.  All lanes return the same values.
-static __device__ __noinline__ void wave_select2(const float *__restrict__ x, int n, int k, int mode, float c, LDS WaveScratch *ws,
-                                    float &vk, float &vkm1)
+template <class P>
+static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int mode, float c, LDS WaveScratch *ws,
+                                                         float &vk, float &vkm1)
 {
     const int ln = lane_id();
     uint32_t prefix = 0, below = 0;
@@ -128,19 +138,53 @@ static __device__ __noinline__ void wave_select2(const float *__restrict__ x, in
     }
 }
 
+static __device__ __noinline__ void wave_select2_global(const float *__restrict__ x, int n, int k, int mode, float c,
+                                                        LDS WaveScratch *ws, float &vk, float &vkm1)
+{
+    wave_select2_impl<const float *>(x, n, k, mode, c, ws, vk, vkm1);
+}
+static __device__ __noinline__ void wave_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS WaveScratch *ws,
+                                                     float &vk, float &vkm1)
+{
+    wave_select2_impl<const LDS float *>(x, n, k, mode, c, ws, vk, vkm1);
+}
+
+// x_(k), x_(k-1) of xform(x[0..n)); with a SegCache the slice is mirrored into LDS first (reused while the
+// requested range stays inside the mirrored one)
+static __device__ void wave_select2(const float *x, int n, int k, int mode, float c, LDS WaveScratch *ws, float &vk,
+                                    float &vkm1, LDS SegCache *sc = nullptr)
+{
+    if (sc && n <= WS_SEG_CAP) {
+        const float *src = sc->src;
+        const int cn = sc->n;
+        if (!(src && x >= src && x + n <= src + cn)) {
+            ws_sync();
+            for (int i = lane_id(); i < n; i += 64) sc->seg[i] = x[i];
+            if (lane_id() == 0) { sc->src = x; sc->n = n; }
+            ws_sync();
+            src = x;
+        }
+        wave_select2_lds(sc->seg + (x - src), n, k, mode, c, ws, vk, vkm1);
+    } else {
+        wave_select2_global(x, n, k, mode, c, ws, vk, vkm1);
+    }
+}
+
 // np.median(xform(x[0..n))) for a NaN-free float32 segment
-static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, LDS WaveScratch *ws)
+static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, LDS WaveScratch *ws,
+                                                 LDS SegCache *sc = nullptr)
 {
     if (n <= 0) return __builtin_nanf("");
     float vk, vkm1;
-    wave_select2(x, n, n / 2, mode, c, ws, vk, vkm1);
+    wave_select2(x, n, n / 2, mode, c, ws, vk, vkm1, sc);
     if (n & 1) return vk;
     return (vkm1 + vk) / 2.0f;
 }
 
 // one np.percentile(x, q) value (linear method): virtual index (n-1)*q/100 in float64,
 // diff in float32, interpolation in float64 (numpy/lib/_function_base_impl.py _lerp)
-static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, LDS WaveScratch *ws)
+static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, LDS WaveScratch *ws,
+                                                      LDS SegCache *sc = nullptr)
 {
     double q = q100 / 100.0;
     double vi = (double)(n - 1) * q;
@@ -150,7 +194,7 @@ static __device__ __noinline__ double wave_percentile(const float *x, int n, dou
     int hi = min(lo + 1, n - 1);
     double g = vi - (double)lo;
     float vk, vkm1;
-    wave_select2(x, n, hi, 0, 0.0f, ws, vk, vkm1);
+    wave_select2(x, n, hi, 0, 0.0f, ws, vk, vkm1, sc);
     float a = (hi == lo) ? vk : vkm1;
     float b = vk;
     float diff = b - a;
