@@ -320,11 +320,22 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
             }
             __syncthreads();
             // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
-            int p0 = -1, p1 = -1;
-            for (int base = 0; base < n && p1 < 0 && !(g_ablate & 1024); base += 64) {
+            // survivors, compacted in index order (LDS state scan), then 64 candidates per step
+            int nkept = 0;
+            for (int base = 0; base < n; base += 64) {
                 int i = base + ln;
+                bool kp = (i < n) && state[i] == ST_KEPT;
+                unsigned long long m = __ballot(kp);
+                if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = i;
+                nkept += __popcll(m);
+            }
+            __syncthreads();
+            int p0 = -1, p1 = -1;
+            for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += 64) {
+                int k = base + ln;
+                int i = (k < nkept) ? pk[k] : -1;
                 bool ok = false;
-                if (i < n && state[i] == ST_KEPT) {
+                if (i >= 0) {
                     double prom = tv_prominence(tv, i);
                     if (1.0 <= prom) ok = (10.0 <= tv_width(tv, i, prom, 0.5));
                 }
@@ -332,7 +343,8 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                 while (m && p1 < 0) {
                     int f = __ffsll((long long)m) - 1;
                     m &= m - 1;
-                    if (p0 < 0) p0 = base + f; else p1 = base + f;
+                    int pi = __shfl(i, f);
+                    if (p0 < 0) p0 = pi; else p1 = pi;
                 }
             }
             // 5. spike heuristics on the UN-sanitised trace
