@@ -54,7 +54,7 @@ struct adp_handle {
     int max_reads = 0, m = 0;
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
-    DevBuf mbs, ghist, gbelow, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf mbs, ghist, gbelow, gcnt, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
     DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
@@ -154,7 +154,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -297,6 +297,43 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     return 0;
 }
 
+// N1 for all minibatches: sampled guess + two verified full passes per statistic (n1_select.h)
+static void launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile)
+{
+    hipStream_t st = h->stream;
+    MbState *mbs = h->mbs.as<MbState>();
+    uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
+    unsigned long long *gc = h->gcnt.as<unsigned long long>();
+    int bpm = 4096 / n_mb; if (bpm > 256) bpm = 256; if (bpm < 4) bpm = 4;
+    dim3 hg(bpm, n_mb), pg(n_mb);
+    int row_step = minibatch / 32; if (row_step < 1) row_step = 1;
+    int sb = (minibatch + row_step - 1) / row_step; if (sb > bpm) sb = bpm; if (sb < 1) sb = 1;
+    dim3 sg(sb, n_mb);
+    const double thr = h->cfg.sig_norm_outlier_thresh;
+    for (int mode = 0; mode < 2; mode++) {
+        // guess from a row sample
+        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS);
+        hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS);
+        hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        // pass 1 over everything, verified
+        if (profile) { Scope s(h, mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med");
+            hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS); }
+        else hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS);
+        hipLaunchKernelGGL((k_n1_pick<1, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        // fallback (runs only for minibatches whose guess missed)
+        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD);
+        hipLaunchKernelGGL((k_n1_pick<0, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD);
+        hipLaunchKernelGGL((k_n1_pick<1, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        // pass 2
+        if (profile) { Scope s(h, mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med");
+            hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS); }
+        else hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS);
+        hipLaunchKernelGGL((k_n1_pick<2, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+    }
+}
+
 static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int minibatch, int flags,
                         adp_row *rows_out, int32_t *mb_status, int upto)
 {
@@ -310,7 +347,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     if (rc) return rc;
     const int n_mb = (n + minibatch - 1) / minibatch;
     h->last_n = n; h->last_nmb = n_mb;
-    if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 4)) {
+    if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 4) || h->gcnt.ensure((size_t)n_mb * 16)) {
         g_err = "device allocation failed"; return ADP_ERR_HIP;
     }
     hipStream_t st = h->stream;
@@ -320,26 +357,12 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
     HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 4, st));
+    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n_mb * 16, st));
     const int T = h->T;
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
-        // ---- N1: median, then MAD (three radix passes each) -----------------------------
-        int bpm = 4096 / n_mb; if (bpm > 256) bpm = 256; if (bpm < 16) bpm = 16;
-        dim3 hg(bpm, n_mb);
-        uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
-        const double thr = h->cfg.sig_norm_outlier_thresh;
-        for (int mode = 0; mode < 2; mode++) {
-            { Scope s(h, mode ? "k_n1_hist<0> mad" : "k_n1_hist<0> med");
-              hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
-            hipLaunchKernelGGL(k_n1_pick<0>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-            { Scope s(h, mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med");
-              hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
-            hipLaunchKernelGGL(k_n1_pick<1>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-            { Scope s(h, mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med");
-              hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb); }
-            hipLaunchKernelGGL(k_n1_pick<2>, dim3(n_mb), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-        }
+        launch_n1(h, dsig, n, m, T, minibatch, n_mb, true);
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
             hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
@@ -530,7 +553,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) ||
+    if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) || h->gcnt.ensure((size_t)n * 16) ||
         h->bounds_stage.ensure((size_t)n * 16 + (size_t)n * 12)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     int64_t *drng = h->bounds_stage.as<int64_t>();
     int64_t *dout = drng + 2 * (size_t)n;
@@ -541,17 +564,8 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n * N1_BINS * 4, st));
     HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n * 4, st));
     HIPCHK(hipMemsetAsync(h->adapter_idx.p, 0, (size_t)n * 4, st));
-    uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
-    dim3 hg(4, n);
-    const double thr = h->cfg.sig_norm_outlier_thresh;
-    for (int mode = 0; mode < 2; mode++) { // per-read normalisation: every read is its own minibatch
-        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
-        hipLaunchKernelGGL(k_n1_pick<0>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
-        hipLaunchKernelGGL(k_n1_pick<1>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, h->T, 1, mode, mbs, gh, gb);
-        hipLaunchKernelGGL(k_n1_pick<2>, dim3(n), dim3(256), 0, st, mbs, gh, gb, mode, thr);
-    }
+    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n * 16, st));
+    launch_n1(h, dsig, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
     hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,

@@ -16,9 +16,10 @@
 // per-minibatch state of the batch-global normalisation (N1)
 struct MbState {
     unsigned long long n_valid;   // non-NaN samples in batch[:, :T]
-    unsigned long long krem;      // rank of the upper median inside the current prefix bucket
-    uint32_t prefix;              // resolved high bits of the selected key
-    uint32_t maxbelow;            // max key strictly below the prefix bucket (0 = none)
+    unsigned long long krem;      // rank of the upper median inside the current key window
+    unsigned long long c_below;   // samples whose key lies below the window (pass 1)
+    uint32_t kbase;               // first key of the current window (2^21 keys in pass 1, 2^10 in pass 2)
+    int32_t bad;                  // the sampled window missed the rank: aligned 3-pass path takes over
     float med, mad, lo, hi;       // N1 parameters (float32, as numpy holds them)
     int32_t status;               // ADP_MB_*
     int32_t pad;

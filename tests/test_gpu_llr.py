@@ -129,3 +129,33 @@ def test_llr_rows_vs_golden_and_oracle(hip, oracle_mod, name):
         for f in INDEX_FIELDS:
             assert getattr(g, f, None) == w.get(f), (i, f)
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["bimodal_rows", "nan_sample", "constant", "negatives"])
+def test_n1_guess_miss_falls_back_exactly(hip, oracle_mod, kind):
+    """N1 guesses a key window from every row_step-th read; when the guess misses, the verified
+    fallback must still return the exact numpy nanmedian / MAD."""
+    from adapted_amd import synth
+    from util import make_spc
+
+    spc = make_spc(CASES["rna004_llr_default"])
+    m = spc.sig_preload_size
+    n = 64  # row_step = 2: even rows are the sample
+    lens = np.full(n, m, dtype=np.int32)
+    sig, _ = synth.synth_batch(3, 0, n, m, lens)
+    if kind == "bimodal_rows":
+        sig[0::2] += np.float32(200.0)
+    elif kind == "nan_sample":
+        sig[0::2] = np.nan
+        lens[0::2] = 0
+    elif kind == "constant":
+        sig[:, :] = np.float32(77.25)
+        sig[1, 5] = np.float32(80.0)
+    elif kind == "negatives":
+        sig[1::2] *= np.float32(-1.0)
+    eng = _engine(hip, spc, n, m)
+    eng.debug_llr_upto(sig, lens, n, n, 1)
+    got = eng.debug_norm_params(1)[0]
+    rc, want = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    assert list(got) == list(want), (kind, got, want)
+    eng.close()
