@@ -1,0 +1,99 @@
+"""GPU parity at BASELINE.json sizes (max_obs_trace = 200 000, m = 201 500) on device-generated data:
+the oracle checks a bounded sample bit for bit, size-independent properties cover the rest."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _spc200k():
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect = True
+    spc.cnn_boundaries.cnn_detect = False
+    spc.core.max_obs_trace = 200000
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    return spc
+
+
+def _rows_equal(got, want):
+    bad = []
+    for i, (g, w) in enumerate(zip(got, want)):
+        for k, v in w.items():
+            if k.startswith("_"):
+                continue
+            a = getattr(g, k, None)
+            if hasattr(a, "tolist"):
+                a = a.tolist()
+            same = (a == v) or (isinstance(v, float) and a is not None and np.isnan(a) and np.isnan(v))
+            if not same:
+                bad.append((i, k, a, v))
+    return bad
+
+
+def test_pareto_lengths_config5_vs_oracle(oracle_mod):
+    """BASELINE configs[4]: lengths ~ Pareto clipped to [10k, 1M]; longer than m -> truncated, shorter ->
+    NaN tail.  One minibatch of 96 reads, every field identical to the oracle."""
+    from adapted_amd import lib, synth
+
+    spc = _spc200k()
+    m = spc.sig_preload_size
+    n = 96
+    lens = np.array([synth.pareto_length(77, i) for i in range(n)], dtype=np.int32)
+    assert lens.min() < m < lens.max()
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+    eng.h2d(dlen, lens)
+    eng.synth_fill(dsig, dlen, n, seed=77, first_read=0)
+    sig = np.zeros((n, m), dtype=np.float32)
+    eng.d2h(sig, dsig)
+    rows, mbs = eng.detect_llr_rows(dsig, dlen, n, n, with_start_peak=True, device_ptrs=True)
+    assert mbs[0] == 0
+    got = lib.rows_to_results(rows, "llr")
+    want = oracle_mod.detect_llr(sig, lens, spc, with_start_peak=True)
+    assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
+    assert sum(g.success for g in got) > n // 3
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
+
+
+def test_full_size_properties_and_sampled_oracle(oracle_mod):
+    """3 minibatches x 1000 reads at 200k: (a) minibatch 1 bit-identical to the oracle; (b) results do not
+    depend on how many minibatches travel in one call (sharding invariance); (c) structural invariants."""
+    from adapted_amd import lib
+
+    spc = _spc200k()
+    m = spc.sig_preload_size
+    mb, n = 1000, 3000
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+    eng.h2d(dlen, np.full(n, m, dtype=np.int32))
+    eng.synth_fill(dsig, dlen, n, seed=9, first_read=4000)
+    rows, mbs = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True)
+    assert (mbs == 0).all()
+    # (b) the middle minibatch alone, as its own call
+    rows_b, _ = eng.detect_llr_rows(dsig + mb * m * 4, dlen + mb * 4, mb, mb, device_ptrs=True)
+    assert rows[mb:2 * mb].tobytes() == rows_b.tobytes()
+    # (a) oracle on the middle minibatch
+    sig = np.zeros((mb, m), dtype=np.float32)
+    eng.d2h(sig, dsig + mb * m * 4)
+    want = oracle_mod.detect_llr(sig, np.full(mb, m, dtype=np.int32), spc)
+    got = lib.rows_to_results(rows_b, "llr")
+    assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
+    # (c) invariants over all rows
+    C = {name: i for i, name in enumerate(lib.COLS)}
+    col = rows["col"]
+    ok = rows["success"] == 1
+    assert ok.mean() > 0.8
+    a_s, a_e, p_e = col[:, C["adapter_start"]], col[:, C["adapter_end"]], col[:, C["polya_end"]]
+    assert (a_s[ok] <= a_e[ok]).all() and (a_e[ok] < p_e[ok]).all() and (p_e[ok] <= m).all()
+    assert ((a_e[ok] - spc.core.min_obs_adapter) % spc.core.downscale_factor == 0).all()
+    assert (col[ok, C["adapter_len"]] == a_e[ok] - a_s[ok]).all()
+    assert (col[ok, C["rna_preloaded_len"]] == m - p_e[ok]).all()
+    assert np.isfinite(col[ok][:, [C["adapter_med"], C["polya_med"], C["rna_preloaded_mad"]]]).all()
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
