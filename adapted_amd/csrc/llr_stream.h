@@ -87,12 +87,23 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
     double2 *c = ck + (size_t)r * nck;
     double a = 0.0, b = 0.0;
     double2 t = make_double2(0.0, 0.0);
-    for (int j = 0; j < n; j++) {
-        if ((j & (CK - 1)) == 0) c[j / CK] = make_double2(a, b);
-        if (j == n - 1) t = make_double2(a, b);
-        double v = (double)s[j];
-        a += v;
-        b += v * v;
+    // one checkpoint block (CK = 16 pooled samples) per iteration: the four float4 loads are independent of
+    // the add chain, so the memory latency is paid once per 16 sequential steps
+    const float4 *s4 = reinterpret_cast<const float4 *>(s); // rows start 256-byte aligned (Lp % 64 == 0)
+    for (int j0 = 0; j0 < n; j0 += CK) {
+        c[j0 / CK] = make_double2(a, b);
+        float4 q0 = s4[j0 / 4], q1 = s4[j0 / 4 + 1], q2 = s4[j0 / 4 + 2], q3 = s4[j0 / 4 + 3];
+        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+        for (int u = 0; u < CK; u++) {
+            const int j = j0 + u;
+            if (j < n) {
+                if (j == n - 1) t = make_double2(a, b);
+                double x = (double)v[u];
+                a += x;
+                b += x * x;
+            }
+        }
     }
     tail[r] = t;
 }
