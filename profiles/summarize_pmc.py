@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output (kernel stats + separate --pmc FETCH_SIZE / WRITE_SIZE passes) into the
+per-launch HBM traffic of each kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (section HBM)
+prescribes for gfx950: FETCH_SIZE (KB) counts 64 B per 128-B request on streaming reads -> doubled;
+WRITE_SIZE (KB) is taken as is.  The correction is cross-checked on k_n1_hist<2>, whose true read volume
+is known exactly (n_reads * T * 4 bytes).
+
+usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <reads_per_launch> <T> <out.json>
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel_max(path):
+    best = collections.defaultdict(float)
+    for row in csv.DictReader(open(path)):
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        best[k] = max(best[k], float(row["Counter_Value"]))
+    return best
+
+
+def main():
+    fetch, write, reads, T, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    f, w = per_kernel_max(fetch), per_kernel_max(write)
+    res = {"_note": "bytes per launch of the largest dispatch; fetch = 2 * FETCH_SIZE * 1024, write = WRITE_SIZE * 1024",
+           "_reads_per_launch": reads}
+    for k in sorted(set(f) | set(w)):
+        fb, wb = 2.0 * f.get(k, 0.0) * 1024.0, w.get(k, 0.0) * 1024.0
+        res[k] = {"fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb}
+    known = reads * T * 4.0
+    if "k_n1_hist<2>" in res:
+        res["_calibration"] = {"kernel": "k_n1_hist<2>", "true_read_bytes": known,
+                               "corrected_fetch_bytes": res["k_n1_hist<2>"]["fetch_bytes"],
+                               "ratio": res["k_n1_hist<2>"]["fetch_bytes"] / known}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in sorted(((k, v) for k, v in res.items() if not k.startswith("_")), key=lambda kv: -kv[1]["hbm_bytes"])[:16]:
+        print("%-28s fetch %8.2f GB  write %7.2f GB" % (k, v["fetch_bytes"] / 1e9, v["write_bytes"] / 1e9))
+    print(res.get("_calibration"))
+
+
+if __name__ == "__main__":
+    main()
