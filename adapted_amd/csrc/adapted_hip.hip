@@ -55,7 +55,7 @@ struct adp_handle {
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
     DevBuf mbs, ghist, gbelow, gcnt, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
-    DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
+    DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -111,7 +111,8 @@ static int alloc_all(adp_handle *h)
     h->vstride = ((h->m + 63) / 64) * 64;
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
     h->pslots = (int)(R < 2048 ? R : 2048);
-    bad |= h->pk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
+    bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
+    bad |= h->npk.ensure(R * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
     if (bad) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     return 0;
@@ -155,7 +156,7 @@ int adp_destroy(adp_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
-                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk,
+                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -380,7 +381,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<1>");
             hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
@@ -393,14 +394,14 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
             int grid = n < h->pslots ? n : h->pslots;
             hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
-                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>());
+                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
         }
     }
     if (upto >= 8) {
@@ -572,11 +573,11 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->ck.as<double2>(), h->tail.as<double2>());
     hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
-                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1);
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
     int grid = n < h->pslots ? n : h->pslots;
     hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,
-                       h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>());
+                       h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
     hipLaunchKernelGGL(k_refine_out, dim3((n + 255) / 256), dim3(256), 0, st, mbs, h->nvalid.as<int32_t>(), h->polya_idx.as<int32_t>(),
                        (const int64_t *)drng, n, h->ds, dout, dstat);
     HIPCHK(hipMemcpyAsync(polya_out, dout, (size_t)n * 8, hipMemcpyDeviceToHost, st));

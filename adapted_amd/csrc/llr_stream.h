@@ -125,7 +125,8 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                                               const int32_t *__restrict__ adapter_idx, int mbsize,
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
-                                              int2 *__restrict__ t1, int sanitize)
+                                              int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
+                                              int32_t *__restrict__ npk_all, int pk_stride)
 {
     __shared__ float sd[64 * (CK + 1)];
     __shared__ double sg[64 * (CK + 1)];
@@ -161,6 +162,13 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
         vs = (double)(E - start) * log(v);
     }
     int first_pos = 0x7fffffff, last_pos = -1;
+    // P4 needs every strict local maximum of the sanitised trace: they are picked up here, while the tile
+    // is in LDS, and handed to k_polya_peak as an index list (npk = -1: a plateau was met, recount there)
+    const bool emit = (PASS == 2 || sanitize) && pk_all;
+    int32_t *pk = emit ? pk_all + (size_t)r * pk_stride : nullptr;
+    int npk = 0;
+    bool plateau = false;
+    double carry1 = 0.0, carry2 = 0.0; // sanitised x[tb-1], x[tb-2]
     for (int tb = 0; tb < n; tb += TRACE_TILE) {
         // stage the pooled samples of this tile: coalesced -> LDS [lane][CK] (stride CK+1)
         __syncthreads();
@@ -223,6 +231,39 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
             int i = tb + e;
             if (i < n) g[i] = sg[(e / CK) * (CK + 1) + (e % CK)];
         }
+        if (emit) {
+            auto sval = [&](int e) { // sanitised value at tile offset e (e >= 0)
+                double x = sg[(e / CK) * (CK + 1) + (e % CK)];
+                if (x != x) x = 0.0;
+                else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+                return x;
+            };
+            for (int k = 0; k < CK; k++) {
+                const int e = k * 64 + ln;
+                const int i = tb + e;   // x[i] is "next"; the candidate is j = i - 1
+                const int j = i - 1;
+                bool pkf = false;
+                if (i < n && j >= 1) {
+                    double xn = sval(e);
+                    double xj = (e >= 1) ? sval(e - 1) : carry1;
+                    double xp = (e >= 2) ? sval(e - 2) : (e == 1 ? carry1 : carry2);
+                    if (xp < xj) {
+                        if (xn < xj) pkf = true;
+                        else if (xn == xj && !(xj == 0.0 && j >= E - ot)) plateau = true; // trailing zeros never peak
+                    }
+                }
+                unsigned long long mk = __ballot(pkf);
+                if (pkf) pk[npk + __popcll(mk & ((1ull << ln) - 1ull))] = j;
+                npk += __popcll(mk);
+            }
+            const int last = min(TRACE_TILE, n - tb) - 1;
+            double c1 = sval(last), c2v = (last >= 1) ? sval(last - 1) : carry1;
+            carry2 = c2v; carry1 = c1;
+        }
+    }
+    if (emit) {
+        plateau = __any(plateau);
+        if (ln == 0) npk_all[r] = plateau ? -1 : npk;
     }
     if (PASS == 1) {
         first_pos = wave_min(first_pos);

@@ -209,26 +209,31 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                                                    const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                    const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
                                                    const MbState *__restrict__ mbs, int32_t *__restrict__ pk_all,
-                                                   uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx)
+                                                   uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx,
+                                                   const int32_t *__restrict__ npk_all)
 {
     extern __shared__ uint8_t state_raw[];
     LDS uint8_t *state = (LDS uint8_t *)state_raw;
     const int ln = lane_id();
     const int half = Lp / 2 + 1;
-    int32_t *pk = pk_all + (size_t)blockIdx.x * half;
     uint32_t *mk = mk_all + (size_t)blockIdx.x * half;
     for (int r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        int32_t *pk = pk_all + (size_t)r * half; // per-read list, pre-filled by k_gains
         int result = 0;
         const int n = nvalid[r];
         const bool active = mbs[r / mbsize].status == ADP_MB_OK && adapter_idx[r] >= 0 && n >= 3;
         if (active) {
             const double *g = trace + (size_t)r * Lp;
             TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, 0, n - 1, 1};
-            // 1. all local maxima, in index order: one load per lane, neighbours by shuffle
-            int npk = 0;
+            // 1. all local maxima, in index order: normally found by k_gains while the trace tile was in LDS;
+            //    recounted here (one load per lane, neighbours by shuffle) when a plateau was met
+            int npk = npk_all[r];
+            const bool recount = npk < 0;
+            if (recount) npk = 0;
             double carry = 0.0; // value at base - 1
             __syncthreads();
-            for (int base0 = 0; base0 < n; base0 += 256) {
+            for (int i = ln; i < n; i += 64) state[i] = ST_NONE;
+            for (int base0 = 0; recount && base0 < n; base0 += 256) {
                 double vv[4], ee[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) { // four tiles in flight
@@ -256,7 +261,6 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                             if (tv_get(tv, j) < v) p = (i + j - 1) / 2;
                         }
                     }
-                    if (i < n) state[i] = ST_NONE;
                     unsigned long long m = __ballot(p >= 0);
                     if (p >= 0) pk[npk + __popcll(m & ((1ull << ln) - 1ull))] = p;
                     npk += __popcll(m);
