@@ -366,7 +366,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         launch_n1(h, dsig, n, m, T, minibatch, n_mb, true);
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
-            hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+            hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
                                (const int32_t *)nullptr);
         }
@@ -567,7 +567,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     HIPCHK(hipMemsetAsync(h->adapter_idx.p, 0, (size_t)n * 4, st));
     HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n * 16, st));
     launch_n1(h, dsig, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
-    hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)256 * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
+    hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>());

@@ -18,7 +18,8 @@
 #include "common.h"
 
 // ---------------------------------------------------------------- D1
-// grid = n_reads blocks of 256 threads; dynamic LDS = 256 * ds floats
+#define NP_TILE 512
+// grid = n_reads blocks of 256 threads; dynamic LDS = NP_TILE * ds floats
 // ranges != nullptr (CNN fallback C4): per-read pooled region [ranges[2r], min(ranges[2r+1], T, full_len))
 __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
@@ -44,29 +45,45 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
     const float *row = sig + (size_t)r * m + off;
     if (threadIdx.x == 0) s_nan = 0;
     int my_nan = 0;
-    const int tile_n = 256 * ds;
-    for (int tb = 0; tb < L; tb += 256) {
+    const int tile_n = NP_TILE * ds; // samples per tile (NP_TILE pooled outputs, 2 per thread)
+    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) && ((tile_n & 3) == 0);
+    auto norm1 = [&](float c) {
+        c = c < lo ? lo : c; // np.clip; NaN stays NaN
+        c = c > hi ? hi : c;
+        return (c - med) / mad;
+    };
+    for (int tb = 0; tb < L; tb += NP_TILE) {
         const int base = tb * ds;
         __syncthreads();
-        for (int i = threadIdx.x; i < tile_n; i += 256) {
-            int idx = base + i;
-            float v = 0.0f; // np.pad(..., mode="constant") for a ragged tail
-            if (idx < Lseg) {
-                float c = row[idx];
-                c = c < lo ? lo : c; // np.clip; NaN stays NaN
-                c = c > hi ? hi : c;
-                v = (c - med) / mad;
+        if (vec) {
+            const float4 *row4 = reinterpret_cast<const float4 *>(row + base);
+            for (int q = threadIdx.x; q < tile_n / 4; q += 256) {
+                const int idx = base + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // np.pad(..., mode="constant") for a ragged tail
+                if (idx + 3 < Lseg) { v = row4[q]; v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
+                else {
+                    if (idx < Lseg) v.x = norm1(row[idx]);
+                    if (idx + 1 < Lseg) v.y = norm1(row[idx + 1]);
+                    if (idx + 2 < Lseg) v.z = norm1(row[idx + 2]);
+                }
+                reinterpret_cast<float4 *>(tile)[q] = v;
             }
-            tile[i] = v;
+        } else {
+            for (int i = threadIdx.x; i < tile_n; i += 256) {
+                int idx = base + i;
+                tile[i] = (idx < Lseg) ? norm1(row[idx]) : 0.0f;
+            }
         }
         __syncthreads();
-        const int j = tb + threadIdx.x;
-        if (j < L) {
-            const float *p = tile + threadIdx.x * ds;
-            float s = pw_leaf_f32(ds, [&](int k) { return p[k]; });
-            float pooled = s / (float)ds;
-            down[(size_t)r * Lp + j] = pooled;
-            if (pooled != pooled) my_nan++;
+        for (int jj = threadIdx.x; jj < NP_TILE; jj += 256) {
+            const int j = tb + jj;
+            if (j < L) {
+                const float *p = tile + jj * ds;
+                float s = pw_leaf_f32(ds, [&](int k) { return p[k]; });
+                float pooled = s / (float)ds;
+                down[(size_t)r * Lp + j] = pooled;
+                if (pooled != pooled) my_nan++;
+            }
         }
     }
     my_nan = wave_sum(my_nan);
