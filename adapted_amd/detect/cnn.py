@@ -161,6 +161,48 @@ def cnn_detect_boundaries(batch_of_signals: np.ndarray, model, params, core_para
     return [Boundaries(adapter_start=0, adapter_end=p[0], polya_end=p[1], polya_end_topk=p[1:]) for p in preds]
 
 
+def detect_rows_device(eng, dsig: int, dlen: int, n: int, lens_host: np.ndarray, model, spc) -> np.ndarray:
+    """combined_detect_cnn over a DEVICE-resident batch (pointers) -> adp_row[]; the short-read fallback needs
+    the host copy of the few affected reads only."""
+    torch = _torch()
+    core = spc.core
+    m = eng.m
+    Lc = (m - core.min_obs_adapter + core.downscale_factor - 1) // core.downscale_factor
+    x = torch.empty((n, 1, Lc), dtype=torch.float32, device=torch.device("cuda", eng.device))
+    eng.cnn_prepare(dsig, n, x.data_ptr(), device_ptrs=True)
+    preds = (cnn_predict(x.to(_model_device(model)), model, spc.cnn_boundaries, core) * core.downscale_factor
+             + core.min_obs_adapter).astype(int)
+    preds[preds == core.min_obs_adapter] = 0
+    bounds = np.ascontiguousarray(preds, dtype=np.int64)
+    rows = eng.validate_rows(dsig, dlen, n, bounds, device_ptrs=True)
+    if spc.cnn_boundaries.fallback_to_llr_short_reads:
+        ae, pe = bounds[:, 0], bounds[:, 1]
+        need = ((rows["success"] == 0) & (rows["fail_code"] < 9) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
+                & (lens_host.astype(np.int64) < 2 * core.max_obs_adapter))
+        idx = np.flatnonzero(need)
+        if idx.size:
+            sub = np.zeros((idx.size, m), dtype=np.float32)
+            for j, i in enumerate(idx):
+                eng.d2h(sub[j], dsig + int(i) * m * 4)
+            _apply_fallback(eng, rows, idx, sub, lens_host[idx], bounds, spc)
+    return rows
+
+
+def _apply_fallback(eng, rows, idx, sig_sub, lens_sub, bounds, spc):
+    new_pe, status = eng.llr_refine_polya(sig_sub, lens_sub, idx.size, bounds[idx, :2])
+    for j, i in enumerate(idx):
+        if status[j] != 0:  # the reference raised inside its per-read try block
+            rows[i] = np.zeros(1, dtype=lib.ROW_DTYPE)[0]
+            rows[i]["n_cand"] = -1
+            rows[i]["n_open_pores"] = -1
+            rows[i]["fail_code"] = status[j]
+    redo = [j for j in range(idx.size) if status[j] == 0 and new_pe[j] > 0]
+    if redo:
+        ii = idx[redo]
+        b2 = np.stack([bounds[ii, 0], new_pe[redo]], axis=1).astype(np.int64)
+        rows[ii] = eng.validate_rows(sig_sub[redo], lens_sub[redo], len(ii), b2)
+
+
 def detect_rows(eng, sig: np.ndarray, lens: np.ndarray, model, spc) -> np.ndarray:
     """combined_detect_cnn over one batch -> adp_row[] (reference adapted/detect/combined.py:230-309)."""
     n = sig.shape[0]
@@ -176,18 +218,7 @@ def detect_rows(eng, sig: np.ndarray, lens: np.ndarray, model, spc) -> np.ndarra
                 & (lens.astype(np.int64) < 2 * spc.core.max_obs_adapter))
         idx = np.flatnonzero(need)
         if idx.size:
-            new_pe, status = eng.llr_refine_polya(sig[idx], lens[idx], idx.size, bounds[idx, :2])
-            for j, i in enumerate(idx):
-                if status[j] != 0:  # the reference raised inside its per-read try block
-                    rows[i] = np.zeros(1, dtype=lib.ROW_DTYPE)[0]
-                    rows[i]["n_cand"] = -1
-                    rows[i]["n_open_pores"] = -1
-                    rows[i]["fail_code"] = status[j]
-            redo = [j for j in range(idx.size) if status[j] == 0 and new_pe[j] > 0]
-            if redo:
-                ii = idx[redo]
-                b2 = np.stack([bounds[ii, 0], new_pe[redo]], axis=1).astype(np.int64)
-                rows[ii] = eng.validate_rows(sig[ii], lens[ii], len(ii), b2)
+            _apply_fallback(eng, rows, idx, sig[idx], lens[idx], bounds, spc)
     return rows
 
 

@@ -339,8 +339,12 @@ class Engine:
         del keep
         return rows
 
-    def cnn_prepare(self, signals: np.ndarray, n: int, out_dev_ptr: int):
+    def cnn_prepare(self, signals, n: int, out_dev_ptr: int, device_ptrs: bool = False):
         """C1 into a device buffer float32 [n, Lc] (e.g. a torch tensor's data_ptr)."""
+        if device_ptrs:
+            self._check(self.lib.adp_cnn_prepare(self._h, C.c_void_p(int(signals)), int(n), self.m, ADP_OUT_DEVICE | ADP_IN_DEVICE,
+                                                 C.c_void_p(int(out_dev_ptr))))
+            return
         sig = np.ascontiguousarray(signals, dtype=np.float32)
         self._check(self.lib.adp_cnn_prepare(self._h, sig.ctypes.data_as(C.c_void_p), int(n), self.m, ADP_OUT_DEVICE,
                                              C.c_void_p(int(out_dev_ptr))))

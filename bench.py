@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-start-peak", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--primary", choices=["llr", "cnn"], default="llr",
+                    help="llr: BASELINE configs[1] (default); cnn: configs[2] (PyTorch-ROCm conv head, per-minibatch calls)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
     args = ap.parse_args()
@@ -114,6 +116,13 @@ def main():
     from adapted_amd import lib
 
     spc = make_spc(args.max_obs_trace)
+    if args.primary == "cnn":
+        spc.llr_boundaries.llr_detect = False
+        spc.cnn_boundaries.cnn_detect = True
+        spc.update_primary_method()
+        from adapted_amd.detect import cnn as cnn_mod
+
+        cnn_model = cnn_mod.load_cnn_model(spc.cnn_boundaries.model_name, device=local)
     m = spc.sig_preload_size
     R, mb = args.reads, args.minibatch
     assert R % mb == 0, "--reads must be a whole number of minibatches"
@@ -136,7 +145,15 @@ def main():
 
     import threading
 
+    lens_host = np.full(R, m, dtype=np.int32)
+
     def run_part(k):
+        if args.primary == "cnn":  # one call per minibatch: conv head in torch, pre/post in the HIP library
+            for s0 in range(k * Rs, (k + 1) * Rs, mb):
+                rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, mb,
+                                                  lens_host[s0:s0 + mb], cnn_model, spc)
+                engines[k].h2d(rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize, rows)
+            return
         engines[k].detect_llr_rows(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, mb,
                                    with_start_peak=not args.no_start_peak, device_ptrs=True,
                                    rows_dev=rows_t.data_ptr() + k * Rs * lib.ROW_DTYPE.itemsize)
@@ -190,7 +207,7 @@ def main():
         rows = np.zeros(R, dtype=lib.ROW_DTYPE)
         eng.d2h(rows, rows_t.data_ptr())
         n_ok = int(rows["success"].sum())
-        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()} or {"(torch conv stack + host top-k)": dt / args.steps * 1e3}
         dom = max(kavg, key=kavg.get)
         b_alg = 4.0 * m * Rs  # 4*m input bytes per read, each launch covers Rs reads
         achieved = b_alg / (kavg[dom] * 1e-3) / 1e9
@@ -200,8 +217,10 @@ def main():
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 samples/statistics, f64 cumulative sums + LLR trace", "data": "synthetic (device-generated, adapted_amd/synth.py twin)",
-            "config": {"workload": "BASELINE configs[1]: RNA004 LLR + start_peak + validate, max_obs_trace=%d (m=%d), "
-                                   "minibatch=%d, %d reads/step/GPU resident in HBM" % (args.max_obs_trace, m, mb, R),
+            "config": {"workload": ("BASELINE configs[1]: RNA004 LLR + start_peak + validate" if args.primary == "llr" else
+                                    "BASELINE configs[2]: RNA004 CNN head (PyTorch-ROCm fp32) + validate") +
+                                   ", max_obs_trace=%d (m=%d), minibatch=%d, %d reads/step/GPU resident in HBM"
+                                   % (args.max_obs_trace, m, mb, R),
                        "reads_per_step_per_gpu": R, "minibatch": mb, "m": m, "pass_rate": n_ok / R, "streams_per_gpu": NS},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -213,7 +232,7 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "kernel_ms_sum": ksum,
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and args.primary == "llr":
             n_s = min(args.cpu_sample, R)
             out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows)
         else:
