@@ -54,7 +54,7 @@ struct adp_handle {
     int max_reads = 0, m = 0;
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
-    DevBuf mbs, ghist, gbelow, gcnt, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf mbs, ghist, gbelow, gcnt, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
     DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
@@ -67,8 +67,8 @@ struct adp_handle {
 static int geom(adp_handle *h)
 {
     const adp_cfg &c = h->cfg;
-    if (c.downscale_factor < 1 || c.downscale_factor > 64 || c.sp_downscale_factor < 1 || c.sp_downscale_factor > 64) {
-        g_err = "downscale_factor must be in [1, 64]"; return ADP_ERR_UNSUPPORTED;
+    if (c.downscale_factor < 1 || c.downscale_factor > 32 || c.sp_downscale_factor < 1 || c.sp_downscale_factor > 64) {
+        g_err = "downscale_factor must be in [1, 32]"; return ADP_ERR_UNSUPPORTED;
     }
     if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
     if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
@@ -91,6 +91,7 @@ static int alloc_all(adp_handle *h)
     int bad = 0;
     bad |= h->down.ensure(R * Lp * 4);
     bad |= h->nvalid.ensure(R * 4);
+    bad |= h->gstat.ensure(R * 24);
     bad |= h->ck.ensure(R * h->nck * sizeof(double2));
     bad |= h->tail.ensure(R * sizeof(double2));
     bad |= h->trace.ensure(R * Lp * 8);
@@ -155,7 +156,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -381,20 +382,20 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<1>");
             hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>());
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
             hipLaunchKernelGGL(k_adapter_peak, dim3(n), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), minibatch, mbs,
                                h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
-                               h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>());
+                               h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>());
         }
         if (upto >= 6) {
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>());
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
@@ -573,7 +574,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->ck.as<double2>(), h->tail.as<double2>());
     hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
-                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1);
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr);
     int grid = n < h->pslots ? n : h->pslots;
     hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,

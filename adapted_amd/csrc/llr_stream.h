@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
                                               int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
-                                              int32_t *__restrict__ npk_all, int pk_stride)
+                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat)
 {
     __shared__ float sd[64 * (CK + 1)];
     __shared__ double sg[64 * (CK + 1)];
@@ -179,6 +179,8 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
         vs = (double)(E - start) * log(v);
     }
     int first_pos = 0x7fffffff, last_pos = -1;
+    double st_s1 = 0.0, st_s2 = 0.0; // PASS 1: sum and sum of squares of the non-NaN trace values (for np.nanstd in P1)
+    int st_nan = 0;
     // P4 needs every strict local maximum of the sanitised trace: they are picked up here, while the tile
     // is in LDS, and handed to k_polya_peak as an index list (npk = -1: a plateau was met, recount there)
     const bool emit = (PASS == 2 || sanitize) && pk_all;
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                     gi = vs - (h + tl);
                 }
                 if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }
+                if (PASS == 1) { if (gi == gi) { st_s1 += gi; st_s2 += gi * gi; } else st_nan++; }
                 if (PASS == 1 && !sanitize) {
                     double m1 = (gi != gi) ? __builtin_inf() : gi;
                     mx = m1 > mx ? m1 : mx;
@@ -291,5 +294,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
             int en = (last_pos < 0) ? n - 1 : last_pos;
             t1[r] = make_int2(st, en);
         }
+        st_s1 = wave_sum(st_s1); st_s2 = wave_sum(st_s2); st_nan = wave_sum(st_nan);
+        if (ln == 0 && gstat) { gstat[3 * r] = st_s1; gstat[3 * r + 1] = st_s2; gstat[3 * r + 2] = (double)st_nan; }
     }
 }

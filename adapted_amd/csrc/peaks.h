@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
                                                      const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                      const int2 *__restrict__ t1, int mbsize, const MbState *__restrict__ mbs,
                                                      double prominence, double rel_height, int width,
-                                                     int32_t *__restrict__ adapter_idx)
+                                                     int32_t *__restrict__ adapter_idx, const double *__restrict__ gstat)
 {
     const int r = blockIdx.x;
     const int ln = lane_id();
@@ -156,16 +156,21 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
         const int2 se = t1[r];
         const int cn = se.y - se.x; // clip = g[start:end]
         if (cn >= 3) {
-            // np.nanstd(clip): mean over the non-NaN points, then the mean squared deviation.
-            // (float64 tree reduction: not numpy's summation order; it only scales a threshold.)
-            double s = 0.0; int cnt = 0;
-            for (int i = se.x + ln; i < se.y; i += 64) { double v = g[i]; if (v == v) { s += v; cnt++; } }
-            s = wave_sum(s); cnt = wave_sum(cnt);
-            double mean = s / (double)cnt;
-            double q = 0.0;
-            for (int i = se.x + ln; i < se.y; i += 64) { double v = g[i]; if (v == v) { double d = v - mean; q += d * d; } }
-            q = wave_sum(q);
-            double sd = sqrt(q / (double)cnt);
+            // np.nanstd(clip), clip = g[start:end]: k_gains<1> left the sum, sum of squares and NaN count of the whole
+            // trace; the few points outside the clip (all <= 0, never NaN, except possibly g[end]) are taken out here.
+            // (One-pass float64 moments instead of numpy's two passes: it only scales a threshold.)
+            double s1 = gstat[3 * r], s2 = gstat[3 * r + 1];
+            int nnan = (int)gstat[3 * r + 2];
+            double o1 = 0.0, o2 = 0.0; int onan = 0;
+            for (int i = ln; i < se.x; i += 64) { double v = g[i]; o1 += v; o2 += v * v; }
+            for (int i = se.y + ln; i < n; i += 64) { double v = g[i]; if (v == v) { o1 += v; o2 += v * v; } else onan++; }
+            o1 = wave_sum(o1); o2 = wave_sum(o2); onan = wave_sum(onan);
+            const int cnt = cn - (nnan - onan);
+            const double sum = s1 - o1, sq = s2 - o2;
+            const double mean = sum / (double)cnt;
+            double var = (sq - sum * mean) / (double)cnt;
+            if (var < 0.0) var = 0.0;
+            double sd = sqrt(var);
             TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, se.x, se.y - 1, 0};
             int peak = wave_first_peak(tv, prominence * sd, (double)width, rel_height);
             if (peak >= 0) {

@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=16000, help="reads per step per GPU (whole minibatches)")
+    ap.add_argument("--reads", type=int, default=32000, help="reads per step per GPU (whole minibatches)")
     ap.add_argument("--minibatch", type=int, default=1000)
     ap.add_argument("--max_obs_trace", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
