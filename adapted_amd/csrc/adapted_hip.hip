@@ -11,6 +11,7 @@
 
 #include "adapted_hip.h"
 __device__ int g_ablate = 0;
+__device__ unsigned long long g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #include "common.h"
 #include "llr_stream.h"
 #include "n1_select.h"
@@ -54,7 +55,7 @@ struct adp_handle {
     int max_reads = 0, m = 0;
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
-    DevBuf mbs, ghist, gbelow, gcnt, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf mbs, ghist, gbelow, gcnt, cbuf, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
     DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
@@ -156,7 +157,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -210,7 +211,7 @@ struct Scope {
     adp_handle *h; hipEvent_t b = nullptr;
     Scope(adp_handle *h_, const char *name) : h(h_)
     {
-        if (!h->profiling) return;
+        if (!h->profiling || !name) return;
         hipEvent_t a = next_event(h);
         b = next_event(h);
         (void)hipEventRecord(a, h->stream);
@@ -299,41 +300,47 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     return 0;
 }
 
-// N1 for all minibatches: sampled guess + two verified full passes per statistic (n1_select.h)
-static void launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile)
+// N1 for all minibatches (n1_select.h): sampled guess, then ONE verified full pass per statistic when the copied
+// bracket holds the rank (k_n1_finish), else the second pass; a missed window falls back to the aligned path.
+static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile)
 {
     hipStream_t st = h->stream;
     MbState *mbs = h->mbs.as<MbState>();
     uint32_t *gh = h->ghist.as<uint32_t>(), *gb = h->gbelow.as<uint32_t>();
     unsigned long long *gc = h->gcnt.as<unsigned long long>();
+    const int collect = ((long long)minibatch * T >= (1ll << 24)) ? 1 : 0; // only worth it (and sized) for big minibatches
+    if (collect && h->cbuf.ensure((size_t)n_mb * N1_CB_CAP * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    uint32_t *cb = h->cbuf.as<uint32_t>();
     int bpm = 4096 / n_mb; if (bpm > 256) bpm = 256; if (bpm < 4) bpm = 4;
     dim3 hg(bpm, n_mb), pg(n_mb);
-    int row_step = minibatch / 32; if (row_step < 1) row_step = 1;
+    // sample: every row_step-th read, one rotating eighth of its window (about 1/32 of the minibatch, from ~250 reads)
+    const int col_div = (T >= 8192) ? 8 : 1;
+    int row_step = (col_div > 1) ? minibatch / 256 : minibatch / 32; if (row_step < 1) row_step = 1;
     int sb = (minibatch + row_step - 1) / row_step; if (sb > bpm) sb = bpm; if (sb < 1) sb = 1;
     dim3 sg(sb, n_mb);
     const double thr = h->cfg.sig_norm_outlier_thresh;
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample
-        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS);
+        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
         hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS);
+        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
         hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 1 over everything, verified
-        if (profile) { Scope s(h, mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med");
-            hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS); }
-        else hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS);
+        { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med"));
+          hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS, cb, collect, 1); }
         hipLaunchKernelGGL((k_n1_pick<1, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
+        hipLaunchKernelGGL(k_n1_finish, pg, dim3(1024), 0, st, mbs, cb, gc, gb, mode, thr);
         // fallback (runs only for minibatches whose guess missed)
-        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD);
+        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1);
         hipLaunchKernelGGL((k_n1_pick<0, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD);
+        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1);
         hipLaunchKernelGGL((k_n1_pick<1, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        // pass 2
-        if (profile) { Scope s(h, mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med");
-            hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS); }
-        else hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS);
+        // pass 2 (only where the bracket did not settle it)
+        { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med"));
+          hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_NOT_DONE, cb, 0, 1); }
         hipLaunchKernelGGL((k_n1_pick<2, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
     }
+    return 0;
 }
 
 static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int minibatch, int flags,
@@ -349,7 +356,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     if (rc) return rc;
     const int n_mb = (n + minibatch - 1) / minibatch;
     h->last_n = n; h->last_nmb = n_mb;
-    if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 4) || h->gcnt.ensure((size_t)n_mb * 16)) {
+    if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 8) || h->gcnt.ensure((size_t)n_mb * 8 * N1_NCNT)) {
         g_err = "device allocation failed"; return ADP_ERR_HIP;
     }
     hipStream_t st = h->stream;
@@ -358,13 +365,14 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     MbState *mbs = h->mbs.as<MbState>();
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
-    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 4, st));
-    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n_mb * 16, st));
+    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 8, st));
+    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n_mb * 8 * N1_NCNT, st));
     const int T = h->T;
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
-        launch_n1(h, dsig, n, m, T, minibatch, n_mb, true);
+        rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true);
+        if (rc) return rc;
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
             hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
@@ -555,7 +563,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) || h->gcnt.ensure((size_t)n * 16) ||
+    if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) || h->gcnt.ensure((size_t)n * 8 * N1_NCNT) ||
         h->bounds_stage.ensure((size_t)n * 16 + (size_t)n * 12)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     int64_t *drng = h->bounds_stage.as<int64_t>();
     int64_t *dout = drng + 2 * (size_t)n;
@@ -564,10 +572,11 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     MbState *mbs = h->mbs.as<MbState>();
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n * N1_BINS * 4, st));
-    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n * 4, st));
+    HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n * 8, st));
     HIPCHK(hipMemsetAsync(h->adapter_idx.p, 0, (size_t)n * 4, st));
-    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n * 16, st));
-    launch_n1(h, dsig, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
+    HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n * 8 * N1_NCNT, st));
+    rc = launch_n1(h, dsig, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
+    if (rc) return rc;
     hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
@@ -670,6 +679,8 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     case 5: src = h->polya_idx.p; break;
     case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
     case 7: src = h->t1.p; break;
+    case 8: { if (bytes < 64) return ADP_ERR_INVALID;
+              HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), 64, 0, hipMemcpyDeviceToHost)); return ADP_OK; }
     default: return ADP_ERR_INVALID;
     }
     HIPCHK(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -1,43 +1,54 @@
 // block_stats.h -- S1 calc_partition_stats (mean, std, median, MAD of a read segment) by one
-// 256-thread workgroup per read, in FOUR passes over the segment instead of ten:
+// 256-thread workgroup per read, in TWO passes over the segment (four when a guess misses):
 //
-//   pass 1  numpy-ordered float32 sum (-> mean)   +  18-bit key histogram around a pivot (median bucket)
-//   pass 2  numpy-ordered sum of (x-mean)^2 (-> var)  +  collect the median bucket + max key below it
-//   pass 3  18-bit histogram of |x - med|
-//   pass 4  collect the MAD bucket + max key below it
+//   pass A  numpy-ordered float32 sum (-> mean)  +  histogram of the top 20 key bits inside a 4096-bucket
+//           window around a pivot (0.03 pA buckets near 100 pA): the median's bucket is known, and the
+//           histogram also tells, to a few buckets, where the MAD will be;
+//   pass B  numpy-ordered sum of (x-mean)^2 (-> std)  +  copy the median's bucket to LDS (+ largest key
+//           below it)  +  count the samples whose distance to the bucket centre is below a bracket
+//           [P, Q] around the predicted MAD and copy those inside it to LDS.
+//   The median is finished exactly inside its bucket; the MAD is finished inside the bracket and
+//   ACCEPTED ONLY IF the selected |x - med| values lie at least one bucket width inside [P, Q] -- that
+//   proves no sample outside the bracket can sit on the wrong side (|x-med| and |x-centre| differ by
+//   less than a bucket width).  Otherwise passes C/D histogram and collect |x - med| as before, and if
+//   the window itself missed the generic 4-pass radix select (wave_stats.h) runs: slower, never wrong.
 //
 // reference: adapted/partition/signal_partitions.py:81-96 (np.mean, np.std, np.median, np.median(|x-med|)
 // on float32 slices).  Sums follow numpy's add.reduce association exactly (8192-element chunks in
 // sequence; each chunk a balanced tree over 128-element leaves; each leaf 8 interleaved accumulators):
 // a half chunk (4096 samples) is staged in LDS with coalesced loads, 256 threads each run one
 // accumulator chain of 16 samples, xor-shuffles fold the 8 accumulators and then the 64 leaves.
-// Selection is exact: the histogram is over the top 18 bits of the order-preserving key inside a
-// 4-octave window around a pivot (0.125 pA bins near 100 pA); the bucket holding the wanted rank is
-// copied to LDS (<= 2048 samples) and finished there.  A rank outside the window or an overflowing
-// bucket falls back to the generic 4-pass radix select (wave_stats.h) -- slower, never wrong.
 #pragma once
 #include "common.h"
 #include "wave_stats.h"
 
 #define BS_THREADS 256
 #define BS_LEAF_STRIDE 136
-#define BS_BINS 2048
-#define BS_COLLECT 2048
+#define BS_BINS 4096      // 20-bit key buckets in the window of pass A
+#define BS_KSH 12         // key >> 12 = 20-bit bucket index
+#define BS_MEDCAP 1024    // samples of the median's bucket kept in LDS
+#define BS_MADCAP 4096    // samples of the MAD bracket kept in LDS (they reuse the histogram's storage)
+#define BS_BINS18 2048    // fallback passes C/D: 18-bit buckets, collect capacity 2048
 
 // (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
 extern __device__ int g_ablate;
+extern __device__ unsigned long long g_dbg[8]; // debug tallies (adp_debug_fetch what=8)
+
+// 16-byte load from a 4-byte aligned address (segments start anywhere): gfx950 global loads need dword alignment only
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct BlockScratch {
     union {
         float stage[32 * BS_LEAF_STRIDE];
         WaveScratch ws; // generic wave-level fallbacks reuse the staging area
     } u;
-    uint32_t hist[BS_BINS];
-    float collect[BS_COLLECT];
+    uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
+    float collect[BS_MEDCAP]; // samples of the median's bucket
     float leafsum[64];
     int scan[8];
-    int bin, before, ncollect, flag;
-    uint32_t below;
+    int bin, before, ncollect, nmad, flag;
+    uint32_t below, cntb;
     float bcast[4];
     int nleaf;
     short leaf_off[132], leaf_len[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk
@@ -85,72 +96,161 @@ static __device__ __noinline__ float bs_eval_tail(int tail, const LDS float *lea
 }
 
 enum { SIDE_NONE = 0, SIDE_HIST = 1, SIDE_COLLECT = 2 };
-struct SumAux { float sum; uint32_t aux; };
+struct SumAux { float sum; uint32_t aux, aux2; };
+struct SideParam { uint32_t key; float c, P, Q; int do_mad; };
 
-// per-sample side effect of a summing pass (kept in registers: no captured state)
-//   SIDE_HIST:    18-bit key histogram inside the window starting at `param`; aux counts samples below it
-//   SIDE_COLLECT: copy the samples of bucket `param` to LDS; aux tracks the largest key below the bucket
+// per-sample side effect of a summing pass (state in registers only)
+//   SIDE_HIST:    20-bit bucket histogram inside the window starting at p.key; aux counts samples below it
+//   SIDE_COLLECT: copy the samples of bucket p.key to LDS, aux = largest key below the bucket; with p.do_mad
+//                 also classify by dt = |v - p.c|: dt < P -> aux2++, P <= dt <= Q -> copy to the bracket buffer
 template <int SIDE>
-static __device__ __forceinline__ void bs_side(float v, uint32_t param, LDS BlockScratch *bs, uint32_t &aux)
+static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BlockScratch *bs, uint32_t &aux, uint32_t &aux2)
 {
     if (SIDE == SIDE_HIST) {
-        uint32_t k18 = f2key(v) >> 14;
-        if (k18 < param) aux++;
-        else if (k18 - param < (uint32_t)BS_BINS)
-            __hip_atomic_fetch_add(&bs->hist[k18 - param], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t kb = f2key(v) >> BS_KSH;
+        if (kb < p.key) aux++;
+        else if (kb - p.key < (uint32_t)BS_BINS)
+            __hip_atomic_fetch_add(&bs->hist[kb - p.key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t key = f2key(v);
-        uint32_t k18 = key >> 14;
-        if (k18 == param) {
+        uint32_t kb = key >> BS_KSH;
+        if (kb == p.key) {
             int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < BS_COLLECT) bs->collect[slot] = v;
-        } else if (k18 < param && key > aux) aux = key;
+            if (slot < BS_MEDCAP) bs->collect[slot] = v;
+        } else if (kb < p.key && key > aux) aux = key;
+        if (p.do_mad) {
+            float dt = fabsf(v - p.c);
+            if (dt < p.P) aux2++;
+            else if (dt <= p.Q) {
+                int slot = __hip_atomic_fetch_add(&bs->nmad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (slot < BS_MADCAP) ((LDS float *)bs->hist)[slot] = v;
+            }
+        }
+    }
+}
+
+// The same for four samples at once with the common path free of branches: out-of-window samples of the
+// histogram pass go to a dump cell, and the rare copies of the collect pass (about 1.6 % of the samples)
+// share ONE divergent branch per four samples.
+template <int SIDE>
+static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, float v3, const SideParam &p, LDS BlockScratch *bs,
+                                                uint32_t &aux, uint32_t &aux2)
+{
+    if (SIDE == SIDE_HIST) {
+        const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t kb = f2key(vv[i]) >> BS_KSH;
+            uint32_t d = kb - p.key;                    // wraps for kb < p.key
+            aux += (kb < p.key) ? 1u : 0u;
+            uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS; // dump cell
+            __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else if (SIDE == SIDE_COLLECT) {
+        const float vv[4] = {v0, v1, v2, v3};
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t key = f2key(vv[i]);
+            uint32_t kb = key >> BS_KSH;
+            uint32_t cand = (kb < p.key) ? key : 0u;    // largest key below the bucket
+            aux = cand > aux ? cand : aux;
+            bool special = (kb == p.key);
+            if (p.do_mad) {
+                float dt = fabsf(vv[i] - p.c);
+                aux2 += (dt < p.P) ? 1u : 0u;
+                special = special || (dt >= p.P && dt <= p.Q);
+            }
+            any = any || special;
+        }
+        if (any) { // rare per lane
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t kb = f2key(vv[i]) >> BS_KSH;
+                if (kb == p.key) {
+                    int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (slot < BS_MEDCAP) bs->collect[slot] = vv[i];
+                }
+                if (p.do_mad) {
+                    float dt = fabsf(vv[i] - p.c);
+                    if (dt >= p.P && dt <= p.Q) {
+                        int slot = __hip_atomic_fetch_add(&bs->nmad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (slot < BS_MADCAP) ((LDS float *)bs->hist)[slot] = vv[i];
+                    }
+                }
+            }
+        }
     }
 }
 
 // numpy-ordered sum of xf(x[0..n)) fused with a per-sample side effect; all threads return the sum and the
-// block-reduced aux (SIDE_HIST: count below the window; SIDE_COLLECT: max key below the bucket)
+// block-reduced aux (SIDE_HIST: count below the window; SIDE_COLLECT: max key below the bucket, aux2 = count
+// of samples closer to the centre than the bracket)
 template <int SIDE>
 static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, int n, int mode, float c, LDS BlockScratch *bs,
-                                                   uint32_t param)
+                                                   SideParam param)
 {
     const int tid = threadIdx.x;
-    uint32_t aux = 0;
+    uint32_t aux = 0, aux2 = 0;
     float total = 0.0f; // meaningful in wave 0
     int s = 0;
-    for (; s + 8192 <= n; s += 8192) {
-        for (int half = 0; half < 2; half++) {
-            const float *p = x + s + half * 4096;
-            float v[16];
+    // Each WAVE owns 8 consecutive leaves (1024 samples) of every half chunk: it stages, sums and folds them
+    // without block-wide barriers; the 8 wave partials of a chunk meet once per 8192 samples.
+    const int w = tid >> 6, ln = tid & 63;
+    LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
+    int parity = 0;
+    const int nhalf = (n / 8192) * 2; // half chunks of 4096 samples inside whole numpy chunks
+    f4u v[4], vn[4];
+    if (nhalf > 0) {
+        const f4u *p = reinterpret_cast<const f4u *>(x + w * 1024);
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = p[u * 256 + tid];
-            __syncthreads(); // previous chain reads of the staging area are done
-#pragma unroll
-            for (int u = 0; u < 16; u++) {
-                int e = u * 256 + tid;
-                bs_side<SIDE>(v[u], param, bs, aux);
-                bs->u.stage[(e >> 7) * BS_LEAF_STRIDE + (e & 127)] = bs_x2(v[u], mode, c);
-            }
-            __syncthreads();
-            const LDS float *q = bs->u.stage + (tid >> 3) * BS_LEAF_STRIDE + (tid & 7);
-            float r = q[0];
-#pragma unroll
-            for (int t = 1; t < 16; t++) r += q[8 * t];
-            r = r + __shfl_xor(r, 1);
-            r = r + __shfl_xor(r, 2);
-            r = r + __shfl_xor(r, 4);
-            if ((tid & 7) == 0) bs->leafsum[half * 32 + (tid >> 3)] = r;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            float l = bs->leafsum[tid];
-            for (int o = 1; o < 64; o <<= 1) l = l + __shfl_xor(l, o);
-            total += l;
-        }
+        for (int u = 0; u < 4; u++) v[u] = p[u * 64 + ln];
     }
+    for (int hc = 0; hc < nhalf; hc++) {
+        const int half = hc & 1;
+        if (hc + 1 < nhalf) { // software pipeline: the next half chunk's loads fly while this one is summed
+            const f4u *p = reinterpret_cast<const f4u *>(x + (size_t)(hc + 1) * 4096 + w * 1024);
+#pragma unroll
+            for (int u = 0; u < 4; u++) vn[u] = p[u * 64 + ln];
+        }
+        ws_sync(); // this wave's previous chain reads of its staging rows are done
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = (u * 64 + ln) * 4; // four consecutive samples of one leaf
+            bs_side4<SIDE>(v[u].x, v[u].y, v[u].z, v[u].w, param, bs, aux, aux2);
+            v4f t4 = {bs_x2(v[u].x, mode, c), bs_x2(v[u].y, mode, c), bs_x2(v[u].z, mode, c), bs_x2(v[u].w, mode, c)};
+            *reinterpret_cast<LDS v4f *>(wstage + (e >> 7) * BS_LEAF_STRIDE + (e & 127)) = t4;
+        }
+        ws_sync();
+        const LDS float *q = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
+        float r = q[0];
+#pragma unroll
+        for (int t = 1; t < 16; t++) r += q[8 * t];
+        r = r + __shfl_xor(r, 1);   // the 8 accumulators of a leaf
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        r = r + __shfl_xor(r, 8);   // the wave's 8 leaves: three levels of numpy's balanced tree
+        r = r + __shfl_xor(r, 16);
+        r = r + __shfl_xor(r, 32);
+        if (ln == 0) bs->leafsum[parity * 8 + half * 4 + w] = r;
+        if (half == 1) {
+            __syncthreads();
+            if (tid < 64) {
+                const LDS float *pp = bs->leafsum + parity * 8;
+                float h0 = (pp[0] + pp[1]) + (pp[2] + pp[3]);
+                float h1 = (pp[4] + pp[5]) + (pp[6] + pp[7]);
+                total += h0 + h1;
+            }
+            parity ^= 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = vn[u];
+    }
+    s = (nhalf / 2) * 8192;
+    __syncthreads();
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
-        for (int i = tid; i < tail; i += BS_THREADS) bs_side<SIDE>(x[s + i], param, bs, aux);
+        for (int i = tid; i < tail; i += BS_THREADS) bs_side<SIDE>(x[s + i], param, bs, aux, aux2);
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
         if (tid == 0) bs_enum_tail(tail, bs);
         __syncthreads();
@@ -195,7 +295,7 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, 
         if (tid < 64) total += bs_eval_tail(tail, bs->u.ws.leaf);
     }
     __syncthreads();
-    if (tid == 0) { bs->bcast[0] = total; bs->below = 0; }
+    if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }
     __syncthreads();
     if (SIDE == SIDE_HIST) {
         uint32_t w = (uint32_t)wave_sum((int)aux);
@@ -203,31 +303,39 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, 
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t w = wave_max(aux);
         if ((tid & 63) == 0 && w) __hip_atomic_fetch_max(&bs->below, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t w2 = (uint32_t)wave_sum((int)aux2);
+        if ((tid & 63) == 0 && w2) __hip_atomic_fetch_add(&bs->cntb, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     SumAux r;
     r.sum = bs->bcast[0];
     r.aux = bs->below;
+    r.aux2 = bs->cntb;
     __syncthreads();
     return r;
 }
 
+// window start (in buckets of 2^SH keys): half an octave below the pivot's octave
+template <int SH>
 static __device__ __forceinline__ uint32_t bs_window_lo(float pivot)
 {
-    uint32_t k18 = f2key(pivot) >> 14;
-    uint32_t oct = k18 & ~511u;
-    return oct >= 1024u ? oct - 1024u : 0u;
+    const uint32_t per_oct = 1u << (23 - SH);
+    uint32_t kb = f2key(pivot) >> SH;
+    uint32_t oct = kb & ~(per_oct - 1u);
+    return oct >= per_oct / 2 ? oct - per_oct / 2 : 0u;
 }
 
-// locate the bucket holding rank k in hist (counts below the window in `under`); sets bs->bin/before,
-// bs->flag = 1 if the rank lies outside the window
-static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, int k, int under)
+// locate the bucket holding rank k in h[0..NB) (with `under` samples before it); sets bs->bin/before,
+// bs->flag = 1 if the rank lies outside
+template <int NB>
+static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, const LDS uint32_t *hh, int k, int under)
 {
     const int tid = threadIdx.x;
-    uint32_t h[8];
+    constexpr int PER = NB / BS_THREADS;
+    uint32_t h[PER];
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) { h[j] = bs->hist[tid * 8 + j]; s += (int)h[j]; }
+    for (int j = 0; j < PER; j++) { h[j] = hh[tid * PER + j]; s += (int)h[j]; }
     int incl = wave_scan_incl(s);
     if ((tid & 63) == 63) bs->scan[tid >> 6] = incl;
     if (tid == 0) { bs->flag = 1; bs->bin = 0; bs->before = 0; }
@@ -238,8 +346,8 @@ static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, int k, 
     if (k >= excl && k < excl + s) {
         int cacc = excl;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (k >= cacc && k < cacc + (int)h[j]) { bs->bin = tid * 8 + j; bs->before = cacc; bs->flag = 0; }
+        for (int j = 0; j < PER; j++) {
+            if (k >= cacc && k < cacc + (int)h[j]) { bs->bin = tid * PER + j; bs->before = cacc; bs->flag = 0; }
             cacc += (int)h[j];
         }
     }
@@ -248,16 +356,15 @@ static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, int k, 
 
 struct SegStats { float mean, sd, med, mad; };
 
-// exact k-th / (k-1)-th from a collected bucket (wave 0), given the max key below the bucket
-static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs, int n, int rk, uint32_t below_key)
+// exact median from the collected bucket (wave 0), given the largest key below the bucket
+static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs, const LDS float *buf, int cnt, int n, int rk,
+                                                           uint32_t below_key)
 {
-    // called by all threads; wave 0 computes, result broadcast
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid < 64) {
-        // the staging area doubles as the wave scratch; the bucket lives in bs->collect (LDS, generic pointer)
         float vk, vkm1;
-        wave_select2_lds(bs->collect, bs->ncollect, rk, 0, 0.f, &bs->u.ws, vk, vkm1);
+        wave_select2_lds(buf, cnt, rk, 0, 0.f, &bs->u.ws, vk, vkm1);
         float res = vk;
         if ((n & 1) == 0) {
             float lo = (rk >= 1) ? vkm1 : key2f(below_key);
@@ -271,56 +378,18 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs,
     return r;
 }
 
-// mean / std / median / MAD of x[0..n), n >= 1.  have_medmad: reuse med_in / mad_in (adapter partition).
-static __device__ SegStats block_segment_stats(const float *__restrict__ x, int n, LDS BlockScratch *bs, bool have_medmad,
-                                               float med_in, float mad_in)
+// passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
+static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x, int n, LDS BlockScratch *bs, float med, float sd)
 {
     const int tid = threadIdx.x;
-    SegStats o;
     const int k1 = n / 2;
-    // ---- pass 1: mean + median histogram ------------------------------------------------
-    uint32_t wlo = 0;
-    if (!have_medmad) {
-        float a = x[n / 4], b = x[n / 2], c3 = x[(3 * (long long)n) / 4];
-        float pivot = fmaxf(fminf(a, b), fminf(fmaxf(a, b), c3));
-        wlo = bs_window_lo(pivot);
-    }
-    for (int i = tid; i < BS_BINS; i += BS_THREADS) bs->hist[i] = 0;
-    __syncthreads();
-    SumAux p1 = have_medmad ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, 0u) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, wlo);
-    o.mean = p1.sum / (float)n;
-    bool fallback_med = false;
-    int bin = 0, rk = 0;
-    if (!have_medmad) {
-        block_find_bin(bs, k1, (int)p1.aux);
-        fallback_med = bs->flag != 0;
-        bin = bs->bin; rk = k1 - bs->before;
-        __syncthreads();
-        if (tid == 0) bs->ncollect = 0;
-        __syncthreads();
-    }
-    // ---- pass 2: variance + collect the median bucket ----------------------------------------
-    const uint32_t target = wlo + (uint32_t)bin;
-    SumAux p2 = (have_medmad || fallback_med) ? block_np_sum<SIDE_NONE>(x, n, 2, o.mean, bs, 0u)
-                                              : block_np_sum<SIDE_COLLECT>(x, n, 2, o.mean, bs, target);
-    o.sd = sqrtf(p2.sum / (float)n);
-    if (have_medmad) { o.med = med_in; o.mad = mad_in; return o; }
-    if (fallback_med || bs->ncollect > BS_COLLECT) {
-        __syncthreads();
-        if (tid < 64) { float m_ = wave_median(x, n, 0, 0.f, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
-        __syncthreads();
-        o.med = bs->bcast[1];
-        __syncthreads();
-    } else {
-        o.med = bs_median_from_bucket(bs, n, rk, p2.aux);
-    }
-    if (g_ablate & 2) { o.mad = 0; return o; }
-    // ---- pass 3: histogram of |x - med| around 0.6745 * sd ------------------------------------
-    const float med = o.med;
-    float pivot = 0.6745f * o.sd;
+    LDS uint32_t *h18 = bs->hist;
+    LDS float *c18 = (LDS float *)(bs->hist + BS_BINS18);
+    float pivot = 0.6745f * sd;
     if (!(pivot > 0.f)) pivot = 1.0f;
-    wlo = bs_window_lo(pivot);
-    for (int i = tid; i < BS_BINS; i += BS_THREADS) bs->hist[i] = 0;
+    const uint32_t wlo = bs_window_lo<14>(pivot) >= 512u ? bs_window_lo<14>(pivot) - 512u : 0u; // [pivot_oct/4, pivot_oct*4)
+    __syncthreads();
+    for (int i = tid; i < BS_BINS18; i += BS_THREADS) h18[i] = 0;
     __syncthreads();
     int under = 0;
     for (int base = 0; base < n; base += BS_THREADS * 8) {
@@ -333,7 +402,7 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
             if (i < n) {
                 uint32_t k18 = f2key(fabsf(v[u] - med)) >> 14;
                 if (k18 < wlo) under++;
-                else if (k18 - wlo < (uint32_t)BS_BINS) __hip_atomic_fetch_add(&bs->hist[k18 - wlo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (k18 - wlo < (uint32_t)BS_BINS18) __hip_atomic_fetch_add(&h18[k18 - wlo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -342,14 +411,13 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     if ((tid & 63) == 0) bs->scan[4 + (tid >> 6)] = under;
     __syncthreads();
     under = bs->scan[4] + bs->scan[5] + bs->scan[6] + bs->scan[7];
-    block_find_bin(bs, k1, under);
-    const bool fallback_mad = bs->flag != 0;
-    bin = bs->bin; rk = k1 - bs->before;
+    block_find_bin<BS_BINS18>(bs, h18, k1, under);
+    const bool miss = bs->flag != 0;
+    const int bin = bs->bin, rk = k1 - bs->before;
     __syncthreads();
     if (tid == 0) { bs->ncollect = 0; bs->below = 0; }
     __syncthreads();
-    // ---- pass 4: collect the MAD bucket ----------------------------------------------------------
-    if (!fallback_mad) {
+    if (!miss) {
         const uint32_t tgt = wlo + (uint32_t)bin;
         uint32_t below = 0;
         for (int base = 0; base < n; base += BS_THREADS * 8) {
@@ -363,7 +431,7 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
                     float d = fabsf(v[u] - med);
                     uint32_t key = f2key(d);
                     uint32_t k18 = key >> 14;
-                    if (k18 == tgt) { int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (slot < BS_COLLECT) bs->collect[slot] = d; }
+                    if (k18 == tgt) { int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (slot < BS_BINS18) c18[slot] = d; }
                     else if (k18 < tgt && key > below) below = key;
                 }
             }
@@ -372,15 +440,136 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
         if ((tid & 63) == 0 && below) __hip_atomic_fetch_max(&bs->below, below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
     }
-    if (fallback_mad || bs->ncollect > BS_COLLECT) {
+    float mad;
+    if (miss || bs->ncollect > BS_BINS18) {
         __syncthreads();
         if (tid < 64) { float m_ = wave_median(x, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
         __syncthreads();
-        o.mad = bs->bcast[1];
+        mad = bs->bcast[1];
         __syncthreads();
     } else {
-        o.mad = bs_median_from_bucket(bs, n, rk, bs->below);
+        mad = bs_median_from_bucket(bs, c18, bs->ncollect, n, rk, bs->below);
     }
+    return mad;
+}
+
+// After pass A: predict where the MAD lies from the bucket histogram.  Returns false if no prediction.
+// c = centre of the median's bucket, w0 = its width; [P, Q] = bracket of distances to c.
+static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_t wlo, int bin, int k1, float &c, float &w0, float &P,
+                                                   float &Q)
+{
+    const int tid = threadIdx.x;
+    const uint32_t key_lo = (wlo + (uint32_t)bin) << BS_KSH;
+    const float c_lo = key2f(key_lo), c_hi = key2f(key_lo + (1u << BS_KSH));
+    c = 0.5f * (c_lo + c_hi);
+    w0 = c_hi - c_lo;
+    if (!(w0 > 0.f) || __builtin_isinf(c_hi) || __builtin_isinf(c_lo)) return false;
+    LDS uint32_t *dh = (LDS uint32_t *)bs->u.stage; // distance histogram, BS_BINS cells of width w0
+    __syncthreads();
+    for (int i = tid; i < BS_BINS; i += BS_THREADS) dh[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < BS_BINS; i += BS_THREADS) {
+        uint32_t h = bs->hist[i];
+        if (h) {
+            float xc = key2f(((wlo + (uint32_t)i) << BS_KSH) + (1u << (BS_KSH - 1)));
+            float d = fabsf(xc - c) / w0;
+            if (d < (float)BS_BINS) __hip_atomic_fetch_add(&dh[(int)d], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    block_find_bin<BS_BINS>(bs, dh, k1, 0);
+    const bool ok = bs->flag == 0;
+    const int j = bs->bin;
+    __syncthreads();
+    if (!ok) return false;
+    P = (float)(j - 3) * w0;
+    if (P < 0.f) P = 0.f;
+    Q = (float)(j + 4) * w0;
+    return true;
+}
+
+// mean / std / median / MAD of x[0..n), n >= 1.  have_medmad: reuse med_in / mad_in (adapter partition).
+static __device__ SegStats block_segment_stats(const float *__restrict__ x, int n, LDS BlockScratch *bs, bool have_medmad,
+                                               float med_in, float mad_in)
+{
+    const int tid = threadIdx.x;
+    SegStats o;
+    const int k1 = n / 2;
+    SideParam sp; sp.key = 0; sp.c = 0.f; sp.P = 0.f; sp.Q = 0.f; sp.do_mad = 0;
+    // ---- pass A: mean + bucket histogram --------------------------------------------------
+    uint32_t wlo = 0;
+    if (!have_medmad) {
+        float a = x[n / 4], b = x[n / 2], c3 = x[(3 * (long long)n) / 4];
+        float pivot = fmaxf(fminf(a, b), fminf(fmaxf(a, b), c3));
+        wlo = bs_window_lo<BS_KSH>(pivot);
+    }
+    __syncthreads();
+    for (int i = tid; i < BS_BINS; i += BS_THREADS) bs->hist[i] = 0;
+    __syncthreads();
+    sp.key = wlo;
+    SumAux p1 = (have_medmad || (g_ablate & 2048)) ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, sp);
+    o.mean = p1.sum / (float)n;
+    bool fallback_med = false, predicted = false;
+    int bin = 0, rk = 0;
+    float c = 0.f, w0 = 0.f, P = 0.f, Q = 0.f;
+    if (!have_medmad) {
+        block_find_bin<BS_BINS>(bs, bs->hist, k1, (int)p1.aux);
+        fallback_med = bs->flag != 0;
+        bin = bs->bin; rk = k1 - bs->before;
+        __syncthreads();
+        if (!fallback_med && !(g_ablate & 2)) predicted = bs_predict_mad(bs, wlo, bin, k1, c, w0, P, Q);
+        __syncthreads();
+        if (tid == 0) { bs->ncollect = 0; bs->nmad = 0; }
+        __syncthreads();
+    }
+    // ---- pass B: variance + median bucket + MAD bracket --------------------------------------
+    sp.key = wlo + (uint32_t)bin; sp.c = c; sp.P = P; sp.Q = Q; sp.do_mad = (predicted && !(g_ablate & 16384)) ? 1 : 0;
+    if (g_ablate & 4096) { o.sd = 0; o.med = 0; o.mad = 0; return o; }
+    SumAux p2 = (have_medmad || fallback_med || (g_ablate & (2048 | 8192))) ? block_np_sum<SIDE_NONE>(x, n, 2, o.mean, bs, sp)
+                                              : block_np_sum<SIDE_COLLECT>(x, n, 2, o.mean, bs, sp);
+    o.sd = sqrtf(p2.sum / (float)n);
+    if (have_medmad || (g_ablate & (2048 | 8192))) { o.med = med_in; o.mad = mad_in; return o; }
+    if (fallback_med || bs->ncollect > BS_MEDCAP) {
+        __syncthreads();
+        if (tid < 64) { float m_ = wave_median(x, n, 0, 0.f, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
+        __syncthreads();
+        o.med = bs->bcast[1];
+        __syncthreads();
+    } else {
+        o.med = bs_median_from_bucket(bs, bs->collect, bs->ncollect, n, rk, p2.aux);
+    }
+    // ---- MAD inside the bracket, if it can be proven ---------------------------------------------
+    bool done = false;
+    if (predicted && !fallback_med) {
+        const int M = bs->nmad;
+        const int rel = k1 - (int)p2.aux2;
+        const bool need_prev = (n & 1) == 0;
+        __syncthreads();
+        if (M <= BS_MADCAP && rel >= (need_prev ? 1 : 0) && rel < M) {
+            if (tid < 64) {
+                float vk, vkm1;
+                wave_select2_lds((const LDS float *)bs->hist, M, rel, 1, o.med, &bs->u.ws, vk, vkm1);
+                const float lo = need_prev ? vkm1 : vk;
+                // |x - med| and |x - c| differ by at most |med - c|: a selected value that far (plus slack) inside
+                // [P, Q] cannot be overtaken by a sample counted as "closer" or dropped as "farther"
+                // (med itself may sit outside the bucket when n is even: use the actual offset |med - c|)
+                const float dm = fabsf(o.med - c) + 0.25f * w0;
+                const bool proven = (lo >= P + dm) && (vk <= Q - dm) && (dm < 2.0f * w0);
+                if (tid == 0) { bs->bcast[2] = need_prev ? (vkm1 + vk) / 2.0f : vk; bs->flag = proven ? 1 : 0; }
+            }
+            __syncthreads();
+            if (bs->flag) { o.mad = bs->bcast[2]; done = true; }
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && n >= 8192) { // tallies for the large segments only
+        atomicAdd(&g_dbg[0], 1ull);
+        if (done) atomicAdd(&g_dbg[1], 1ull);
+        if (fallback_med) atomicAdd(&g_dbg[2], 1ull);
+        if (!predicted) atomicAdd(&g_dbg[3], 1ull);
+        if (predicted && !done && bs->nmad > BS_MADCAP) atomicAdd(&g_dbg[4], 1ull);
+    }
+    if (!done) o.mad = bs_mad_two_pass(x, n, bs, o.med, o.sd);
     return o;
 }
 

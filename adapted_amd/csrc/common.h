@@ -20,6 +20,9 @@ struct MbState {
     unsigned long long c_below;   // samples whose key lies below the window (pass 1)
     uint32_t kbase;               // first key of the current window (2^21 keys in pass 1, 2^10 in pass 2)
     int32_t bad;                  // the sampled window missed the rank: aligned 3-pass path takes over
+    uint32_t cklo, ckw;           // narrow bracket [cklo, cklo + ckw) whose keys pass 1 copies out (ckw = 0: none)
+    int32_t done;                 // the statistic was finished from the copied bracket: pass 2 is skipped
+    int32_t pad2;
     float med, mad, lo, hi;       // N1 parameters (float32, as numpy holds them)
     int32_t status;               // ADP_MB_*
     int32_t pad;

@@ -25,15 +25,22 @@
 #define N1_THREADS 256
 #define N1_WIN (1u << 21)
 
-enum { N1_ALWAYS = 0, N1_IF_BAD = 1 };
+#define N1_CB_LDS 4096          // per-block staging of bracket keys (flushed after every row)
+#define N1_CB_CAP (1u << 22)    // bracket keys kept per minibatch
+#define N1_NCNT 8               // u64 counters per minibatch: n_valid, below window, below bracket, bracket count, overflow
+
+enum { N1_ALWAYS = 0, N1_IF_BAD = 1, N1_IF_NOT_DONE = 2 };
+
+extern __device__ unsigned long long g_dbg[8];
 
 // transform: mode 0 -> x ; mode 1 -> |x - med| (float32, as numpy computes np.abs(signal - med))
 static __device__ __forceinline__ float n1_xform(float x, int mode, float med) { return mode ? fabsf(x - med) : x; }
 
-struct N1Acc { uint32_t below, d_prev, run; uint32_t nvalid, nbelow; };
+struct N1Acc { uint32_t below, d_prev, run; uint32_t nvalid, nbelow; uint32_t below2, nbelow2; };
 
 template <int PASS>
-static __device__ __forceinline__ void n1_account(float x, int mode, float med, uint32_t kbase, LDS uint32_t *hist, N1Acc &a)
+static __device__ __forceinline__ void n1_account(float x, int mode, float med, uint32_t kbase, LDS uint32_t *hist, N1Acc &a,
+                                                   uint32_t cklo, uint32_t ckw, LDS uint32_t *cb, LDS uint32_t *cb_cnt)
 {
     float v = n1_xform(x, mode, med);
     if (v != v) return;
@@ -42,6 +49,17 @@ static __device__ __forceinline__ void n1_account(float x, int mode, float med, 
     if (PASS == 0) digit = key >> 21;
     else if (PASS == 1) {
         a.nvalid++;
+        if (ckw) { // narrow bracket around the sampled rank: copy its keys out, count / track what lies below
+            uint32_t dd = key - cklo;
+            const bool lower = key < cklo;
+            a.nbelow2 += lower ? 1u : 0u;
+            const uint32_t cand = lower ? key : 0u;
+            a.below2 = cand > a.below2 ? cand : a.below2;
+            if (dd < ckw) { // ~0.3 % of the samples
+                uint32_t slot = __hip_atomic_fetch_add(cb_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (slot < N1_CB_LDS) cb[slot] = key;
+            }
+        }
         uint32_t d = key - kbase;
         if (d >= N1_WIN) { if (key < kbase) { a.nbelow++; if (key > a.below) a.below = key; } return; }
         digit = d >> 10;
@@ -63,41 +81,82 @@ template <int PASS>
 __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                          int mode, const MbState *__restrict__ mbs, uint32_t *__restrict__ ghist,
                                                          uint32_t *__restrict__ gbelow, unsigned long long *__restrict__ gcnt,
-                                                         int row_step, int when)
+                                                         int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div)
 {
     __shared__ uint32_t hist_[N1_BINS];
-    __shared__ uint32_t sbelow;
+    __shared__ uint32_t sbelow, sbelow2, cb_cnt_, cb_base;
+    __shared__ uint32_t cb_[PASS == 1 ? N1_CB_LDS : 1];
     LDS uint32_t *hist = (LDS uint32_t *)hist_;
+    LDS uint32_t *cb = (LDS uint32_t *)cb_;
+    LDS uint32_t *cb_cnt = (LDS uint32_t *)&cb_cnt_;
     const int mb = blockIdx.y;
     const MbState st = mbs[mb];
     if (st.status != ADP_MB_OK) return;
     if (when == N1_IF_BAD && !st.bad) return;
+    if (when == N1_IF_NOT_DONE && st.done) return;
+    const uint32_t cklo = st.cklo, ckw = (PASS == 1 && collect) ? st.ckw : 0u;
     for (int i = threadIdx.x; i < N1_BINS; i += N1_THREADS) hist[i] = 0;
-    if (threadIdx.x == 0) sbelow = 0;
+    if (threadIdx.x == 0) { sbelow = 0; sbelow2 = 0; cb_cnt_ = 0; }
     __syncthreads();
     const int r0 = mb * mbsize;
     const int r1 = min(n_reads, r0 + mbsize);
     const float med = st.med;
     const uint32_t kbase = st.kbase;
-    N1Acc a; a.below = 0; a.d_prev = 0xffffffffu; a.run = 0; a.nvalid = 0; a.nbelow = 0;
+    N1Acc a; a.below = 0; a.d_prev = 0xffffffffu; a.run = 0; a.nvalid = 0; a.nbelow = 0; a.below2 = 0; a.nbelow2 = 0;
     const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
         const float *row = sig + (size_t)r * m;
-        if (vec) {
+        if (col_div > 1) {
+            // sampling pass: one contiguous 1/col_div of the row, the part rotating from sampled row to sampled row so
+            // that every position of the window is covered by many different reads
+            const int Tc = (T / col_div) & ~3;
+            const int chunk = (int)(((r - r0) / row_step) % col_div);
+            const float *seg = row + (size_t)chunk * Tc;
+            if (vec) {
+                const float4 *seg4 = reinterpret_cast<const float4 *>(seg);
+                for (int i = threadIdx.x; i < (Tc >> 2); i += N1_THREADS) {
+                    float4 v = seg4[i];
+                    n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                    n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                    n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                    n1_account<PASS>(v.w, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                }
+            } else {
+                for (int i = threadIdx.x; i < Tc; i += N1_THREADS)
+                    n1_account<PASS>(seg[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+            }
+        } else if (vec) {
             const int T4 = T >> 2;
             const float4 *row4 = reinterpret_cast<const float4 *>(row);
             for (int i = threadIdx.x; i < T4; i += N1_THREADS) {
                 float4 v = row4[i];
-                n1_account<PASS>(v.x, mode, med, kbase, hist, a);
-                n1_account<PASS>(v.y, mode, med, kbase, hist, a);
-                n1_account<PASS>(v.z, mode, med, kbase, hist, a);
-                n1_account<PASS>(v.w, mode, med, kbase, hist, a);
+                n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                n1_account<PASS>(v.w, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
             }
             for (int i = (T4 << 2) + threadIdx.x; i < T; i += N1_THREADS)
-                n1_account<PASS>(row[i], mode, med, kbase, hist, a);
+                n1_account<PASS>(row[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
         } else {
             for (int i = threadIdx.x; i < T; i += N1_THREADS)
-                n1_account<PASS>(row[i], mode, med, kbase, hist, a);
+                n1_account<PASS>(row[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+        }
+        if (PASS == 1 && ckw) { // hand the row's bracket keys to the minibatch buffer: one global atomic per row and block
+            __syncthreads();
+            const uint32_t cnt = cb_cnt_;
+            if (threadIdx.x == 0) {
+                if (cnt > N1_CB_LDS) { atomicAdd(&gcnt[N1_NCNT * mb + 4], 1ull); cb_base = 0xffffffffu; }
+                else cb_base = cnt ? (uint32_t)atomicAdd(&gcnt[N1_NCNT * mb + 3], (unsigned long long)cnt) : 0u;
+            }
+            __syncthreads();
+            const uint32_t base = cb_base;
+            if (base != 0xffffffffu) {
+                uint32_t *dst = cbuf + (size_t)mb * N1_CB_CAP;
+                for (uint32_t i = threadIdx.x; i < cnt; i += N1_THREADS) if (base + i < N1_CB_CAP) dst[base + i] = cb[i];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) cb_cnt_ = 0;
+            __syncthreads();
         }
     }
     if (a.run) __hip_atomic_fetch_add(&hist[a.d_prev], a.run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -107,9 +166,13 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
     }
     if (PASS == 1) {
         unsigned long long nv = (unsigned long long)wave_sum((int)a.nvalid), nb = (unsigned long long)wave_sum((int)a.nbelow);
+        unsigned long long nb2 = (unsigned long long)wave_sum((int)a.nbelow2);
+        uint32_t b2 = wave_max(a.below2);
         if (lane_id() == 0) {
-            if (nv) atomicAdd(&gcnt[2 * mb], nv);
-            if (nb) atomicAdd(&gcnt[2 * mb + 1], nb);
+            if (nv) atomicAdd(&gcnt[N1_NCNT * mb], nv);
+            if (nb) atomicAdd(&gcnt[N1_NCNT * mb + 1], nb);
+            if (nb2) atomicAdd(&gcnt[N1_NCNT * mb + 2], nb2);
+            if (b2) atomicMax(&sbelow2, b2);
         }
     }
     __syncthreads();
@@ -118,7 +181,8 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
         uint32_t c = hist[i];
         if (c) atomicAdd(&gh[i], c);
     }
-    if (PASS > 0 && threadIdx.x == 0 && sbelow) atomicMax(&gbelow[mb], sbelow);
+    if (PASS > 0 && threadIdx.x == 0 && sbelow) atomicMax(&gbelow[2 * mb], sbelow);
+    if (PASS == 1 && threadIdx.x == 0 && sbelow2) atomicMax(&gbelow[2 * mb + 1], sbelow2);
 }
 
 // block-wide: total of the histogram and the bin holding rank k (bin = -1 if k >= total)
@@ -162,6 +226,7 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
     MbState st = mbs[mb];
     if (st.status != ADP_MB_OK) return;
     if (KIND == N1_FALLBACK && !st.bad) return;
+    if (PASS == 2 && st.done) return; // finished from the copied bracket (k_n1_finish)
     uint32_t *gh = ghist + (size_t)mb * N1_BINS;
     const int nb = (PASS == 2) ? 1024 : 2048;
     const int per = nb / 256;
@@ -177,22 +242,45 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
         __syncthreads();
         k = s_total / 2;
         __syncthreads();
-    } else if (PASS == 1 && KIND == N1_FULL) {
-        st.n_valid = gcnt[2 * mb];
-        st.c_below = gcnt[2 * mb + 1];
+    } else if (PASS == 1 && (KIND == N1_FULL || KIND == N1_SAMPLE)) {
+        st.n_valid = gcnt[N1_NCNT * mb];       // (of the sample for KIND sample)
+        st.c_below = gcnt[N1_NCNT * mb + 1];
         k = st.n_valid / 2; // absolute rank; made window-relative below
     } else {
         k = st.krem;
     }
     bool miss = false;
     unsigned long long krel = k;
-    if (PASS == 1 && KIND == N1_FULL) {
+    if (PASS == 1 && (KIND == N1_FULL || KIND == N1_SAMPLE)) {
         if (k < st.c_below) { miss = true; krel = 0; } else krel = k - st.c_below;
     }
     n1_find(gh, nb, krel, part, &s_bin, &s_before, &s_total, loc);
     const int bin = s_bin;
     const unsigned long long before = s_before;
     if (bin < 0) miss = true;
+    if (PASS == 1 && KIND == N1_SAMPLE) {
+        // bracket: the buckets holding the sample ranks krem -/+ D, D = 8 standard deviations of the rank of the
+        // true median inside an independent sample of M_s (binomial) -- reads differ, so the sample is clustered
+        // and the bracket is only a good bet; whether it held is verified exactly after pass 1
+        const unsigned long long tot = s_total;
+        const unsigned long long Ms = st.n_valid; // sample size
+        const unsigned long long D = (unsigned long long)(6.0 * sqrt((double)Ms)) + 16ull;
+        const bool cut = miss || krel < D || krel + D >= tot; // the bracket would be cut off by the window: no bracket
+        const unsigned long long rlo = krel > D ? krel - D : 0ull;
+        unsigned long long rhi = krel + D;
+        if (tot && rhi > tot - 1) rhi = tot - 1;
+        __syncthreads();
+        n1_find(gh, nb, rlo, part, &s_bin, &s_before, &s_total, loc);
+        const int blo = s_bin;
+        __syncthreads();
+        n1_find(gh, nb, rhi, part, &s_bin, &s_before, &s_total, loc);
+        const int bhi = s_bin;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (tot && !cut && blo >= 0 && bhi >= blo) { mbs[mb].cklo = st.kbase + ((uint32_t)blo << 10); mbs[mb].ckw = (uint32_t)(bhi + 1 - blo) << 10; }
+            else { mbs[mb].cklo = 0; mbs[mb].ckw = 0; }
+        }
+    }
 
     if (PASS == 1 && KIND == N1_FULL && st.n_valid == 0) {
         if (threadIdx.x == 0) {
@@ -202,23 +290,55 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
     } else if (PASS == 0) {
         if (threadIdx.x == 0) {
             if (KIND == N1_FALLBACK) mbs[mb].n_valid = s_total;
-            mbs[mb].kbase = (bin < 0) ? 0u : ((uint32_t)bin << 21);
-            mbs[mb].krem = (bin < 0) ? 0ull : k - before;
+            if (KIND == N1_SAMPLE) {
+                // centre the sample's second pass on the median interpolated inside its top-11-bit bucket, so that the
+                // bracket around it is not cut off by a bucket edge
+                mbs[mb].done = 0; mbs[mb].ckw = 0;
+                unsigned long long c = 0;
+                if (bin >= 0) {
+                    unsigned long long cnt = gh[bin];
+                    double frac = cnt ? (double)(k - before) / (double)cnt : 0.5;
+                    c = ((unsigned long long)bin << 21) + (unsigned long long)(frac * 2097152.0);
+                }
+                unsigned long long lo = c > (N1_WIN >> 1) ? c - (N1_WIN >> 1) : 0ull;
+                lo &= ~1023ull;
+                if (lo > 0xFFFFFFFFull - N1_WIN) lo = (0xFFFFFFFFull - N1_WIN) & ~1023ull;
+                mbs[mb].kbase = (uint32_t)lo;
+                mbs[mb].krem = 0;
+            } else {
+                mbs[mb].kbase = (bin < 0) ? 0u : ((uint32_t)bin << 21);
+                mbs[mb].krem = (bin < 0) ? 0ull : k - before;
+            }
         }
     } else if (PASS == 1) {
         if (threadIdx.x == 0) {
             if (KIND == N1_SAMPLE) {
-                // centre of the sample median's 1024-key bucket -> window start
-                unsigned long long c = (unsigned long long)st.kbase + (bin < 0 ? (N1_WIN >> 1) : (((unsigned long long)bin << 10) + 512ull));
+                // the sample median's 1024-key bucket -> centre of the full pass's window (same 1024-key grid)
+                unsigned long long c = (unsigned long long)st.kbase + (bin < 0 ? (N1_WIN >> 1) : ((unsigned long long)bin << 10));
                 unsigned long long lo = c > (N1_WIN >> 1) ? c - (N1_WIN >> 1) : 0ull;
-                if (lo > 0xFFFFFFFFull - N1_WIN) lo = 0xFFFFFFFFull - N1_WIN;
+                lo &= ~1023ull;
+                if (lo > 0xFFFFFFFFull - N1_WIN) lo = (0xFFFFFFFFull - N1_WIN) & ~1023ull;
                 mbs[mb].kbase = (uint32_t)lo;
                 mbs[mb].bad = 0;
             } else if (KIND == N1_FULL) {
+                // was the rank inside the copied bracket?  (below-bracket count, bracket count, overflow flag)
+                const unsigned long long nb2 = gcnt[N1_NCNT * mb + 2], nc = gcnt[N1_NCNT * mb + 3], ovf = gcnt[N1_NCNT * mb + 4];
+                if (st.ckw && !ovf && nc <= N1_CB_CAP && k >= nb2 && k < nb2 + nc) {
+                    mbs[mb].done = 2;              // k_n1_finish selects inside the bracket
+                    mbs[mb].c_below = k - nb2;     // rank inside the bracket
+                    mbs[mb].n_valid = st.n_valid;
+                    mbs[mb].bad = 0;
+                } else {
+                if (st.ckw) { // tallies of why the bracket did not settle the statistic (debug)
+                    if (ovf) atomicAdd(&g_dbg[5], 1ull);
+                    else if (k < nb2) atomicAdd(&g_dbg[6], 1ull);
+                    else atomicAdd(&g_dbg[7], 1ull);
+                }
                 mbs[mb].n_valid = st.n_valid;
                 mbs[mb].c_below = st.c_below;
                 if (miss) mbs[mb].bad = 1;
                 else { mbs[mb].bad = 0; mbs[mb].kbase = st.kbase + ((uint32_t)bin << 10); mbs[mb].krem = krel - before; }
+                }
             } else {
                 mbs[mb].bad = 0; // the aligned bucket always holds the rank
                 mbs[mb].kbase = st.kbase + ((uint32_t)(bin < 0 ? 0 : bin) << 10);
@@ -241,7 +361,7 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
                 unsigned long long rank_in_bin = k - before;
                 float v0 = v;
                 if (rank_in_bin == 0) {
-                    uint32_t k0 = gbelow[mb];
+                    uint32_t k0 = gbelow[2 * mb];
                     if (s_lowbin >= 0) { uint32_t ka = st.kbase + (uint32_t)s_lowbin; if (ka > k0) k0 = ka; }
                     v0 = key2f(k0);
                 }
@@ -262,7 +382,94 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
     __syncthreads();
     for (int i = threadIdx.x; i < N1_BINS; i += 256) gh[i] = 0;
     if (threadIdx.x == 0) {
-        gbelow[mb] = 0;
-        if (PASS == 1) { gcnt[2 * mb] = 0; gcnt[2 * mb + 1] = 0; } // also the sample's / fallback's counts
+        gbelow[2 * mb] = 0;
+        if (!(PASS == 1 && KIND == N1_FULL)) gbelow[2 * mb + 1] = 0; // the finish kernel still needs the bracket's "below" key
+        if (PASS == 1 && KIND != N1_FULL) for (int i = 0; i < N1_NCNT; i++) gcnt[N1_NCNT * mb + i] = 0; // sample's / fallback's counts
+        if (PASS == 1 && KIND == N1_FULL) { gcnt[N1_NCNT * mb] = 0; gcnt[N1_NCNT * mb + 1] = 0; } // [2..4] are consumed by k_n1_finish
+    }
+}
+
+// One block per minibatch: when pass 1 proved that the wanted rank lies inside the copied bracket, select it
+// there (MSB-first 8-bit radix over key - min, LDS histogram) and finish the statistic: pass 2 is skipped.
+__global__ void __launch_bounds__(1024) k_n1_finish(MbState *__restrict__ mbs, const uint32_t *__restrict__ cbuf,
+                                                    unsigned long long *__restrict__ gcnt, uint32_t *__restrict__ gbelow, int mode,
+                                                    double thresh)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_min, s_max, s_below, s_prefix, s_k;
+    __shared__ int s_low, s_lastw;
+    const int mb = blockIdx.x;
+    const MbState st = mbs[mb];
+    const int tid = threadIdx.x;
+    if (st.status != ADP_MB_OK || st.done != 2) {
+        if (tid == 0) { gcnt[N1_NCNT * mb + 2] = 0; gcnt[N1_NCNT * mb + 3] = 0; gcnt[N1_NCNT * mb + 4] = 0; gbelow[2 * mb + 1] = 0; }
+        return;
+    }
+    const uint32_t n = (uint32_t)gcnt[N1_NCNT * mb + 3];
+    const uint32_t *keys = cbuf + (size_t)mb * N1_CB_CAP;
+    if (tid == 0) { s_min = 0xffffffffu; s_max = 0; s_below = 0; s_prefix = 0; s_k = (uint32_t)st.c_below; s_low = -1; }
+    __syncthreads();
+    uint32_t mn = 0xffffffffu, mx = 0;
+    for (uint32_t i = tid; i < n; i += 1024) { uint32_t key = keys[i]; mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if (lane_id() == 0) { atomicMin(&s_min, mn); atomicMax(&s_max, mx); }
+    __syncthreads();
+    mn = s_min; mx = s_max;
+    const uint32_t span = mx - mn;
+    int rb = span ? 32 - __clz(span) : 0; // bits still unresolved of d = key - mn
+    while (rb > 0) {
+        const int w = rb < 8 ? rb : 8;
+        const int shift = rb - w;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        uint32_t below = 0;
+        for (uint32_t i = tid; i < n; i += 1024) {
+            uint32_t d = keys[i] - mn;
+            uint32_t top = (rb >= 32) ? 0u : (d >> rb);
+            if (top == prefix) atomicAdd(&hist[(d >> shift) & ((1u << w) - 1u)], 1u);
+            else if (shift == 0 && top < prefix && d + 1u > below) below = d + 1u; // (+1: 0 means "none")
+        }
+        if (shift == 0) { below = wave_max(below); if (lane_id() == 0 && below) atomicMax(&s_below, below); }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t k = s_k, cum = 0; int bin = (1 << w) - 1, low = -1;
+            for (int b = 0; b < (1 << w); b++) {
+                uint32_t h = hist[b];
+                if (k < cum + h) { bin = b; break; }
+                if (h) low = b;
+                cum += h;
+            }
+            s_k = k - cum;
+            s_prefix = (prefix << w) | (uint32_t)bin;
+            if (shift == 0) { s_low = low; s_lastw = w; }
+        }
+        __syncthreads();
+        rb = shift;
+    }
+    if (tid == 0) {
+        const uint32_t dsel = s_prefix;
+        const float v = key2f(mn + dsel);
+        float res = v;
+        if ((st.n_valid & 1ull) == 0) {
+            float v0 = v;
+            if (s_k == 0) { // the lower median is the largest key below the selected one
+                uint32_t k0 = gbelow[2 * mb + 1]; // below the bracket (pass 1)
+                if (s_below) { uint32_t ka = mn + (s_below - 1u); if (ka > k0) k0 = ka; }
+                if (span && s_low >= 0) { uint32_t ka = mn + ((dsel & ~((1u << s_lastw) - 1u)) | (uint32_t)s_low); if (ka > k0) k0 = ka; }
+                v0 = key2f(k0);
+            }
+            res = (v0 + v) / 2.0f;
+        }
+        if (mode == 0) mbs[mb].med = res;
+        else {
+            mbs[mb].mad = res;
+            double dmed = (double)st.med, dmad = (double)res;
+            mbs[mb].lo = (float)(dmed - dmad * thresh);
+            mbs[mb].hi = (float)(dmed + dmad * thresh);
+            if (res == 0.0f) mbs[mb].status = ADP_MB_MAD_ZERO;
+        }
+        mbs[mb].done = 1; mbs[mb].kbase = 0; mbs[mb].krem = 0; mbs[mb].bad = 0; mbs[mb].ckw = 0;
+        gcnt[N1_NCNT * mb + 2] = 0; gcnt[N1_NCNT * mb + 3] = 0; gcnt[N1_NCNT * mb + 4] = 0; gbelow[2 * mb + 1] = 0;
     }
 }

@@ -380,6 +380,11 @@ class Engine:
         self._check(self.lib.adp_debug_fetch(self._h, what, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
         return a
 
+    def debug_counters(self):
+        a = np.zeros(8, dtype=np.uint64)
+        self._check(self.lib.adp_debug_fetch(self._h, 8, a.ctypes.data_as(C.c_void_p), C.c_uint64(64)))
+        return a
+
     def debug_norm_params(self, n_mb: int):
         a = np.zeros((n_mb, 4), dtype=np.float64)
         self._check(self.lib.adp_debug_fetch(self._h, 0, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
