@@ -22,7 +22,7 @@ struct MbState {
     int32_t bad;                  // the sampled window missed the rank: aligned 3-pass path takes over
     uint32_t cklo, ckw;           // narrow bracket [cklo, cklo + ckw) whose keys pass 1 copies out (ckw = 0: none)
     int32_t done;                 // the statistic was finished from the copied bracket: pass 2 is skipped
-    int32_t pad2;
+    int32_t fused;                // both statistics were settled by the single fused pass (n1_fused.h)
     float med, mad, lo, hi;       // N1 parameters (float32, as numpy holds them)
     int32_t status;               // ADP_MB_*
     int32_t pad;

@@ -1,0 +1,350 @@
+// n1_fused.h -- N1 in ONE pass over the minibatch: median and MAD of batch[:, :T] together.
+//
+// n1_select.h needs one full HBM pass per statistic because the MAD's keys |x - med| depend on the median.
+// Here both are settled from a single pass, exactly, for minibatches big enough to sample:
+//
+//   sample   (the same two cheap histogram passes over the row/column sample as n1_select.h, run for both
+//            statistics up front) gives   med_s        a median estimate,
+//                                         [A0, A1)     a bracket of u = x - med_s that should hold the true median,
+//                                         [D0, D1]     a bracket of t = |x - med_s| that should hold the true MAD,
+//                                                      widened by the width of the median bracket;
+//   pass     over all samples: count the valid ones, those with u < A0 ("below") and those with t < D0
+//            ("inner"); copy out every x with u in [A0, A1) or t in [D0, D1]  (about 1.5 % of the samples);
+//   finish   one block per minibatch: the median is the (n/2 - below)-th copied value of the first bracket if
+//            that rank falls inside it (exact: u is monotone in x).  With the exact median known, every sample
+//            whose v = |x - med| lies strictly between
+//                  vlo = D0 + |med - med_s|  (rounded up)   and   vhi = D1 - |med - med_s|  (rounded down)
+//            was copied (inner samples have v <= vlo, outer ones v >= vhi, because float32 subtraction is
+//            monotone), so the MAD is the (n/2 - inner - #{copied: v <= vlo})-th of the copied v inside that
+//            zone, if the rank falls there.
+// Anything that does not verify (rank outside a bracket, staging overflow, degenerate sample) leaves the
+// minibatch to n1_select.h's passes, which run afterwards for exactly those minibatches.
+#pragma once
+#include "n1_select.h"
+
+#define N1F_LDS_M 2048            // per-block staging (floats) of the median bracket, flushed after every row
+#define N1F_LDS_B 6144            // ... of the MAD band
+#define N1F_MCAP (N1_CB_CAP / 4)  // copied samples kept per minibatch: median bracket ...
+#define N1F_BCAP (N1_CB_CAP - N1F_MCAP) // ... and MAD band (the two lists share the minibatch's slice of cbuf)
+#define N1F_BINS 32768            // finish: LDS counting histogram (128 KB)
+
+struct N1Fused {
+    float med_s, A0, A1, D0, D1, eps;
+    int32_t ok, pad;
+};
+// counters per minibatch (u64): 0 valid, 1 below (u < A0), 2 inner (t < D0), 3 copied (median bracket), 4 staging overflow,
+// 5 copied (MAD band)
+#define N1F_NCNT 8
+
+// after the sample passes of a statistic: turn the key bracket into the float brackets of the fused pass
+__global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__ fz, int n_mb, int mode)
+{
+    const int mb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mb >= n_mb) return;
+    MbState st = mbs[mb];
+    N1Fused f = fz[mb];
+    if (mode == 0) {
+        f.ok = 0; f.med_s = 0.f; f.A0 = 0.f; f.A1 = 0.f; f.D0 = 0.f; f.D1 = 0.f; f.eps = 0.f;
+        if (st.status == ADP_MB_OK && st.ckw && st.cklo + st.ckw > st.cklo) {
+            const float a_lo = key2f(st.cklo), a_hi = key2f(st.cklo + st.ckw);
+            const float ms = key2f(st.cklo + (st.ckw >> 1));
+            f.med_s = ms; f.A0 = a_lo - ms; f.A1 = a_hi - ms;
+            f.eps = fmaxf(-f.A0, f.A1);
+            f.ok = (f.A0 <= 0.f && f.A1 > 0.f && f.eps < __builtin_inff()) ? 1 : 0;
+        }
+        mbs[mb].med = f.med_s; // the MAD's sample passes measure |x - med_s|
+    } else {
+        if (f.ok) {
+            if (st.ckw && st.cklo + st.ckw > st.cklo) {
+                const float d_lo = key2f(st.cklo), d_hi = key2f(st.cklo + st.ckw);
+                const float e = f.eps * 1.01f + 1e-6f * fabsf(f.med_s) + 1e-30f;
+                f.D0 = d_lo - e; f.D1 = d_hi + e;
+                f.ok = (f.D0 > f.eps && f.D1 > f.D0 && f.D1 < __builtin_inff()) ? 1 : 0; // the median bracket lies inside the inner zone
+            } else f.ok = 0;
+        }
+        // leave the state as n1_select.h's own sample passes expect to find it
+        mbs[mb].med = 0.f; mbs[mb].ckw = 0; mbs[mb].cklo = 0; mbs[mb].kbase = 0; mbs[mb].krem = 0; mbs[mb].bad = 0; mbs[mb].done = 0;
+    }
+    fz[mb] = f;
+}
+
+struct N1FAcc { uint32_t nvalid, nbelow, ninner; };
+
+static __device__ __forceinline__ void n1f_account(float x, float med_s, float A0, float A1, float D0, float D1, N1FAcc &a,
+                                                   LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+{
+    const float u = x - med_s;
+    const float t = fabsf(u);
+    a.nvalid += (t == t) ? 1u : 0u;
+    a.nbelow += (u < A0) ? 1u : 0u;
+    const bool inner = t < D0;
+    a.ninner += inner ? 1u : 0u;
+    if (inner) {
+        if (u >= A0 && u < A1) {
+            uint32_t slot = __hip_atomic_fetch_add(cnt2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < N1F_LDS_M) cbm[slot] = x;
+        }
+    } else if (t <= D1) {
+        uint32_t slot = __hip_atomic_fetch_add(cnt2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (slot < N1F_LDS_B) cbb[slot] = x;
+    }
+}
+
+// grid = (blocks_per_minibatch, n_minibatch); block = N1_THREADS
+__global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
+                                                          const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
+                                                          unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf)
+{
+    __shared__ float cbm_[N1F_LDS_M];
+    __shared__ float cbb_[N1F_LDS_B];
+    __shared__ uint32_t cnt2_[2], base2[2];
+    LDS float *cbm = (LDS float *)cbm_;
+    LDS float *cbb = (LDS float *)cbb_;
+    LDS uint32_t *cnt2 = (LDS uint32_t *)cnt2_;
+    const int mb = blockIdx.y;
+    if (mbs[mb].status != ADP_MB_OK) return;
+    const N1Fused f = fz[mb];
+    if (!f.ok) return;
+    if (threadIdx.x < 2) cnt2_[threadIdx.x] = 0;
+    __syncthreads();
+    const int r0 = mb * mbsize;
+    const int r1 = min(n_reads, r0 + mbsize);
+    const float med_s = f.med_s, A0 = f.A0, A1 = f.A1, D0 = f.D0, D1 = f.D1;
+    N1FAcc a; a.nvalid = 0; a.nbelow = 0; a.ninner = 0;
+    const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
+    float *dstm = cbuf + (size_t)mb * N1_CB_CAP;
+    float *dstb = dstm + N1F_MCAP;
+#define ACC(xx) n1f_account(xx, med_s, A0, A1, D0, D1, a, cbm, cbb, cnt2)
+    for (int r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
+        const float *row = sig + (size_t)r * m;
+        if (vec) {
+            const int T4 = T >> 2;
+            const float4 *row4 = reinterpret_cast<const float4 *>(row);
+            int i = threadIdx.x;
+            for (; i + N1_THREADS < T4; i += 2 * N1_THREADS) { // two loads in flight per lane
+                float4 v = row4[i], w = row4[i + N1_THREADS];
+                ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w);
+                ACC(w.x); ACC(w.y); ACC(w.z); ACC(w.w);
+            }
+            for (; i < T4; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
+            for (int j = (T4 << 2) + threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+        } else {
+            for (int j = threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+        }
+        // hand the row's copied samples to the minibatch's lists: one global atomic per list, row and block
+        __syncthreads();
+        const uint32_t cm = cnt2_[0], cbn = cnt2_[1];
+        if (threadIdx.x == 0) {
+            if (cm > N1F_LDS_M || cbn > N1F_LDS_B) { atomicAdd(&fcnt[N1F_NCNT * mb + 4], 1ull); base2[0] = 0xffffffffu; }
+            else {
+                base2[0] = cm ? (uint32_t)atomicAdd(&fcnt[N1F_NCNT * mb + 3], (unsigned long long)cm) : 0u;
+                base2[1] = cbn ? (uint32_t)atomicAdd(&fcnt[N1F_NCNT * mb + 5], (unsigned long long)cbn) : 0u;
+            }
+        }
+        __syncthreads();
+        if (base2[0] != 0xffffffffu) {
+            const uint32_t bm = base2[0], bb = base2[1];
+            for (uint32_t i = threadIdx.x; i < cm; i += N1_THREADS) if (bm + i < N1F_MCAP) dstm[bm + i] = cbm[i];
+            for (uint32_t i = threadIdx.x; i < cbn; i += N1_THREADS) if (bb + i < N1F_BCAP) dstb[bb + i] = cbb[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) cnt2_[threadIdx.x] = 0;
+        __syncthreads();
+    }
+#undef ACC
+    unsigned long long nv = (unsigned long long)wave_sum((int)a.nvalid), nb = (unsigned long long)wave_sum((int)a.nbelow),
+                       ni = (unsigned long long)wave_sum((int)a.ninner);
+    if (lane_id() == 0) {
+        if (nv) atomicAdd(&fcnt[N1F_NCNT * mb], nv);
+        if (nb) atomicAdd(&fcnt[N1F_NCNT * mb + 1], nb);
+        if (ni) atomicAdd(&fcnt[N1F_NCNT * mb + 2], ni);
+    }
+}
+
+// ---- finish: counting selection in LDS -------------------------------------------------------------------------
+struct N1Sel {
+    uint32_t wtot[16];
+    uint32_t s_before, s_total, s_below, s_clo, s_chi;
+    int s_bin, s_low;
+};
+
+// block-wide (1024 threads): total of hist[0..nb) and the bin holding rank k (-1: k >= total)
+static __device__ void n1f_find(LDS uint32_t *hist, int nb, uint32_t k, LDS N1Sel *S)
+{
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024, b0 = tid * per;
+    uint32_t s = 0;
+    for (int j = 0; j < per; j++) if (b0 + j < nb) s += hist[b0 + j];
+    const uint32_t incl = (uint32_t)wave_scan_incl((int)s);
+    if (lane_id() == 63) S->wtot[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < 16; w++) { uint32_t t = S->wtot[w]; S->wtot[w] = run; run += t; }
+        S->s_total = run; S->s_bin = -1; S->s_before = 0; S->s_low = -1;
+    }
+    __syncthreads();
+    const uint32_t excl = S->wtot[tid >> 6] + incl - s;
+    if (s && k >= excl && k < excl + s) {
+        uint32_t cum = excl;
+        for (int j = 0; j < per; j++) {
+            uint32_t c = hist[b0 + j];
+            if (k < cum + c) { S->s_bin = b0 + j; S->s_before = cum; break; }
+            cum += c;
+        }
+    }
+    __syncthreads();
+}
+
+// Block-wide exact selection among xs[0..n) by the keys keyf(x), restricted to the zone [klo, khi] (inclusive):
+// *c_lo / *c_hi = items with a key below / above the zone, *n_zone = items inside; if 0 <= kz(c_lo) < n_zone (kz =
+// the wanted rank inside the zone, given c_lo) the key of that rank and of the rank before it (needs kz >= 1) are
+// returned.  Counting sort on a key histogram in LDS, 15 bits of the zone's span per level.
+template <class KF, class RK>
+static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float *__restrict__ xs, uint32_t n, KF keyf, uint32_t klo,
+                                  uint32_t khi, RK rank_in_zone, bool need_prev, uint32_t *out_k, uint32_t *out_km1,
+                                  uint32_t *c_lo_out, uint32_t *c_hi_out)
+{
+    const int tid = threadIdx.x;
+    const unsigned long long span = (unsigned long long)khi - klo + 1ull;
+    int bits = 0; while ((1ull << bits) < span) bits++;
+    int sh = bits > 15 ? bits - 15 : 0;
+    uint32_t base = klo;
+    unsigned long long width = span; // keys still in play: [base, base + width)
+    long long kz = 0;
+    bool first = true;
+    const float4 *xs4 = reinterpret_cast<const float4 *>(xs);
+    for (;;) {
+        const int nb = (int)((width + ((1ull << sh) - 1ull)) >> sh);
+        for (int i = tid; i < nb; i += 1024) hist[i] = 0;
+        if (tid == 0) { S->s_below = 0; if (first) { S->s_clo = 0; S->s_chi = 0; } }
+        __syncthreads();
+        uint32_t clo = 0, chi = 0, below = 0;
+        auto visit = [&](float x) {
+            const uint32_t key = keyf(x);
+            if (key < base) {
+                if (key < klo) clo++;
+                else if (key + 1u > below) below = key + 1u; // inside the zone, below the range in play (+1: 0 = none)
+            } else {
+                const unsigned long long d = (unsigned long long)key - base;
+                if (d < width) __hip_atomic_fetch_add(&hist[(uint32_t)(d >> sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (key > khi) chi++;
+            }
+        };
+        const uint32_t n4 = n >> 2;
+        uint32_t i = tid;
+        for (; i + 1024 < n4; i += 2048) {
+            float4 v = xs4[i], w = xs4[i + 1024];
+            visit(v.x); visit(v.y); visit(v.z); visit(v.w); visit(w.x); visit(w.y); visit(w.z); visit(w.w);
+        }
+        for (; i < n4; i += 1024) { float4 v = xs4[i]; visit(v.x); visit(v.y); visit(v.z); visit(v.w); }
+        for (uint32_t j = (n4 << 2) + tid; j < n; j += 1024) visit(xs[j]);
+        below = wave_max(below);
+        if (lane_id() == 0 && below) atomicMax((uint32_t *)&S->s_below, below);
+        if (first) {
+            clo = (uint32_t)wave_sum((int)clo); chi = (uint32_t)wave_sum((int)chi);
+            if (lane_id() == 0) { if (clo) atomicAdd((uint32_t *)&S->s_clo, clo); if (chi) atomicAdd((uint32_t *)&S->s_chi, chi); }
+        }
+        __syncthreads();
+        if (first) {
+            *c_lo_out = S->s_clo; *c_hi_out = S->s_chi;
+            kz = rank_in_zone(S->s_clo);
+            if (kz < (need_prev ? 1 : 0)) return false;
+        }
+        n1f_find(hist, nb, (uint32_t)kz, S);
+        if (S->s_bin < 0) return false; // (first level: kz >= n_zone)
+        const int bin = S->s_bin;
+        const uint32_t before = S->s_before;
+        if (sh == 0) {
+            // largest non-empty bin below `bin`
+            { const int per = (nb + 1023) / 1024, b0 = tid * per; int low = -1;
+              for (int j = 0; j < per; j++) { int b = b0 + j; if (b < bin && b < nb && hist[b]) low = b; }
+              if (low >= 0) atomicMax((int *)&S->s_low, low); }
+            __syncthreads();
+            const uint32_t k1 = base + (uint32_t)bin;
+            uint32_t k0 = k1;
+            if ((uint32_t)kz == before) { // first of its key: the rank before it is the largest key below
+                if (S->s_low >= 0) k0 = base + (uint32_t)S->s_low;
+                else if (S->s_below) k0 = S->s_below - 1u;
+                else if (need_prev) return false; // (cannot happen with kz >= 1)
+            }
+            *out_k = k1; *out_km1 = k0;
+            __syncthreads();
+            return true;
+        }
+        base += (uint32_t)bin << sh;
+        width = 1ull << sh;
+        kz -= before;
+        sh = sh > 15 ? sh - 15 : 0;
+        first = false;
+        __syncthreads();
+    }
+}
+
+// one block (1024 threads) per minibatch
+__global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
+                                                           unsigned long long *__restrict__ fcnt, const float *__restrict__ cbuf,
+                                                           double thresh)
+{
+    __shared__ uint32_t hist_[N1F_BINS];
+    __shared__ N1Sel S_;
+    LDS uint32_t *hist = (LDS uint32_t *)hist_;
+    LDS N1Sel *S = (LDS N1Sel *)&S_;
+    const int mb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const MbState st = mbs[mb];
+    const N1Fused f = fz[mb];
+    const unsigned long long n_valid = fcnt[N1F_NCNT * mb], n_below = fcnt[N1F_NCNT * mb + 1], n_inner = fcnt[N1F_NCNT * mb + 2],
+                             n_cm = fcnt[N1F_NCNT * mb + 3], ovf = fcnt[N1F_NCNT * mb + 4], n_cb = fcnt[N1F_NCNT * mb + 5];
+    __syncthreads();
+    if (tid < N1F_NCNT) fcnt[N1F_NCNT * mb + tid] = 0; // ready for the next call
+    if (st.status != ADP_MB_OK || !f.ok) return;
+    if (tid == 0) atomicAdd(&g_dbg[5], 1ull);
+    if (ovf || n_cm > N1F_MCAP || n_cb > N1F_BCAP || n_valid < 4) { if (tid == 0) atomicAdd(&g_dbg[6], 1ull); return; }
+    const float *xm = cbuf + (size_t)mb * N1_CB_CAP;
+    const float *xb = xm + N1F_MCAP;
+    const float med_s = f.med_s, D0 = f.D0, D1 = f.D1;
+    const bool even = (n_valid & 1ull) == 0;
+    const unsigned long long k = n_valid / 2;
+
+    // ---- median: rank k - below among the copied samples of the first bracket (a little slack on the key range:
+    // the bracket is defined on u = x - med_s; anything outside the range makes the attempt fail, never wrong)
+    uint32_t kk = 0, kkm1 = 0, c_lo = 0, c_hi = 0;
+    {
+        const uint32_t ka = f2key(med_s + f.A0), kb = f2key(med_s + f.A1);
+        const uint32_t klo = ka > 64u ? ka - 64u : 0u, khi = kb < 0xffffffffu - 64u ? kb + 64u : 0xffffffffu;
+        const bool okm = n1f_select(hist, S, xm, (uint32_t)n_cm, [](float x) { return f2key(x); }, klo, khi,
+                                    [&](uint32_t) { return (k >= n_below && k - n_below < n_cm) ? (long long)(k - n_below) : -1ll; },
+                                    even, &kk, &kkm1, &c_lo, &c_hi);
+        if (!okm || c_lo || c_hi) { if (tid == 0) atomicAdd(&g_dbg[6], 1ull); return; }
+    }
+    float med = key2f(kk);
+    if (even) med = (key2f(kkm1) + med) / 2.0f;
+
+    // ---- MAD: zone (vlo, vhi) of v = |x - med| whose members were all copied
+    const double delta = fabs((double)med - (double)med_s);
+    const double tlo = ((double)D0 + delta) * (1.0 + 1e-12), thi = ((double)D1 - delta) * (1.0 - 1e-12);
+    float vlo = (float)tlo; if ((double)vlo < tlo) vlo = __uint_as_float(__float_as_uint(vlo) + 1u); // round up   (vlo > 0)
+    float vhi = (float)thi; if ((double)vhi > thi) vhi = __uint_as_float(__float_as_uint(vhi) - 1u); // round down (vhi > 0)
+    if (!(thi > 0.0) || !(vhi > vlo) || f2key(vhi) - f2key(vlo) < 2u) { if (tid == 0) atomicAdd(&g_dbg[7], 1ull); return; }
+    {
+        // samples with v <= vlo: every inner one plus the copied ones below the zone
+        const bool okd = n1f_select(hist, S, xb, (uint32_t)n_cb, [&](float x) { return f2key(fabsf(x - med)); }, f2key(vlo) + 1u,
+                                    f2key(vhi) - 1u,
+                                    [&](uint32_t clo) { unsigned long long cle = n_inner + clo; return k >= cle ? (long long)(k - cle) : -1ll; },
+                                    even, &kk, &kkm1, &c_lo, &c_hi);
+        if (!okd) { if (tid == 0) atomicAdd(&g_dbg[7], 1ull); return; }
+    }
+    float mad = key2f(kk);
+    if (even) mad = (key2f(kkm1) + mad) / 2.0f;
+    if (tid == 0) {
+        mbs[mb].n_valid = n_valid;
+        mbs[mb].med = med;
+        mbs[mb].mad = mad;
+        const double dmed = (double)med, dmad = (double)mad;
+        mbs[mb].lo = (float)(dmed - dmad * thresh);
+        mbs[mb].hi = (float)(dmed + dmad * thresh);
+        if (mad == 0.0f) mbs[mb].status = ADP_MB_MAD_ZERO;
+        mbs[mb].fused = 1;
+    }
+}

@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
     LDS uint32_t *cb_cnt = (LDS uint32_t *)&cb_cnt_;
     const int mb = blockIdx.y;
     const MbState st = mbs[mb];
-    if (st.status != ADP_MB_OK) return;
+    if (st.status != ADP_MB_OK || st.fused) return;
     if (when == N1_IF_BAD && !st.bad) return;
     if (when == N1_IF_NOT_DONE && st.done) return;
     const uint32_t cklo = st.cklo, ckw = (PASS == 1 && collect) ? st.ckw : 0u;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
     __shared__ unsigned long long s_before, s_total;
     const int mb = blockIdx.x;
     MbState st = mbs[mb];
-    if (st.status != ADP_MB_OK) return;
+    if (st.status != ADP_MB_OK || st.fused) return;
     if (KIND == N1_FALLBACK && !st.bad) return;
     if (PASS == 2 && st.done) return; // finished from the copied bracket (k_n1_finish)
     uint32_t *gh = ghist + (size_t)mb * N1_BINS;
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(1024) k_n1_finish(MbState *__restrict__ mbs, c
     const int mb = blockIdx.x;
     const MbState st = mbs[mb];
     const int tid = threadIdx.x;
-    if (st.status != ADP_MB_OK || st.done != 2) {
+    if (st.status != ADP_MB_OK || st.done != 2 || st.fused) {
         if (tid == 0) { gcnt[N1_NCNT * mb + 2] = 0; gcnt[N1_NCNT * mb + 3] = 0; gcnt[N1_NCNT * mb + 4] = 0; gbelow[2 * mb + 1] = 0; }
         return;
     }

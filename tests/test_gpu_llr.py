@@ -159,3 +159,43 @@ def test_n1_guess_miss_falls_back_exactly(hip, oracle_mod, kind):
     rc, want = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
     assert list(got) == list(want), (kind, got, want)
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["plain", "odd_count", "bimodal_rows", "nan_sample", "constant", "negatives", "two_values"])
+def test_n1_fused_single_pass_is_exact_or_falls_back(hip, oracle_mod, kind, monkeypatch):
+    """Big minibatches get median and MAD from one pass (n1_fused.h); forced here on a small batch.  Whatever the
+    sampled brackets cannot prove must fall through to the multi-pass selection: the result is always numpy's."""
+    from adapted_amd import synth
+    from util import make_spc
+
+    monkeypatch.setenv("ADP_N1_FUSED_MIN", "1")
+    spc = make_spc(CASES["rna004_llr_default"])
+    m = spc.sig_preload_size
+    n = 96
+    lens = np.full(n, m, dtype=np.int32)
+    sig, _ = synth.synth_batch(5, 0, n, m, lens)
+    if kind == "odd_count":
+        sig[3, 17] = np.nan
+    elif kind == "bimodal_rows":
+        sig[0::2] += np.float32(200.0)
+    elif kind == "nan_sample":
+        sig[0::3] = np.nan
+        lens[0::3] = 0
+    elif kind == "constant":
+        sig[:, :] = np.float32(77.25)
+        sig[1, 5] = np.float32(80.0)
+    elif kind == "negatives":
+        sig[1::2] *= np.float32(-1.0)
+    elif kind == "two_values":
+        sig[:, :] = np.float32(50.0)
+        sig[:, 1::2] = np.float32(90.0)
+    eng = _engine(hip, spc, n, m)
+    before = eng.debug_counters().copy()
+    eng.debug_llr_upto(sig, lens, n, n, 1)
+    got = eng.debug_norm_params(1)[0]
+    after = eng.debug_counters()
+    rc, want = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    assert list(got) == list(want), (kind, got, want)
+    print(kind, "fused attempts/median misses/MAD misses:", (after - before)[5:8])
+    # (small batches are clustered samples: the brackets may well miss, or not be set up at all)
+    eng.close()

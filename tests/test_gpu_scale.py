@@ -72,14 +72,21 @@ def test_full_size_properties_and_sampled_oracle(oracle_mod):
     dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
     eng.h2d(dlen, np.full(n, m, dtype=np.int32))
     eng.synth_fill(dsig, dlen, n, seed=9, first_read=4000)
+    c0 = eng.debug_counters().copy()
     rows, mbs = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True)
     assert (mbs == 0).all()
+    # N1 of minibatches this big comes from the single fused pass (n1_fused.h): attempted 3x, no bracket missed
+    c1 = eng.debug_counters()
+    assert list((c1 - c0)[5:8]) == [3, 0, 0], (c0, c1)
+    # ... and is numpy's nanmedian / MAD exactly
+    sig = np.zeros((mb, m), dtype=np.float32)
+    eng.d2h(sig, dsig + mb * m * 4)
+    rc, want_np = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    assert list(eng.debug_norm_params(3)[1]) == list(want_np)
     # (b) the middle minibatch alone, as its own call
     rows_b, _ = eng.detect_llr_rows(dsig + mb * m * 4, dlen + mb * 4, mb, mb, device_ptrs=True)
     assert rows[mb:2 * mb].tobytes() == rows_b.tobytes()
     # (a) oracle on the middle minibatch
-    sig = np.zeros((mb, m), dtype=np.float32)
-    eng.d2h(sig, dsig + mb * m * 4)
     want = oracle_mod.detect_llr(sig, np.full(mb, m, dtype=np.int32), spc)
     got = lib.rows_to_results(rows_b, "llr")
     assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
