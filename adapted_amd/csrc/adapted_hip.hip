@@ -74,7 +74,7 @@ static int geom(adp_handle *h)
     }
     if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
     if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
-    if ((c.max_obs_trace - c.min_obs_adapter) / c.downscale_factor > 150000) { g_err = "max_obs_trace too large for the LDS state of k_polya_peak"; return ADP_ERR_UNSUPPORTED; }
+    if ((c.max_obs_trace - c.min_obs_adapter) / c.downscale_factor > 400000) { g_err = "max_obs_trace too large for the LDS state of k_polya_peak"; return ADP_ERR_UNSUPPORTED; }
     h->T = c.max_obs_trace < h->m ? c.max_obs_trace : h->m;
     h->off = c.min_obs_adapter;
     h->ds = c.downscale_factor;
@@ -113,7 +113,7 @@ static int alloc_all(adp_handle *h)
     h->vslots = (int)(R < 2048 ? R : 2048);
     h->vstride = ((h->m + 63) / 64) * 64;
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
-    h->pslots = (int)(R < 2048 ? R : 2048);
+    h->pslots = (int)(R < 8192 ? R : 8192);
     bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
     bad |= h->npk.ensure(R * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
@@ -431,7 +431,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
             int grid = n < h->pslots ? n : h->pslots;
-            hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+            hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)(((h->Lp / 2 + 1) + 8) / 16 + 2) * 4, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
                                h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
         }
@@ -608,7 +608,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr);
     int grid = n < h->pslots ? n : h->pslots;
-    hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)h->Lp, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+    hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)(((h->Lp / 2 + 1) + 8) / 16 + 2) * 4, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,
                        h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
     hipLaunchKernelGGL(k_refine_out, dim3((n + 255) / 256), dim3(256), 0, st, mbs, h->nvalid.as<int32_t>(), h->polya_idx.as<int32_t>(),

@@ -136,8 +136,20 @@ static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, doubl
 // index with a positive-or-NaN gain).  PASS 2: start = adapter candidate, offsets (1, 1).
 // Emits the trace (float64) and per-64-point summaries: PASS 1 of the raw trace (NaN => +inf max),
 // PASS 2 of the np.nan_to_num-sanitised trace that find_peaks sees in P4.
+#ifndef GAINS_UNROLL
+#define GAINS_UNROLL 1
+#endif
+#ifndef GAINS_SU
+#define GAINS_SU 4
+#endif
+#ifndef GAINS_EU
+#define GAINS_EU 4
+#endif
+#ifndef GAINS_WPS
+#define GAINS_WPS 1
+#endif
 template <int PASS>
-__global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
+__global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
                                               const double2 *__restrict__ ck, const double2 *__restrict__ tail,
                                               const int32_t *__restrict__ adapter_idx, int mbsize,
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
@@ -145,7 +157,6 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                                               int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
                                               int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat)
 {
-    __shared__ float sd[64 * (CK + 1)];
     __shared__ double sg[64 * (CK + 1)];
     const int r = blockIdx.x;
     const int ln = lane_id();
@@ -189,20 +200,21 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
     bool plateau = false;
     double carry1 = 0.0, carry2 = 0.0; // sanitised x[tb-1], x[tb-2]
     for (int tb = 0; tb < n; tb += TRACE_TILE) {
-        // stage the pooled samples of this tile: coalesced -> LDS [lane][CK] (stride CK+1)
-        __syncthreads();
-        for (int k = 0; k < CK; k++) {
-            int e = k * 64 + ln;
-            int i = tb + e;
-            sd[(e / CK) * (CK + 1) + (e % CK)] = (i < n) ? s[i] : 0.0f;
-        }
+        // each lane walks CK = 16 consecutive pooled samples: four float4 loads (rows start 256-byte aligned and
+        // are padded to Lp, so the loads stay inside the row; samples at or beyond n are not used)
         __syncthreads();
         const int i0 = tb + ln * CK;
+        const float4 *s4 = reinterpret_cast<const float4 *>(s + (i0 < Lp ? i0 : 0));
         double a = 0.0, b = 0.0;
         if (i0 < n) { double2 p = c[i0 / CK]; a = p.x; b = p.y; }
         double mx = -__builtin_inf(), mn = __builtin_inf();
-#pragma unroll 4
-        for (int t = 0; t < CK; t++) {
+#pragma unroll GAINS_UNROLL
+        for (int tq = 0; tq < CK / 4; tq++) {
+            const float4 q4 = s4[tq];
+            const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = tq * 4 + u;
             const int i = i0 + t;
             double gi = 0.0;
             if (i < n) {
@@ -226,11 +238,12 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                     mx = x > mx ? x : mx;
                     mn = x < mn ? x : mn;
                 }
-                double v = (double)sd[ln * (CK + 1) + t];
+                double v = (double)qv[u];
                 a += v;
                 b += v * v;
             }
             sg[ln * (CK + 1) + t] = gi;
+        }
         }
         // 4 lanes = one 64-point summary block
         {
@@ -246,6 +259,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
             }
         }
         __syncthreads();
+#pragma unroll GAINS_SU
         for (int k = 0; k < CK; k++) {
             int e = k * 64 + ln;
             int i = tb + e;
@@ -258,6 +272,7 @@ __global__ void __launch_bounds__(64) k_gains(const float *__restrict__ down, co
                 else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
                 return x;
             };
+#pragma unroll GAINS_EU
             for (int k = 0; k < CK; k++) {
                 const int e = k * 64 + ln;
                 const int i = tb + e;   // x[i] is "next"; the candidate is j = i - 1

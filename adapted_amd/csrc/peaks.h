@@ -203,13 +203,19 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------- poly(A) end (P4)
-#define ST_NONE 0
-#define ST_UNDECIDED 1
-#define ST_KEPT 2
-#define ST_REMOVED 3
+// 2-bit state per local maximum, by ORDINAL in the read's index-ordered list of maxima; transitions only clear
+// bits (one LDS atomic and): undecided 3 -> kept 2 / removed 1
+#define PST_NONE 0u
+#define PST_REMOVED 1u
+#define PST_KEPT 2u
+#define PST_UNDECIDED 3u
 
-// persistent grid of waves; slot scratch in HBM: pk[Lp/2+1] int32, mk[Lp/2+1] uint32; the per-position
-// state bytes live in dynamic LDS (Lp bytes per wave)
+// persistent grid of waves.  pk[Lp/2+1] int32 per READ (list of maxima, pre-filled by k_gains; ends up holding
+// the kept ones), mk[Lp/2+1] uint32 per SLOT (work list of undecided maxima: ordinal << 8 | neighbour mask);
+// the states live in dynamic LDS: ((Lp/2+1) + 8) / 16 + 2 words per wave.
+//
+// Strict local maxima are at least two samples apart, so at most four of them lie within the minimum distance
+// (|dp| <= 9) on either side of a maximum: the neighbourhood is the ordinals k-4 .. k+4, whatever the positions.
 __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
                                                    const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                    const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
@@ -217,8 +223,8 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                                                    uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx,
                                                    const int32_t *__restrict__ npk_all)
 {
-    extern __shared__ uint8_t state_raw[];
-    LDS uint8_t *state = (LDS uint8_t *)state_raw;
+    extern __shared__ uint32_t stw_raw[];
+    LDS uint32_t *stw = (LDS uint32_t *)stw_raw; // ordinal k is slot k + 4 (slots 0..3 stay PST_NONE)
     const int ln = lane_id();
     const int half = Lp / 2 + 1;
     uint32_t *mk = mk_all + (size_t)blockIdx.x * half;
@@ -237,7 +243,6 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
             if (recount) npk = 0;
             double carry = 0.0; // value at base - 1
             __syncthreads();
-            for (int i = ln; i < n; i += 64) state[i] = ST_NONE;
             for (int base0 = 0; recount && base0 < n; base0 += 256) {
                 double vv[4], ee[4];
 #pragma unroll
@@ -271,74 +276,95 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                     npk += __popcll(m);
                 }
             }
-            __syncthreads();
             if (g_ablate & 256) npk = 0;
-            for (int k = ln; k < npk; k += 64) state[pk[k]] = ST_UNDECIDED;
+            for (int w = ln; w < (npk + 8 + 15) / 16 + 1; w += 64) stw[w] = 0;
             __syncthreads();
-            // 2. per peak: which positions within +-9 hold a higher-priority peak
-            //    (scipy _select_by_peak_distance, distance = 10 -> |dp| < 10; equal heights: later index first)
-            for (int k = ln; k < npk; k += 64) {
-                const int p = pk[k];
-                const double xp = tv_get(tv, p);
-                uint32_t nb = 0;
+            // 2. per maximum: which of the up to 8 maxima within +-9 samples have a higher priority
+            //    (scipy _select_by_peak_distance, distance = 10 -> |dp| < 10; equal heights: later index first).
+            //    56 maxima per step (lanes 4..59), their neighbours by shuffle.  A maximum without any is kept
+            //    at once; the others form the work list of step 3.
+            int nund = 0;
+            for (int base = 0; base < npk; base += 56) {
+                const int k = base - 4 + ln;
+                const bool valid = k >= 0 && k < npk;
+                const int p = valid ? pk[k] : (k < 0 ? -0x40000000 : 0x40000000);
+                const double v = valid ? tv_get(tv, p) : 0.0;
+                uint32_t mask = 0;
 #pragma unroll
-                for (int o = -9; o <= 9; o++) {
-                    int q = p + o;
-                    if (o != 0 && q >= 0 && q < n && state[q] != ST_NONE) nb |= 1u << (o + 9);
+                for (int j = 1; j <= 4; j++) {
+                    const int pf = __shfl_down(p, j); const double vf = __shfl_down(v, j);
+                    const int pb = __shfl_up(p, j);   const double vb = __shfl_up(v, j);
+                    if (pf - p <= 9 && vf >= v) mask |= 1u << (j - 1);
+                    if (p - pb <= 9 && vb > v) mask |= 1u << (4 + j - 1);
                 }
-                double xq[19];
-#pragma unroll
-                for (int o = 0; o < 19; o++) xq[o] = (nb >> o & 1u) ? tv_get(tv, p + o - 9) : 0.0; // independent loads
-                uint32_t bits = 0;
-#pragma unroll
-                for (int o = 0; o < 19; o++)
-                    if ((nb >> o & 1u) && (xq[o] > xp || (xq[o] == xp && o > 9))) bits |= 1u << o;
-                mk[k] = bits;
+                const bool out = valid && ln >= 4 && ln < 60;
+                if (out) {
+                    const uint32_t sl = (uint32_t)(k + 4);
+                    __hip_atomic_fetch_or(&stw[sl >> 4], (mask ? PST_UNDECIDED : PST_KEPT) << ((sl & 15u) * 2u), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const bool und = out && mask;
+                const unsigned long long m = __ballot(und);
+                if (und) mk[nund + __popcll(m & ((1ull << ln) - 1ull))] = ((uint32_t)k << 8) | mask;
+                nund += __popcll(m);
             }
             __syncthreads();
             // 3. fixed point of "kept iff no kept higher-priority neighbour"
-            int nund = (g_ablate & 512) ? 0 : npk;
+            if (g_ablate & 512) nund = 0;
             while (nund > 0) {
                 int w = 0;
                 for (int base = 0; base < nund; base += 64) {
-                    int k = base + ln;
-                    int p = -1; uint32_t bits = 0;
+                    const int idx = base + ln;
+                    uint32_t e = 0;
                     bool pending = false;
-                    if (k < nund) {
-                        p = pk[k]; bits = mk[k];
+                    if (idx < nund) {
+                        e = mk[idx];
+                        const uint32_t k = e >> 8;
+                        // states of the ordinals k-4 .. k+4 = slots k .. k+8
+                        const unsigned long long W =
+                            (((unsigned long long)stw[(k >> 4) + 1] << 32) | stw[k >> 4]) >> ((k & 15u) * 2u);
                         bool kept_nb = false;
-                        uint32_t b = bits;
+                        uint32_t b = e & 255u;
                         while (b) {
-                            int o = __ffs(b) - 1; b &= b - 1;
-                            uint8_t s = state[p + o - 9];
-                            if (s == ST_KEPT) kept_nb = true;
-                            else if (s == ST_UNDECIDED) pending = true;
+                            const int o = __ffs(b) - 1; b &= b - 1;
+                            const int f = o < 4 ? 5 + o : 7 - o; // k+1..k+4 -> fields 5..8 ; k-1..k-4 -> fields 3..0
+                            const uint32_t sn = (uint32_t)(W >> (2 * f)) & 3u;
+                            if (sn == PST_KEPT) kept_nb = true;
+                            else if (sn == PST_UNDECIDED) pending = true;
                         }
-                        if (kept_nb) { state[p] = ST_REMOVED; pending = false; }
-                        else if (!pending) state[p] = ST_KEPT;
+                        const uint32_t sl = k + 4u;
+                        if (kept_nb) {
+                            __hip_atomic_fetch_and(&stw[sl >> 4], ~(2u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            pending = false;
+                        } else if (!pending) {
+                            __hip_atomic_fetch_and(&stw[sl >> 4], ~(1u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
-                    unsigned long long m = __ballot(pending);
-                    if (pending) {
-                        int dst = w + __popcll(m & ((1ull << ln) - 1ull));
-                        pk[dst] = p; mk[dst] = bits;
-                    }
+                    const unsigned long long m = __ballot(pending);
+                    if (pending) mk[w + __popcll(m & ((1ull << ln) - 1ull))] = e;
                     w += __popcll(m);
                     __syncthreads();
                 }
                 nund = w;
             }
             __syncthreads();
-            // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
-            // survivors, compacted in index order (LDS state scan), then 64 candidates per step
+            // kept maxima, in index order, compacted in place
             int nkept = 0;
-            for (int base = 0; base < n; base += 64) {
-                int i = base + ln;
-                bool kp = (i < n) && state[i] == ST_KEPT;
-                unsigned long long m = __ballot(kp);
-                if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = i;
+            for (int base = 0; base < npk; base += 64) {
+                const int k = base + ln;
+                int pp = -1; bool kp = false;
+                if (k < npk) {
+                    pp = pk[k];
+                    const uint32_t sl = (uint32_t)(k + 4);
+                    kp = ((stw[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == PST_KEPT;
+                }
+                const unsigned long long m = __ballot(kp);
+                if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = pp;
                 nkept += __popcll(m);
             }
             __syncthreads();
+            // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
+            // survivors, compacted in index order (LDS state scan), then 64 candidates per step
             int p0 = -1, p1 = -1;
             for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += 64) {
                 int k = base + ln;

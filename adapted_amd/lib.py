@@ -100,7 +100,7 @@ def load():
     if _LIB is not None:
         return _LIB
     try:
-        path = _build.build()
+        path = os.environ.get("ADAPTED_HIP_LIB") or _build.build()  # (override: a developer's experimental build)
         lib = C.CDLL(path)
     except Exception as e:  # no CPU fallback by design
         raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
