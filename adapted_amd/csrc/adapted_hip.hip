@@ -11,7 +11,7 @@
 
 #include "adapted_hip.h"
 __device__ int g_ablate = 0;
-__device__ unsigned long long g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+__device__ unsigned long long g_dbg[24] = {0};
 #include "common.h"
 #include "llr_stream.h"
 #include "n1_select.h"
@@ -702,8 +702,8 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     case 5: src = h->polya_idx.p; break;
     case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
     case 7: src = h->t1.p; break;
-    case 8: { if (bytes < 64) return ADP_ERR_INVALID;
-              HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), 64, 0, hipMemcpyDeviceToHost)); return ADP_OK; }
+    case 8: { if (bytes < 64 || bytes > sizeof(unsigned long long) * 24) return ADP_ERR_INVALID;
+              HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost)); return ADP_OK; }
     default: return ADP_ERR_INVALID;
     }
     HIPCHK(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, h->stream));

@@ -4,9 +4,12 @@
 //   pass A  numpy-ordered float32 sum (-> mean)  +  histogram of the top 20 key bits inside a 4096-bucket
 //           window around a pivot (0.03 pA buckets near 100 pA): the median's bucket is known, and the
 //           histogram also tells, to a few buckets, where the MAD will be;
-//   pass B  numpy-ordered sum of (x-mean)^2 (-> std)  +  copy the median's bucket to LDS (+ largest key
-//           below it)  +  count the samples whose distance to the bucket centre is below a bracket
-//           [P, Q] around the predicted MAD and copy those inside it to LDS.
+//   pass B  numpy-ordered sum of (x-mean)^2 (-> std)  +  copy the median's bucket to LDS  +  count the
+//           samples whose distance to the bucket centre is below a bracket [P, Q] around the predicted MAD
+//           and copy those inside it to LDS.  (Per sample only a subtraction, three compares and a flag bit;
+//           the ~2 % flagged samples are re-read and classified exactly.  The largest sample below the
+//           median's bucket -- the lower median of an even count that falls on the bucket's first sample --
+//           costs a pass of its own in that rare case.)
 //   The median is finished exactly inside its bucket; the MAD is finished inside the bracket and
 //   ACCEPTED ONLY IF the selected |x - med| values lie at least one bucket width inside [P, Q] -- that
 //   proves no sample outside the bracket can sit on the wrong side (|x-med| and |x-centre| differ by
@@ -32,10 +35,10 @@
 
 // (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
 extern __device__ int g_ablate;
-extern __device__ unsigned long long g_dbg[8]; // debug tallies (adp_debug_fetch what=8)
+extern __device__ unsigned long long g_dbg[24]; // debug tallies (adp_debug_fetch what=8): 0-4 here, 5-7 N1, 8-15 phase cycles here
 
 // 16-byte load from a 4-byte aligned address (segments start anywhere): gfx950 global loads need dword alignment only
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct BlockScratch {
@@ -97,12 +100,12 @@ static __device__ __noinline__ float bs_eval_tail(int tail, const LDS float *lea
 
 enum { SIDE_NONE = 0, SIDE_HIST = 1, SIDE_COLLECT = 2 };
 struct SumAux { float sum; uint32_t aux, aux2; };
-struct SideParam { uint32_t key; float c, P, Q; int do_mad; };
+struct SideParam { uint32_t key; float c, P, Q, hw; int do_mad; }; // hw: |v - c| <= hw for every sample of bucket `key`
 
 // per-sample side effect of a summing pass (state in registers only)
 //   SIDE_HIST:    20-bit bucket histogram inside the window starting at p.key; aux counts samples below it
-//   SIDE_COLLECT: copy the samples of bucket p.key to LDS, aux = largest key below the bucket; with p.do_mad
-//                 also classify by dt = |v - p.c|: dt < P -> aux2++, P <= dt <= Q -> copy to the bracket buffer
+//   SIDE_COLLECT: copy the samples of bucket p.key to LDS; with p.do_mad also classify by dt = |v - p.c|:
+//                 dt < P -> aux2++, P <= dt <= Q -> copy to the bracket buffer
 template <int SIDE>
 static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BlockScratch *bs, uint32_t &aux, uint32_t &aux2)
 {
@@ -117,7 +120,7 @@ static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS 
         if (kb == p.key) {
             int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < BS_MEDCAP) bs->collect[slot] = v;
-        } else if (kb < p.key && key > aux) aux = key;
+        }
         if (p.do_mad) {
             float dt = fabsf(v - p.c);
             if (dt < p.P) aux2++;
@@ -146,50 +149,51 @@ static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, fl
             uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS; // dump cell
             __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-    } else if (SIDE == SIDE_COLLECT) {
-        const float vv[4] = {v0, v1, v2, v3};
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t key = f2key(vv[i]);
-            uint32_t kb = key >> BS_KSH;
-            uint32_t cand = (kb < p.key) ? key : 0u;    // largest key below the bucket
-            aux = cand > aux ? cand : aux;
-            bool special = (kb == p.key);
-            if (p.do_mad) {
-                float dt = fabsf(vv[i] - p.c);
-                aux2 += (dt < p.P) ? 1u : 0u;
-                special = special || (dt >= p.P && dt <= p.Q);
-            }
-            any = any || special;
-        }
-        if (any) { // rare per lane
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t kb = f2key(vv[i]) >> BS_KSH;
-                if (kb == p.key) {
-                    int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (slot < BS_MEDCAP) bs->collect[slot] = vv[i];
-                }
-                if (p.do_mad) {
-                    float dt = fabsf(vv[i] - p.c);
-                    if (dt >= p.P && dt <= p.Q) {
-                        int slot = __hip_atomic_fetch_add(&bs->nmad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (slot < BS_MADCAP) ((LDS float *)bs->hist)[slot] = vv[i];
-                    }
-                }
-            }
+    }
+}
+
+// the copies of SIDE_COLLECT alone (dt < P is counted elsewhere)
+static __device__ __forceinline__ void bs_copy_exact(float v, const SideParam &p, LDS BlockScratch *bs)
+{
+    if ((f2key(v) >> BS_KSH) == p.key) {
+        int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (slot < BS_MEDCAP) bs->collect[slot] = v;
+    }
+    if (p.do_mad) {
+        const float dt = fabsf(v - p.c);
+        if (dt >= p.P && dt <= p.Q) {
+            int slot = __hip_atomic_fetch_add(&bs->nmad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (slot < BS_MADCAP) ((LDS float *)bs->hist)[slot] = v;
         }
     }
+}
+
+// SIDE_COLLECT for four samples, free of branches: count dt < P and flag (one bit per sample) the candidates for a
+// copy -- dt <= hw (a superset of the median's bucket) or P <= dt <= Q.  The flagged samples (about 2 %) are
+// re-read and classified exactly by bs_side<SIDE_COLLECT> afterwards.
+static __device__ __forceinline__ uint32_t bs_flag4(float v0, float v1, float v2, float v3, const SideParam &p, uint32_t &aux2)
+{
+    const float vv[4] = {v0, v1, v2, v3};
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float dt = fabsf(vv[i] - p.c);
+        const bool lt = dt < p.P;
+        aux2 += lt ? 1u : 0u;
+        const bool special = (dt <= p.hw) || (!lt && dt <= p.Q);
+        f |= special ? (1u << i) : 0u;
+    }
+    return f;
 }
 
 // numpy-ordered sum of xf(x[0..n)) fused with a per-sample side effect; all threads return the sum and the
 // block-reduced aux (SIDE_HIST: count below the window; SIDE_COLLECT: max key below the bucket, aux2 = count
 // of samples closer to the centre than the bracket)
 template <int SIDE>
-static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, int n, int mode, float c, LDS BlockScratch *bs,
+static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_, int n, int mode, float c, LDS BlockScratch *bs,
                                                    SideParam param)
 {
+    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     uint32_t aux = 0, aux2 = 0;
     float total = 0.0f; // meaningful in wave 0
@@ -202,30 +206,41 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, 
     const int nhalf = (n / 8192) * 2; // half chunks of 4096 samples inside whole numpy chunks
     f4u v[4], vn[4];
     if (nhalf > 0) {
-        const f4u *p = reinterpret_cast<const f4u *>(x + w * 1024);
+        const GLB f4u *p = reinterpret_cast<const GLB f4u *>(x + w * 1024);
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = p[u * 64 + ln];
     }
     for (int hc = 0; hc < nhalf; hc++) {
         const int half = hc & 1;
         if (hc + 1 < nhalf) { // software pipeline: the next half chunk's loads fly while this one is summed
-            const f4u *p = reinterpret_cast<const f4u *>(x + (size_t)(hc + 1) * 4096 + w * 1024);
+            const GLB f4u *p = reinterpret_cast<const GLB f4u *>(x + (size_t)(hc + 1) * 4096 + w * 1024);
 #pragma unroll
             for (int u = 0; u < 4; u++) vn[u] = p[u * 64 + ln];
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
+        uint32_t flags = 0;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int e = (u * 64 + ln) * 4; // four consecutive samples of one leaf
-            bs_side4<SIDE>(v[u].x, v[u].y, v[u].z, v[u].w, param, bs, aux, aux2);
-            v4f t4 = {bs_x2(v[u].x, mode, c), bs_x2(v[u].y, mode, c), bs_x2(v[u].z, mode, c), bs_x2(v[u].w, mode, c)};
+            if (SIDE == SIDE_COLLECT) flags |= bs_flag4(v[u].x, v[u].y, v[u].z, v[u].w, param, aux2) << (4 * u);
+            else bs_side4<SIDE>(v[u].x, v[u].y, v[u].z, v[u].w, param, bs, aux, aux2);
+            // RAW samples are staged (the transform is applied on the way out): the flagged ones are re-read here
+            v4f t4 = {v[u].x, v[u].y, v[u].z, v[u].w};
             *reinterpret_cast<LDS v4f *>(wstage + (e >> 7) * BS_LEAF_STRIDE + (e & 127)) = t4;
         }
         ws_sync();
+        if (SIDE == SIDE_COLLECT && flags) { // the few flagged samples: exact classification and copies
+            do {
+                const int b = __ffs(flags) - 1;
+                flags &= flags - 1;
+                const int e = ((b >> 2) * 64 + ln) * 4 + (b & 3);
+                bs_copy_exact(wstage[(e >> 7) * BS_LEAF_STRIDE + (e & 127)], param, bs);
+            } while (flags);
+        }
         const LDS float *q = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
-        float r = q[0];
+        float r = bs_x2(q[0], mode, c);
 #pragma unroll
-        for (int t = 1; t < 16; t++) r += q[8 * t];
+        for (int t = 1; t < 16; t++) r += bs_x2(q[8 * t], mode, c);
         r = r + __shfl_xor(r, 1);   // the 8 accumulators of a leaf
         r = r + __shfl_xor(r, 2);
         r = r + __shfl_xor(r, 4);
@@ -255,7 +270,7 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x, 
         if (tid == 0) bs_enum_tail(tail, bs);
         __syncthreads();
         const int nleaf = bs->nleaf;
-        const float *xt = x + s;
+        const GLB float *xt = x + s;
         for (int g0 = 0; g0 < nleaf; g0 += 32) {
             // stage 32 leaves: wave w loads leaves g0 + 8w .. g0 + 8w + 7 (coalesced, 2 loads per leaf)
             __syncthreads();
@@ -378,9 +393,28 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs,
     return r;
 }
 
-// passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
-static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x, int n, LDS BlockScratch *bs, float med, float sd)
+// largest key below `key_lo` among x[0..n) (0 if none) -- all threads return it
+static __device__ __noinline__ uint32_t bs_max_key_below(const float *__restrict__ x_, int n, uint32_t key_lo, LDS BlockScratch *bs)
 {
+    const GLB float *x = (const GLB float *)x_;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) bs->below = 0;
+    __syncthreads();
+    uint32_t best = 0;
+    for (int i = tid; i < n; i += BS_THREADS) { uint32_t key = f2key(x[i]); if (key < key_lo && key > best) best = key; }
+    best = wave_max(best);
+    if ((tid & 63) == 0 && best) __hip_atomic_fetch_max(&bs->below, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    best = bs->below;
+    __syncthreads();
+    return best;
+}
+
+// passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
+static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x_, int n, LDS BlockScratch *bs, float med, float sd)
+{
+    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     const int k1 = n / 2;
     LDS uint32_t *h18 = bs->hist;
@@ -443,7 +477,7 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
     float mad;
     if (miss || bs->ncollect > BS_BINS18) {
         __syncthreads();
-        if (tid < 64) { float m_ = wave_median(x, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
+        if (tid < 64) { float m_ = wave_median(x_, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
         __syncthreads();
         mad = bs->bcast[1];
         __syncthreads();
@@ -455,15 +489,9 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
 
 // After pass A: predict where the MAD lies from the bucket histogram.  Returns false if no prediction.
 // c = centre of the median's bucket, w0 = its width; [P, Q] = bracket of distances to c.
-static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_t wlo, int bin, int k1, float &c, float &w0, float &P,
-                                                   float &Q)
+static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
 {
     const int tid = threadIdx.x;
-    const uint32_t key_lo = (wlo + (uint32_t)bin) << BS_KSH;
-    const float c_lo = key2f(key_lo), c_hi = key2f(key_lo + (1u << BS_KSH));
-    c = 0.5f * (c_lo + c_hi);
-    w0 = c_hi - c_lo;
-    if (!(w0 > 0.f) || __builtin_isinf(c_hi) || __builtin_isinf(c_lo)) return false;
     LDS uint32_t *dh = (LDS uint32_t *)bs->u.stage; // distance histogram, BS_BINS cells of width w0
     __syncthreads();
     for (int i = tid; i < BS_BINS; i += BS_THREADS) dh[i] = 0;
@@ -495,6 +523,16 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     const int tid = threadIdx.x;
     SegStats o;
     const int k1 = n / 2;
+#ifdef ADP_PHASE_TIMING
+    long long tph = clock64();
+    auto phase = [&](int slot) { // (debug build) shader cycles per phase, summed over the blocks' first threads
+        long long t = clock64();
+        if (tid == 0) atomicAdd(&g_dbg[8 + slot], (unsigned long long)(t - tph));
+        tph = t;
+    };
+#else
+    auto phase = [](int) {};
+#endif
     SideParam sp; sp.key = 0; sp.c = 0.f; sp.P = 0.f; sp.Q = 0.f; sp.do_mad = 0;
     // ---- pass A: mean + bucket histogram --------------------------------------------------
     uint32_t wlo = 0;
@@ -509,25 +547,41 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     sp.key = wlo;
     SumAux p1 = (have_medmad || (g_ablate & 2048)) ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, sp);
     o.mean = p1.sum / (float)n;
+    phase(0);
     bool fallback_med = false, predicted = false;
     int bin = 0, rk = 0;
-    float c = 0.f, w0 = 0.f, P = 0.f, Q = 0.f;
+    float c = 0.f, w0 = 0.f, P = 0.f, Q = 0.f, hw = 0.f;
     if (!have_medmad) {
         block_find_bin<BS_BINS>(bs, bs->hist, k1, (int)p1.aux);
         fallback_med = bs->flag != 0;
         bin = bs->bin; rk = k1 - bs->before;
         __syncthreads();
-        if (!fallback_med && !(g_ablate & 2)) predicted = bs_predict_mad(bs, wlo, bin, k1, c, w0, P, Q);
+        if (!fallback_med) {
+            // centre and (conservative) half width of the median's bucket
+            const uint32_t key_lo = (wlo + (uint32_t)bin) << BS_KSH;
+            const float c_lo = key2f(key_lo), c_hi = key2f(key_lo + (1u << BS_KSH));
+            c = 0.5f * (c_lo + c_hi);
+            w0 = c_hi - c_lo;
+            if (!(w0 > 0.f) || __builtin_isinf(c_hi) || __builtin_isinf(c_lo)) fallback_med = true; // (degenerate bucket: generic select)
+            else {
+                const float hm = fmaxf(c - c_lo, c_hi - c) * 1.0001f;
+                hw = __uint_as_float(__float_as_uint(hm) + 2u);
+            }
+        }
+        if (!fallback_med && !(g_ablate & 2)) predicted = bs_predict_mad(bs, wlo, k1, c, w0, P, Q);
         __syncthreads();
         if (tid == 0) { bs->ncollect = 0; bs->nmad = 0; }
         __syncthreads();
     }
+    phase(1);
     // ---- pass B: variance + median bucket + MAD bracket --------------------------------------
-    sp.key = wlo + (uint32_t)bin; sp.c = c; sp.P = P; sp.Q = Q; sp.do_mad = (predicted && !(g_ablate & 16384)) ? 1 : 0;
+    sp.key = wlo + (uint32_t)bin; sp.c = c; sp.hw = hw; sp.do_mad = (predicted && !(g_ablate & 16384)) ? 1 : 0;
+    if (sp.do_mad) { sp.P = P; sp.Q = Q; } else { sp.P = __builtin_inff(); sp.Q = -1.0f; } // (no bracket: nothing flagged for it)
     if (g_ablate & 4096) { o.sd = 0; o.med = 0; o.mad = 0; return o; }
     SumAux p2 = (have_medmad || fallback_med || (g_ablate & (2048 | 8192))) ? block_np_sum<SIDE_NONE>(x, n, 2, o.mean, bs, sp)
                                               : block_np_sum<SIDE_COLLECT>(x, n, 2, o.mean, bs, sp);
     o.sd = sqrtf(p2.sum / (float)n);
+    phase(2);
     if (have_medmad || (g_ablate & (2048 | 8192))) { o.med = med_in; o.mad = mad_in; return o; }
     if (fallback_med || bs->ncollect > BS_MEDCAP) {
         __syncthreads();
@@ -536,8 +590,11 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
         o.med = bs->bcast[1];
         __syncthreads();
     } else {
-        o.med = bs_median_from_bucket(bs, bs->collect, bs->ncollect, n, rk, p2.aux);
+        uint32_t below_key = 0;
+        if ((n & 1) == 0 && rk == 0) below_key = bs_max_key_below(x, n, (wlo + (uint32_t)bin) << BS_KSH, bs); // (rare)
+        o.med = bs_median_from_bucket(bs, bs->collect, bs->ncollect, n, rk, below_key);
     }
+    phase(3);
     // ---- MAD inside the bracket, if it can be proven ---------------------------------------------
     bool done = false;
     if (predicted && !fallback_med) {
@@ -569,7 +626,9 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
         if (!predicted) atomicAdd(&g_dbg[3], 1ull);
         if (predicted && !done && bs->nmad > BS_MADCAP) atomicAdd(&g_dbg[4], 1ull);
     }
+    phase(4);
     if (!done) o.mad = bs_mad_two_pass(x, n, bs, o.med, o.sd);
+    phase(5);
     return o;
 }
 

@@ -8,6 +8,9 @@
 // pointers into LDS keep their address space across (non-inlined) function boundaries, so that
 // accesses stay ds_* instructions instead of degrading to flat_* ones
 #define LDS __attribute__((address_space(3)))
+// likewise for global memory: a plain pointer handed to a non-inlined function is "generic" and its loads become
+// flat_* instructions, which also count against the LDS wait counter (lgkmcnt) and so serialise with LDS traffic
+#define GLB __attribute__((address_space(1)))
 #define WAVE 64
 #define CK 16          // cumulative-sum checkpoint spacing (pooled samples)
 #define TRACE_TILE 1024 // pooled samples handled per wave iteration in the gains kernel (64 lanes x CK)

@@ -31,7 +31,7 @@
 
 enum { N1_ALWAYS = 0, N1_IF_BAD = 1, N1_IF_NOT_DONE = 2 };
 
-extern __device__ unsigned long long g_dbg[8];
+extern __device__ unsigned long long g_dbg[24];
 
 // transform: mode 0 -> x ; mode 1 -> |x - med| (float32, as numpy computes np.abs(signal - med))
 static __device__ __forceinline__ float n1_xform(float x, int mode, float med) { return mode ? fabsf(x - med) : x; }
@@ -329,11 +329,6 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
                     mbs[mb].n_valid = st.n_valid;
                     mbs[mb].bad = 0;
                 } else {
-                if (st.ckw) { // tallies of why the bracket did not settle the statistic (debug)
-                    if (ovf) atomicAdd(&g_dbg[5], 1ull);
-                    else if (k < nb2) atomicAdd(&g_dbg[6], 1ull);
-                    else atomicAdd(&g_dbg[7], 1ull);
-                }
                 mbs[mb].n_valid = st.n_valid;
                 mbs[mb].c_below = st.c_below;
                 if (miss) mbs[mb].bad = 1;

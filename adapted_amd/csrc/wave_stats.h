@@ -20,16 +20,12 @@
 #define WS_STAGE_FLOATS (32 * 129)
 #define WS_LEAFBUF 160
 
-// barrier among the lanes of ONE wave that orders LDS traffic: a real s_barrier when the workgroup is a
-// single wave, otherwise a wave-level fence (LDS operations of one wave execute in order)
+// barrier among the lanes of ONE wave that orders its LDS traffic (LDS operations of one wave execute in order)
 static __device__ __forceinline__ void ws_sync()
 {
-    if (blockDim.x == 64) ws_sync();
-    else {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct WaveScratch {
@@ -141,7 +137,7 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
 static __device__ __noinline__ void wave_select2_global(const float *__restrict__ x, int n, int k, int mode, float c,
                                                         LDS WaveScratch *ws, float &vk, float &vkm1)
 {
-    wave_select2_impl<const float *>(x, n, k, mode, c, ws, vk, vkm1);
+    wave_select2_impl<const GLB float *>((const GLB float *)x, n, k, mode, c, ws, vk, vkm1);
 }
 static __device__ __noinline__ void wave_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                                      float &vk, float &vkm1)
@@ -221,7 +217,7 @@ static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int
             len = n2;                                           // descend left
         }
         if ((id & 63) == lane_id()) {
-            const float *p = x + off;
+            const GLB float *p = (const GLB float *)x + off;
             ws->leaf[id] = pw_leaf_f32(len, [&](int i) { return ws_xform(p[i], mode, c); });
         }
         id++;
@@ -261,7 +257,7 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
             float leafsum = 0.0f;
             for (int half = 0; half < 2; half++) {
                 ws_sync();
-                const float *p = x + s + half * 4096;
+                const GLB float *p = (const GLB float *)x + s + half * 4096;
                 for (int t = 0; t < 64; t++) {
                     int e = t * 64 + ln;
                     ws->stage[(e >> 7) * 129 + (e & 127)] = ws_xform(p[e], mode, c);

@@ -380,9 +380,9 @@ class Engine:
         self._check(self.lib.adp_debug_fetch(self._h, what, a.ctypes.data_as(C.c_void_p), C.c_uint64(a.nbytes)))
         return a
 
-    def debug_counters(self):
-        a = np.zeros(8, dtype=np.uint64)
-        self._check(self.lib.adp_debug_fetch(self._h, 8, a.ctypes.data_as(C.c_void_p), C.c_uint64(64)))
+    def debug_counters(self, n: int = 8):
+        a = np.zeros(n, dtype=np.uint64)
+        self._check(self.lib.adp_debug_fetch(self._h, 8, a.ctypes.data_as(C.c_void_p), C.c_uint64(8 * n)))
         return a
 
     def debug_norm_params(self, n_mb: int):
