@@ -469,6 +469,30 @@ int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len,
     return llr_pipeline(h, signals, full_len, n_reads, m, minibatch, flags, rows_out, mb_status, 8);
 }
 
+__global__ void k_debug_log(const double *in, double *out, int n)
+{
+    __shared__ double lt_[3 * LOGCR_N];
+    for (int i = threadIdx.x; i < 3 * LOGCR_N; i += blockDim.x) lt_[i] = g_logcr_table[i];
+    __syncthreads();
+    const LDS double *lt = (const LDS double *)lt_;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log_cr_impl(in[i], lt, [](double u) { return log(u); });
+}
+
+int adp_debug_log(adp_handle *h, const double *host_in, double *host_out, int n)
+{
+    if (!h || !host_in || !host_out || n < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)n * 16));
+    HIPCHK(hipMemcpyAsync(d, host_in, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_debug_log, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, d + n, n);
+    HIPCHK(hipMemcpyAsync(host_out, d + n, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d));
+    return ADP_OK;
+}
+
 int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch,
                        int flags, int stage)
 {

@@ -7,6 +7,8 @@
 //   G1  c_llr_trace -> _gains(0, n-1, c, c2, 5, 5)      adapted/detect/_c_llr.pyx:202-236, 67-88
 //   G2  c_llr_trace_gains -> _gains(a, n-1, c, c2, 1, 1) adapted/detect/_c_llr.pyx:176-199
 //       var_c                                            adapted/detect/_c_llr.pyx:23-37
+//       (the reference's libc log is replaced by log_cr.h: correctly rounded in practice, 2x cheaper than
+//       the device library's)
 //
 // np.cumsum is a strictly sequential float64 recurrence and the pass-2 trace next to the
 // adapter boundary is pure cumulative-sum rounding noise, so the recurrence is kept bit-exact:
@@ -16,6 +18,9 @@
 // evaluated in parallel.
 #pragma once
 #include "common.h"
+#include "log_cr.h"
+
+__device__ const double g_logcr_table[3 * LOGCR_N] = LOGCR_TABLE;
 
 // ---------------------------------------------------------------- D1
 #define NP_TILE 512
@@ -158,8 +163,13 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
                                               int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat)
 {
     __shared__ double sg[64 * (CK + 1)];
+    __shared__ double lt_[3 * LOGCR_N]; // log_cr's table
     const int r = blockIdx.x;
     const int ln = lane_id();
+    for (int i = ln; i < 3 * LOGCR_N; i += 64) lt_[i] = g_logcr_table[i];
+    __syncthreads();
+    const LDS double *lt = (const LDS double *)lt_;
+    auto flog = [&](double v) { return log_cr_impl(v, lt, [](double u) { return log(u); }); };
     if (mbs[r / mbsize].status != ADP_MB_OK) return;
     const int n = nvalid[r];
     if (n <= 0) return;
@@ -187,7 +197,7 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
     double vs;
     {
         double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, (double)(E - start));
-        vs = (double)(E - start) * log(v);
+        vs = (double)(E - start) * flog(v);
     }
     int first_pos = 0x7fffffff, last_pos = -1;
     double st_s1 = 0.0, st_s2 = 0.0; // PASS 1: sum and sum of squares of the non-NaN trace values (for np.nanstd in P1)
@@ -221,8 +231,8 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
                 if (i >= start + oh && i < E - ot) {
                     double vh = var_seg(b, c2s, a, cs, (double)(i - start));
                     double vt = var_seg(te.y, b, te.x, a, (double)(E - i));
-                    double h = (double)(i - start) * log(vh);
-                    double tl = (double)(E - i) * log(vt);
+                    double h = (double)(i - start) * flog(vh);
+                    double tl = (double)(E - i) * flog(vt);
                     gi = vs - (h + tl);
                 }
                 if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }

@@ -116,7 +116,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_destroy", "adp_set_config", "adp_stream", "adp_synchronize", "adp_detect_llr", "adp_detect_start_peak",
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
-           "adp_debug_llr_upto"]
+           "adp_debug_llr_upto", "adp_debug_log"]
 
 
 def _rng(r):
@@ -360,6 +360,12 @@ class Engine:
         return out, st
 
     # -- debug (tests) ------------------------------------------------------------------------
+    def debug_log(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._check(self.lib.adp_debug_log(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), int(x.size)))
+        return y
+
     def debug_llr_upto(self, signals, full_lens, n, minibatch, stage):
         sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, False)
         self._check(self.lib.adp_debug_llr_upto(self._h, sp, lp, int(n), self.m, int(minibatch), flags, int(stage)))

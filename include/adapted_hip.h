@@ -197,6 +197,9 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes);
 int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                        int minibatch, int flags, int stage);
 
+/* log_cr (adapted_amd/csrc/log_cr.h), the logarithm of the gains kernels, applied to n host doubles (tests only) */
+int adp_debug_log(adp_handle *h, const double *host_in, double *host_out, int n);
+
 #ifdef __cplusplus
 }
 #endif
