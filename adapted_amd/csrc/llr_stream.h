@@ -131,10 +131,33 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
 }
 
 // ---------------------------------------------------------------- gains
-static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, double len)
+// The two quotients of var_c share their divisor (the segment length), so the refined reciprocal of the IEEE
+// division sequence is computed once: y = v_rcp_f64(b) + two Newton steps, then per numerator
+// q0 = a y, r = a - b q0 (exact, one fma), q = q0 + r y.  This is instruction for instruction what the compiler
+// emits for a / b (v_div_scale / v_div_fmas / v_div_fixup only rescale operands near the ends of the exponent range
+// and patch zero / infinite / NaN operands), so the quotients are the same bits as long as no scaling is needed:
+// b is an integer in [1, 2^31), and the numerators are differences of running sums of float32 values or of their
+// squares -- zero, or multiples of 2^-298 below 2^83.  An infinite or NaN sum ends as a NaN variance either way.
+static __device__ __forceinline__ double recip_refined(double b)
 {
-    double mu = (chi - clo) / len;
-    return (c2hi - c2lo) / len - mu * mu;
+    const double y0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, y0, 1.0);
+    const double y1 = __builtin_fma(y0, e0, y0);
+    const double e1 = __builtin_fma(-b, y1, 1.0);
+    return __builtin_fma(y1, e1, y1);
+}
+static __device__ __forceinline__ double div_by_len(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, y, q0);
+}
+
+static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, int len)
+{
+    const double dl = (double)len, y = recip_refined(dl);
+    double mu = div_by_len(chi - clo, dl, y);
+    return div_by_len(c2hi - c2lo, dl, y) - mu * mu;
 }
 
 // grid = n_reads waves (block = 64).  PASS 1: start = 0, offsets (5, 5), also emits T1 (first / last
@@ -196,7 +219,7 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
     }
     double vs;
     {
-        double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, (double)(E - start));
+        double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, E - start);
         vs = (double)(E - start) * flog(v);
     }
     int first_pos = 0x7fffffff, last_pos = -1;
@@ -229,8 +252,8 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
             double gi = 0.0;
             if (i < n) {
                 if (i >= start + oh && i < E - ot) {
-                    double vh = var_seg(b, c2s, a, cs, (double)(i - start));
-                    double vt = var_seg(te.y, b, te.x, a, (double)(E - i));
+                    double vh = var_seg(b, c2s, a, cs, i - start);
+                    double vt = var_seg(te.y, b, te.x, a, E - i);
                     double h = (double)(i - start) * flog(vh);
                     double tl = (double)(E - i) * flog(vt);
                     gi = vs - (h + tl);
