@@ -53,87 +53,96 @@ static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 
 // ---------------------------------------------------------------- selection
 // x_(k) and x_(k-1) of xform(x[0..n)), 0 <= k < n.  All lanes return the same values.
+// One pass for the smallest and largest key, then an MSB-first radix select over d = key - min, 8 bits of the
+// SPAN per pass (a segment spanning 1.5 octaves of pA needs 3 passes, a constant one none): the digits are spread
+// over the bins whatever the level of the signal, so plain LDS atomics do.
 template <class P>
 static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                                          float &vk, float &vkm1)
 {
     const int ln = lane_id();
-    uint32_t prefix = 0, below = 0;
-    int krem = k;
-    int rank_in_bin = 0, lowbin = -1;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 24 - 8 * pass;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int base = 0; base < n; base += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : x[0]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { uint32_t key = f2key(ws_xform(v[u], mode, c)); mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    const uint32_t span = mx - mn;
+    int rb = span ? 32 - __clz(span) : 0; // bits of d still unresolved
+    uint32_t prefix = 0, krem = (uint32_t)k, below = 0; // below: largest d + 1 under the selected prefix (last pass)
+    int lowbin = -1, lastw = 0;
+    while (rb > 0) {
+        const int w = rb < 8 ? rb : 8;
+        const int shift = rb - w;
         for (int i = ln; i < 256; i += 64) ws->hist[i] = 0;
         ws_sync();
-        for (int base = 0; base < n; base += 256) {
-            float v[4];
+        for (int base = 0; base < n; base += 512) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : 0.0f; }
+            for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : 0.0f; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int i = base + u * 64 + ln;
-                uint32_t key = f2key(ws_xform(v[u], mode, c));
-                bool act = i < n;
-                if (pass > 0) {
-                    uint32_t top = key >> (shift + 8);
-                    if (pass == 3 && act && top < prefix && key > below) below = key;
-                    act = act && (top == prefix);
-                }
-                uint32_t digit = (key >> shift) & 255u;
-                unsigned long long m = __ballot(act);
-                if (m) {
-                    int f = __ffsll((long long)m) - 1;
-                    uint32_t d0 = __shfl(digit, f);
-                    bool same = !act || digit == d0;
-                    if (__all(same)) { if (ln == f) ws->hist[d0] += (uint32_t)__popcll(m); }
-                    else if (act) __hip_atomic_fetch_add(&ws->hist[digit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int u = 0; u < 8; u++) {
+                const int i = base + u * 64 + ln;
+                const uint32_t d = f2key(ws_xform(v[u], mode, c)) - mn;
+                const uint32_t top = (rb >= 32) ? 0u : (d >> rb);
+                if (i < n) {
+                    if (top == prefix) __hip_atomic_fetch_add(&ws->hist[(d >> shift) & ((1u << w) - 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else if (shift == 0 && top < prefix && d + 1u > below) below = d + 1u;
                 }
             }
         }
         ws_sync();
         // locate the bin of rank krem: each lane owns 4 consecutive bins
-        uint32_t h0 = ws->hist[4 * ln], h1 = ws->hist[4 * ln + 1], h2 = ws->hist[4 * ln + 2], h3 = ws->hist[4 * ln + 3];
-        int s = (int)(h0 + h1 + h2 + h3);
-        int incl = wave_scan_incl(s);
-        int excl = incl - s;
-        bool mine = krem >= excl && krem < incl;
+        const uint32_t h0 = ws->hist[4 * ln], h1 = ws->hist[4 * ln + 1], h2 = ws->hist[4 * ln + 2], h3 = ws->hist[4 * ln + 3];
+        const int s = (int)(h0 + h1 + h2 + h3);
+        const int incl = wave_scan_incl(s);
+        const int excl = incl - s;
+        const bool mine = (int)krem >= excl && (int)krem < incl;
         int bin = 0, before = 0;
         if (mine) {
             int cacc = excl;
-            if (krem < cacc + (int)h0) { bin = 4 * ln; before = cacc; }
+            if ((int)krem < cacc + (int)h0) { bin = 4 * ln; before = cacc; }
             else { cacc += h0;
-                if (krem < cacc + (int)h1) { bin = 4 * ln + 1; before = cacc; }
+                if ((int)krem < cacc + (int)h1) { bin = 4 * ln + 1; before = cacc; }
                 else { cacc += h1;
-                    if (krem < cacc + (int)h2) { bin = 4 * ln + 2; before = cacc; }
+                    if ((int)krem < cacc + (int)h2) { bin = 4 * ln + 2; before = cacc; }
                     else { cacc += h2; bin = 4 * ln + 3; before = cacc; } } }
         }
-        unsigned long long mm = __ballot(mine);
-        int src = __ffsll((long long)mm) - 1;
+        const unsigned long long mm = __ballot(mine);
+        const int src = __ffsll((long long)mm) - 1;
         bin = __shfl(bin, src);
         before = __shfl(before, src);
-        if (pass == 3) {
-            rank_in_bin = krem - before;
+        if (shift == 0) {
             int cand = -1; // largest non-empty bin below `bin` among this lane's four
             if (4 * ln < bin && h0) cand = 4 * ln;
             if (4 * ln + 1 < bin && h1) cand = 4 * ln + 1;
             if (4 * ln + 2 < bin && h2) cand = 4 * ln + 2;
             if (4 * ln + 3 < bin && h3) cand = 4 * ln + 3;
             lowbin = wave_max(cand);
+            lastw = w;
         }
-        prefix = (prefix << 8) | (uint32_t)bin;
-        krem -= before;
+        prefix = (prefix << w) | (uint32_t)bin;
+        krem -= (uint32_t)before;
+        rb = shift;
         ws_sync();
     }
-    vk = key2f(prefix);
+    vk = key2f(mn + prefix);
     vkm1 = vk;
-    if (rank_in_bin == 0 && k > 0) {
+    if (krem == 0 && k > 0) { // first of its key: the value before it is the largest key below
         below = wave_max(below);
-        uint32_t k0 = below;
-        if (lowbin >= 0) { uint32_t ka = (prefix & ~255u) | (uint32_t)lowbin; if (ka > k0) k0 = ka; }
-        vkm1 = key2f(k0);
+        uint32_t d0 = below ? below - 1u : 0u;
+        bool have = below != 0;
+        if (span && lowbin >= 0) {
+            uint32_t da = (prefix & ~((1u << lastw) - 1u)) | (uint32_t)lowbin;
+            if (!have || da > d0) d0 = da;
+            have = true;
+        }
+        if (have) vkm1 = key2f(mn + d0);
     }
 }
-
 static __device__ __noinline__ void wave_select2_global(const float *__restrict__ x, int n, int k, int mode, float c,
                                                         LDS WaveScratch *ws, float &vk, float &vkm1)
 {
