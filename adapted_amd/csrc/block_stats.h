@@ -49,6 +49,7 @@ struct BlockScratch {
     uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
     float collect[BS_MEDCAP]; // samples of the median's bucket
     float leafsum[64];
+    float tleaf[132]; // leaf sums of a ragged chunk
     int scan[8];
     int bin, before, ncollect, nmad, flag;
     uint32_t below, cntb;
@@ -303,11 +304,11 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
                 float res;
                 if (len >= 8) { res = r; for (int i = len - (len % 8); i < len; i++) res += q[i]; }
                 else { res = 0.0f; for (int i = 0; i < len; i++) res += q[i]; }
-                bs->u.ws.leaf[l] = res;
+                bs->tleaf[l] = res;
             }
         }
         __syncthreads();
-        if (tid < 64) total += bs_eval_tail(tail, bs->u.ws.leaf);
+        if (tid < 64) total += bs_eval_tail(tail, bs->tleaf);
     }
     __syncthreads();
     if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }

@@ -17,7 +17,8 @@
 #pragma once
 #include "common.h"
 
-#define WS_STAGE_FLOATS (32 * 129)
+#define WS_LEAF_STRIDE 136
+#define WS_STAGE_FLOATS (8 * WS_LEAF_STRIDE)
 #define WS_LEAFBUF 160
 
 // barrier among the lanes of ONE wave that orders its LDS traffic (LDS operations of one wave execute in order)
@@ -263,22 +264,36 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
         const int len = min(8192, n - s);
         float chunk;
         if (len == 8192) {
-            float leafsum = 0.0f;
-            for (int half = 0; half < 2; half++) {
+            // eight phases of 8 leaves (1024 samples): lane = (leaf, accumulator) runs one of numpy's 8 interleaved
+            // accumulator chains (16 samples); xor-shuffles fold the accumulators, then the 8 leaves (three levels of
+            // the balanced tree); the 8 phase sums make the top three levels
+            float ph[8];
+            const GLB float *p = (const GLB float *)x + s;
+#pragma unroll
+            for (int phs = 0; phs < 8; phs++) {
                 ws_sync();
-                const GLB float *p = (const GLB float *)x + s + half * 4096;
-                for (int t = 0; t < 64; t++) {
-                    int e = t * 64 + ln;
-                    ws->stage[(e >> 7) * 129 + (e & 127)] = ws_xform(p[e], mode, c);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = (u * 64 + ln) * 4;
+                    const GLB float *q4 = p + phs * 1024 + e;
+                    float a0 = ws_xform(q4[0], mode, c), a1 = ws_xform(q4[1], mode, c), a2 = ws_xform(q4[2], mode, c), a3 = ws_xform(q4[3], mode, c);
+                    LDS float *d = ws->stage + (e >> 7) * WS_LEAF_STRIDE + (e & 127);
+                    d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
                 }
                 ws_sync();
-                if ((ln >> 5) == half) {
-                    const LDS float *q = ws->stage + (ln & 31) * 129;
-                    leafsum = pw_leaf_f32(128, [&](int i) { return q[i]; });
-                }
+                const LDS float *q = ws->stage + (ln >> 3) * WS_LEAF_STRIDE + (ln & 7);
+                float r = q[0];
+#pragma unroll
+                for (int t = 1; t < 16; t++) r += q[8 * t];
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                r = r + __shfl_xor(r, 8);
+                r = r + __shfl_xor(r, 16);
+                r = r + __shfl_xor(r, 32);
+                ph[phs] = r;
             }
-            for (int o = 1; o < 64; o <<= 1) leafsum = leafsum + __shfl_xor(leafsum, o);
-            chunk = leafsum;
+            chunk = ((ph[0] + ph[1]) + (ph[2] + ph[3])) + ((ph[4] + ph[5]) + (ph[6] + ph[7]));
         } else {
             int id = 0;
             ws_sync();
