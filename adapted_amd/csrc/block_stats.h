@@ -49,13 +49,14 @@ struct BlockScratch {
     uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
     float collect[BS_MEDCAP]; // samples of the median's bucket
     float leafsum[64];
-    float tleaf[132]; // leaf sums of a ragged chunk
+    float tleaf[128]; // leaf sums of a ragged chunk, by tree slot
     int scan[8];
     int bin, before, ncollect, nmad, flag;
     uint32_t below, cntb;
     float bcast[4];
-    int nleaf;
-    short leaf_off[132], leaf_len[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk
+    int nleaf, tail_cached;
+    short leaf_off[132], leaf_len[132], leaf_slot[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk, and their tree slots
+    unsigned char slot_used[128];
 };
 
 static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
@@ -65,38 +66,59 @@ static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
     return d * d;
 }
 
-// numpy's pairwise recursion over a ragged chunk (< 8192 samples, depth <= 7), unrolled at compile time so
-// that no private stack is needed: leaves left to right, then the same tree over the leaf sums.
-template <int D>
-static __device__ __forceinline__ void bs_enum_leaves(int off, int len, LDS BlockScratch *bs, int &nl)
+// numpy's pairwise recursion over a ragged chunk (< 8192 samples): a node longer than 128 splits into
+// (n2, len - n2) with n2 = (len / 2) & ~7; depth <= 7.  Thread t < 128 walks from the root along the bits of t
+// (MSB first); a node that is already a leaf stays on the all-zero continuation of its path, so after 7 steps the
+// occupied slots, in slot order, are the leaves in numpy's left-to-right order.  The table is kept per tail
+// length: the two passes over a segment (and equal tails of later segments) reuse it.
+static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BlockScratch *bs)
 {
-    if (D == 0 || len <= 128) { bs->leaf_off[nl] = (short)off; bs->leaf_len[nl] = (short)len; nl++; return; }
-    int n2 = len / 2;
-    n2 -= n2 % 8;
-    bs_enum_leaves<(D > 0 ? D - 1 : 0)>(off, n2, bs, nl);
-    bs_enum_leaves<(D > 0 ? D - 1 : 0)>(off + n2, len - n2, bs, nl);
-}
-template <int D>
-static __device__ __forceinline__ float bs_eval_tree(int len, const LDS float *leaf, int &id)
-{
-    if (D == 0 || len <= 128) return leaf[id++];
-    int n2 = len / 2;
-    n2 -= n2 % 8;
-    float a = bs_eval_tree<(D > 0 ? D - 1 : 0)>(n2, leaf, id);
-    float b = bs_eval_tree<(D > 0 ? D - 1 : 0)>(len - n2, leaf, id);
-    return a + b;
+    const int tid = threadIdx.x;
+    if (bs->tail_cached == tail) return; // (uniform: written by one thread behind a barrier)
+    __syncthreads();
+    int off = 0, len = tail;
+    bool occupied = tid < 128;
+#pragma unroll
+    for (int d = 6; d >= 0; d--) {
+        const int bit = (tid >> d) & 1;
+        if (len <= 128) { if (bit) occupied = false; }
+        else {
+            int n2 = len / 2;
+            n2 -= n2 % 8;
+            if (bit) { off += n2; len -= n2; } else len = n2;
+        }
+    }
+    // compact the occupied slots (threads 0..127 = waves 0 and 1) in slot order
+    const unsigned long long m = __ballot(occupied);
+    if (tid == 0) bs->scan[0] = __popcll(m);
+    __syncthreads();
+    if (tid < 128) {
+        const int idx = (tid >= 64 ? bs->scan[0] : 0) + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+        if (occupied) { bs->leaf_off[idx] = (short)off; bs->leaf_len[idx] = (short)len; bs->leaf_slot[idx] = (short)tid; }
+        bs->tleaf[tid] = 0.0f;
+        bs->slot_used[tid] = occupied ? 1 : 0;
+        if (tid == 64) bs->nleaf = bs->scan[0] + __popcll(m);
+    }
+    if (tid == 0) bs->tail_cached = tail;
+    __syncthreads();
 }
 
-static __device__ __noinline__ void bs_enum_tail(int tail, LDS BlockScratch *bs)
+// sum of the tree from the leaf sums stored by slot (bs->tleaf, bs->slot_used): seven levels bottom-up; an empty
+// right sibling means the left one is carried up unchanged.  Wave 0 works; lane 0 returns the root.
+static __device__ __forceinline__ float bs_tail_tree(LDS BlockScratch *bs)
 {
-    int nl = 0;
-    bs_enum_leaves<7>(0, tail, bs, nl);
-    bs->nleaf = nl;
-}
-static __device__ __noinline__ float bs_eval_tail(int tail, const LDS float *leaf)
-{
-    int id = 0;
-    return bs_eval_tree<7>(tail, leaf, id);
+    const int ln = threadIdx.x; // (< 64)
+    float v0 = bs->tleaf[2 * ln], v1 = bs->tleaf[2 * ln + 1];
+    bool u0 = bs->slot_used[2 * ln] != 0, u1 = bs->slot_used[2 * ln + 1] != 0;
+    float v = u1 ? v0 + v1 : v0; // level 6 (64 nodes, one per lane)
+    bool u = u0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { // levels 5 .. 0: node = lanes aligned to 2*o
+        const float w = __shfl_down(v, o);
+        const bool wu = __shfl_down((int)u, o) != 0;
+        if ((ln & (2 * o - 1)) == 0) { if (wu) v = v + w; }
+    }
+    return v;
 }
 
 enum { SIDE_NONE = 0, SIDE_HIST = 1, SIDE_COLLECT = 2 };
@@ -268,8 +290,7 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
     if (tail > 0 && !(g_ablate & 4)) {
         for (int i = tid; i < tail; i += BS_THREADS) bs_side<SIDE>(x[s + i], param, bs, aux, aux2);
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
-        if (tid == 0) bs_enum_tail(tail, bs);
-        __syncthreads();
+        bs_tail_leaves(tail, bs);
         const int nleaf = bs->nleaf;
         const GLB float *xt = x + s;
         for (int g0 = 0; g0 < nleaf; g0 += 32) {
@@ -304,11 +325,11 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
                 float res;
                 if (len >= 8) { res = r; for (int i = len - (len % 8); i < len; i++) res += q[i]; }
                 else { res = 0.0f; for (int i = 0; i < len; i++) res += q[i]; }
-                bs->tleaf[l] = res;
+                bs->tleaf[bs->leaf_slot[l]] = res;
             }
         }
         __syncthreads();
-        if (tid < 64) total += bs_eval_tail(tail, bs->tleaf);
+        if (tid < 64) total += bs_tail_tree(bs); // (lane 0 holds the root)
     }
     __syncthreads();
     if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }
@@ -651,6 +672,8 @@ __global__ void __launch_bounds__(BS_THREADS, 4) k_partition_stats(const float *
     const int r = blockIdx.x;
     const PartReq q = req[r];
     if (!q.valid) return;
+    if (threadIdx.x == 0) bs->tail_cached = -1;
+    __syncthreads();
     const float *sig = sigs + (size_t)r * m;
     adp_row *row = rows + r;
     const int S = q.S;
