@@ -109,13 +109,14 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
     double2 *c = ck + (size_t)r * nck;
     double a = 0.0, b = 0.0;
     double2 t = make_double2(0.0, 0.0);
-    // one checkpoint block (CK = 16 pooled samples) per iteration: the four float4 loads are independent of
-    // the add chain, so the memory latency is paid once per 16 sequential steps
+    // one checkpoint block (CK = 16 pooled samples) per iteration; its four float4 loads are issued a block AHEAD of
+    // the add chain, so the chain never waits for memory
     const float4 *s4 = reinterpret_cast<const float4 *>(s); // rows start 256-byte aligned (Lp % 64 == 0)
+    float4 q0 = s4[0], q1 = s4[1], q2 = s4[2], q3 = s4[3];
     for (int j0 = 0; j0 < n; j0 += CK) {
         c[j0 / CK] = make_double2(a, b);
-        float4 q0 = s4[j0 / 4], q1 = s4[j0 / 4 + 1], q2 = s4[j0 / 4 + 2], q3 = s4[j0 / 4 + 3];
         const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        if (j0 + CK < n) { const int k4 = (j0 + CK) / 4; q0 = s4[k4]; q1 = s4[k4 + 1]; q2 = s4[k4 + 2]; q3 = s4[k4 + 3]; }
 #pragma unroll
         for (int u = 0; u < CK; u++) {
             const int j = j0 + u;

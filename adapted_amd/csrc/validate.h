@@ -42,43 +42,94 @@ struct RowW {
     __device__ void set(int c, double v) { if (lane_id() == 0) row->col[c] = v; present |= 1ull << c; }
 };
 
+// The two bottleneck recurrences below are strictly sequential chains in one lane.  Their loads do not depend on
+// the chain, so they are issued eight steps at a time, a block AHEAD of the arithmetic: otherwise every step
+// would wait for its own round trip to memory.
+#define BN_BLK 8
+
 // bottleneck.move_mean(a, window=w) for i >= w-1 (float32, NaN-free input) -- single lane
-static __device__ __noinline__ void bn_move_mean(const float *a, int n, int w, float *out)
+static __device__ __noinline__ void bn_move_mean(const float *a_, int n, int w, float *out_)
 {
+    const GLB float *a = (const GLB float *)a_;
+    GLB float *out = (GLB float *)out_;
     float asum = 0.f;
-    for (int i = 0; i < w; i++) asum += a[i];
+    for (int i0 = 0; i0 < w; i0 += BN_BLK) {
+        float v[BN_BLK];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) v[j] = (i0 + j < w) ? a[i0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) if (i0 + j < w) asum += v[j];
+    }
     out[0] = asum / (float)w;
     const float inv = (float)(1.0 / (double)w);
-    for (int i = w; i < n; i++) {
-        asum += a[i] - a[i - w];
-        out[i - w + 1] = asum * inv;
+    float cn[BN_BLK], co[BN_BLK], nn[BN_BLK], no[BN_BLK];
+#pragma unroll
+    for (int j = 0; j < BN_BLK; j++) { const int i = w + j; cn[j] = i < n ? a[i] : 0.f; co[j] = i < n ? a[i - w] : 0.f; }
+    for (int i0 = w; i0 < n; i0 += BN_BLK) {
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) { const int i = i0 + BN_BLK + j; nn[j] = i < n ? a[i] : 0.f; no[j] = i < n ? a[i - w] : 0.f; }
+        float res[BN_BLK];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) {
+            asum += cn[j] - co[j];
+            res[j] = asum * inv;
+        }
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) if (i0 + j < n) out[i0 + j - w + 1] = res[j];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) { cn[j] = nn[j]; co[j] = no[j]; }
     }
 }
 
 // bottleneck.move_var(a, window=w, ddof=0) for i >= w-1 -- single lane
-static __device__ __noinline__ void bn_move_var(const float *a, int n, int w, float *out)
+static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, float *out_)
 {
+    const GLB float *a = (const GLB float *)a_;
+    GLB float *out = (GLB float *)out_;
     float amean = 0.f, assqdm = 0.f;
     int count = 0;
-    for (int i = 0; i < w; i++) {
-        float ai = a[i];
-        count++;
-        float delta = ai - amean;
-        amean += delta / (float)count;
-        assqdm += delta * (ai - amean);
+    for (int i0 = 0; i0 < w; i0 += BN_BLK) {
+        float v[BN_BLK];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) v[j] = (i0 + j < w) ? a[i0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) {
+            if (i0 + j < w) {
+                const float ai = v[j];
+                count++;
+                float delta = ai - amean;
+                amean += delta / (float)count;
+                assqdm += delta * (ai - amean);
+            }
+        }
     }
     if (assqdm < 0) assqdm = 0;
     out[0] = assqdm / (float)count;
     const float ddof_inv = (float)(1.0 / (double)count), count_inv = ddof_inv;
-    for (int i = w; i < n; i++) {
-        float ai = a[i], aold = a[i - w];
-        float delta = ai - aold;
-        aold -= amean;
-        amean += delta * count_inv;
-        ai -= amean;
-        assqdm += (ai + aold) * delta;
-        if (assqdm < 0) assqdm = 0;
-        out[i - w + 1] = assqdm * ddof_inv;
+    float cn[BN_BLK], co[BN_BLK], nn[BN_BLK], no[BN_BLK];
+#pragma unroll
+    for (int j = 0; j < BN_BLK; j++) { const int i = w + j; cn[j] = i < n ? a[i] : 0.f; co[j] = i < n ? a[i - w] : 0.f; }
+    for (int i0 = w; i0 < n; i0 += BN_BLK) {
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) { const int i = i0 + BN_BLK + j; nn[j] = i < n ? a[i] : 0.f; no[j] = i < n ? a[i - w] : 0.f; }
+        float res[BN_BLK];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) {
+            if (i0 + j < n) { // (the padding of the last block must not touch the state)
+                float ai = cn[j], aold = co[j];
+                float delta = ai - aold;
+                aold -= amean;
+                amean += delta * count_inv;
+                ai -= amean;
+                assqdm += (ai + aold) * delta;
+                if (assqdm < 0) assqdm = 0;
+                res[j] = assqdm * ddof_inv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) if (i0 + j < n) out[i0 + j - w + 1] = res[j];
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) { cn[j] = nn[j]; co[j] = no[j]; }
     }
 }
 

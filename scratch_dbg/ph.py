@@ -1,0 +1,27 @@
+import sys, numpy as np
+sys.path.insert(0, "/root/repo")
+import torch
+from adapted_amd import lib
+from bench import make_spc
+spc = make_spc(200000)
+m = spc.sig_preload_size
+R, mb = 8000, 500
+eng = lib.Engine(spc, R, m, device=0)
+sig = torch.empty((R, m), dtype=torch.float32, device="cuda")
+ln = torch.full((R,), m, dtype=torch.int32, device="cuda")
+rows = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
+eng.synth_fill(sig.data_ptr(), ln.data_ptr(), R, seed=1, first_read=0, decorate=True)
+eng.detect_llr_rows(sig.data_ptr(), ln.data_ptr(), R, mb, with_start_peak=True, device_ptrs=True, rows_dev=rows.data_ptr())
+c0 = eng.debug_counters(24).astype(np.int64)
+eng.detect_llr_rows(sig.data_ptr(), ln.data_ptr(), R, mb, with_start_peak=True, device_ptrs=True, rows_dev=rows.data_ptr())
+c1 = eng.debug_counters(24).astype(np.int64)
+d = c1 - c0
+print("tallies", d[:8])
+ph = d[8:14].astype(float)
+print("phase share: passA %.1f%%  find/predict %.1f%%  passB %.1f%%  median %.1f%%  mad-select %.1f%%  mad-fallback %.1f%%" % tuple(100 * ph / ph.sum()))
+r = np.zeros(R, dtype=lib.ROW_DTYPE); eng.d2h(r, rows.data_ptr())
+C = {name: i for i, name in enumerate(lib.COLS)}
+col = r["col"]; ok = r["success"] == 1
+for nm in ("adapter_len", "polya_len", "rna_preloaded_len"):
+    v = col[ok, C[nm]]
+    print(nm, "mean %.0f  median %.0f  p90 %.0f" % (v.mean(), np.median(v), np.percentile(v, 90)))
