@@ -444,7 +444,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
             { Scope s(h, "k_start_peak");
-              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), 0, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
             hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
                                (const int32_t *)nullptr);
         }
@@ -517,7 +517,7 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
         const int32_t *ln = dlen + s0;
         HIPCHK(hipMemsetAsync(h->any_none.p, 0, 4, st));
         { Scope s(h, "k_start_peak");
-          hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), 0, st, sg, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
+          hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, sg, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
         hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
                            h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
         rc = launch_validate(h, sg, ln, n, m, 1, minibatch, false);

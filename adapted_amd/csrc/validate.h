@@ -426,10 +426,35 @@ static __device__ __forceinline__ float sp_pooled(const float *row, int m, int d
     return pw_leaf_f32(ds, [&](int k) { int i = b + k; return i < m ? row[i] : 0.0f; }) / (float)ds;
 }
 
-// detect_rna_start_peak (reference adapted/detect/start_peak.py:7-119); grid = n_reads waves
+// 64 pooled values j0 .. j0 + 63 at once: the 64 * ds raw samples are staged in LDS with coalesced 16-byte loads
+// (lane-strided scalar loads of ds samples each keep the texture-address unit busy ~4x longer), then lane l pools
+// its ds samples from LDS in numpy's order.  Samples at or beyond m count as zero (np.pad).
+typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
+static __device__ __forceinline__ float sp_pooled_tile(const float *row_, int m, int ds, int j0, LDS float *tile)
+{
+    const GLB float *row = (const GLB float *)row_;
+    const int ln = lane_id();
+    const long long b0 = (long long)j0 * ds;
+    const int nt = 64 * ds;
+    ws_sync();
+    for (int q = ln * 4; q < nt; q += 256) {
+        const long long i = b0 + q;
+        float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
+        if (i + 3 < m) { sp_f4u v = *reinterpret_cast<const GLB sp_f4u *>(row + i); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
+        else { if (i < m) x0 = row[i]; if (i + 1 < m) x1 = row[i + 1]; if (i + 2 < m) x2 = row[i + 2]; }
+        tile[q] = x0; if (q + 1 < nt) tile[q + 1] = x1; if (q + 2 < nt) tile[q + 2] = x2; if (q + 3 < nt) tile[q + 3] = x3;
+    }
+    ws_sync();
+    const LDS float *p = tile + ln * ds;
+    return pw_leaf_f32(ds, [&](int k) { return p[k]; }) / (float)ds;
+}
+
+// detect_rna_start_peak (reference adapted/detect/start_peak.py:7-119); grid = n_reads waves; dynamic LDS = 64 * ds floats
 __global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                    int m, adp_cfg cfg, SpOut *__restrict__ out)
 {
+    extern __shared__ float sp_tile_raw[];
+    LDS float *tile = (LDS float *)sp_tile_raw;
     const int r = blockIdx.x;
     const int ln = lane_id();
     const float *row = sigs + (size_t)r * m;
@@ -442,11 +467,15 @@ __global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sig
     // open pore: first raw sample above the threshold among the first end_idx RAW samples
     int op = 0x7fffffff;
     const float thr = (float)cfg.open_pore_pa;
-    for (int base = 0; base < end_idx && base < m; base += 64) {
-        int i = base + ln;
-        bool f = i < end_idx && i < m && row[i] > thr;
-        unsigned long long mk = __ballot(f);
-        if (mk) { op = base + __ffsll((long long)mk) - 1; break; }
+    for (int base = 0; base < end_idx && base < m && op == 0x7fffffff; base += 512) { // 8 tiles per round trip to memory
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + u * 64 + ln; v[u] = (i < end_idx && i < m) ? row[i] : -__builtin_inff(); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long mk = __ballot(v[u] > thr);
+            if (mk && op == 0x7fffffff) op = base + u * 64 + __ffsll((long long)mk) - 1;
+        }
     }
     op = (op == 0x7fffffff) ? 0 : op / ds;
     const bool has_op = op > 0;
@@ -454,12 +483,20 @@ __global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sig
     bool valid = (b - a > 0);
     float mx = 0.f; int max_idx = 0;
     if (valid) {
-        float lm = -__builtin_inff(); bool anynan = false;
-        for (int j = a + ln; j < b; j += 64) { float v = sp_pooled(row, m, ds, j); if (v != v) anynan = true; else if (v > lm) lm = v; }
+        // np.argmax semantics in one sweep: value and FIRST index of the maximum; a NaN anywhere makes the maximum NaN,
+        // which equals nothing (index 0)
+        float lm = -__builtin_inff(); int li = 0x7fffffff; bool anynan = false;
+        for (int j0 = a; j0 < b; j0 += 64) {
+            const int j = j0 + ln;
+            float v = sp_pooled_tile(row, m, ds, j0, tile);
+            if (j >= b) continue;
+            if (v != v) anynan = true;
+            else if (v > lm || li == 0x7fffffff) { lm = v; li = j; }
+        }
         anynan = __any(anynan);
-        mx = anynan ? __builtin_nanf("") : wave_max(lm);
-        int first = 0x7fffffff;
-        for (int j = a + ln; j < b; j += 64) { if (sp_pooled(row, m, ds, j) == mx) first = min(first, j); }
+        const float wm = wave_max(lm);
+        mx = anynan ? __builtin_nanf("") : wm;
+        int first = (!anynan && li != 0x7fffffff && lm == wm) ? li : 0x7fffffff;
         first = wave_min(first);
         max_idx = (first == 0x7fffffff ? 0 : first - a) + off1;
     }
@@ -469,11 +506,11 @@ __global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sig
     int nxt = 0;
     if (valid) {
         int hit = 0x7fffffff;
-        for (int base = a2; base < e0; base += 64) {
-            int j = base + ln;
-            bool f = j < e0 && sp_pooled(row, m, ds, j) > mx;
-            unsigned long long mk = __ballot(f);
-            if (mk) { hit = base + __ffsll((long long)mk) - 1; break; }
+        for (int base = a2; base < e0 && hit == 0x7fffffff; base += 64) {
+            const int j = base + ln;
+            const float v = sp_pooled_tile(row, m, ds, base, tile);
+            const unsigned long long mk = __ballot(j < e0 && v > mx);
+            if (mk) hit = base + __ffsll((long long)mk) - 1;
         }
         nxt = (hit == 0x7fffffff ? 0 : hit - a2) + s0;
         if (nxt >= L) valid = false;
