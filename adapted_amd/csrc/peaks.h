@@ -119,6 +119,200 @@ static __device__ double tv_width(const TraceView &t, int p, double prom, double
     return right_ip - left_ip;
 }
 
+// ---- long walks, cooperatively ------------------------------------------------------------------------
+// The dominant peak of a trace has nothing higher on either side: its prominence walk runs to the ends of the
+// trace (hundreds of dependent steps in ONE lane while 63 wait), and its width walk is long too.  A lane whose
+// private walk is not done within a budget hands the peak to the whole wave: 64 summary blocks (or the 64 samples
+// of one block) are tested per step.
+enum { WALK_PROM = 0, WALK_WIDTH = 1 };
+
+template <int KIND>
+static __device__ __forceinline__ bool walk_block_clean(double bmx, double bmn, double xp, double height)
+{
+    return KIND == WALK_PROM ? (bmx <= xp) : (bmn > height && bmx <= xp);
+}
+template <int KIND>
+static __device__ __forceinline__ bool walk_hit(double v, double xp, double height)
+{
+    return KIND == WALK_PROM ? !(v <= xp) : !(height < v);
+}
+
+// nearest j in [limit, start], searching downwards, with walk_hit(x[j]); limit - 1 if none.  mn (WALK_PROM):
+// minimum of the samples passed, i.e. those above j.  Uniform call (all lanes, same arguments).
+template <int KIND>
+static __device__ int coop_find_down(const TraceView &t, int start, int limit, double xp, double height, double &mn)
+{
+    const int ln = lane_id();
+    double lmn = xp;
+    int i = start, found = limit - 1;
+    while (i >= limit) {
+        int b = i / SUMBLK, bstart = b * SUMBLK;
+        if (t.bmax && i == bstart + SUMBLK - 1 && bstart >= limit) {
+            // up to 64 whole blocks at once: lane l looks at block b - l
+            const int bb = b - ln;
+            const bool whole = bb >= 0 && bb * SUMBLK >= limit;
+            const double bmx = whole ? t.bmax[bb] : 0.0, bmn = whole ? t.bmin[bb] : 0.0;
+            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height);
+            const unsigned long long m = __ballot(dirty);
+            const int first = m ? __ffsll((long long)m) - 1 : 64;
+            if (KIND == WALK_PROM && ln < first && bmn < lmn) lmn = bmn;
+            b -= first; bstart = b * SUMBLK;
+            i = bstart + SUMBLK - 1;
+            if (first == 64 || i < limit) continue;
+        }
+        // the samples of block b within [limit, i]
+        const int e = bstart + ln;
+        const bool in = e >= limit && e <= i;
+        const double v = in ? tv_get(t, e) : 0.0;
+        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height));
+        if (m) {
+            found = bstart + 63 - __clzll((long long)m);
+            if (KIND == WALK_PROM && in && e > found && v < lmn) lmn = v;
+            break;
+        }
+        if (KIND == WALK_PROM && in && v < lmn) lmn = v;
+        i = bstart - 1;
+    }
+    if (KIND == WALK_PROM) mn = wave_min(lmn);
+    return found;
+}
+
+// nearest j in [start, limit], searching upwards; limit + 1 if none
+template <int KIND>
+static __device__ int coop_find_up(const TraceView &t, int start, int limit, double xp, double height, double &mn)
+{
+    const int ln = lane_id();
+    double lmn = xp;
+    int i = start, found = limit + 1;
+    while (i <= limit) {
+        int b = i / SUMBLK, bstart = b * SUMBLK;
+        if (t.bmax && i == bstart && bstart + SUMBLK - 1 <= limit) {
+            const int bb = b + ln;
+            const bool whole = bb * SUMBLK + SUMBLK - 1 <= limit;
+            const double bmx = whole ? t.bmax[bb] : 0.0, bmn = whole ? t.bmin[bb] : 0.0;
+            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height);
+            const unsigned long long m = __ballot(dirty);
+            const int first = m ? __ffsll((long long)m) - 1 : 64;
+            if (KIND == WALK_PROM && ln < first && bmn < lmn) lmn = bmn;
+            b += first; bstart = b * SUMBLK;
+            i = bstart;
+            if (first == 64 || i > limit) continue;
+        }
+        const int e = bstart + ln;
+        const bool in = e >= i && e <= limit;
+        const double v = in ? tv_get(t, e) : 0.0;
+        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height));
+        if (m) {
+            found = bstart + __ffsll((long long)m) - 1;
+            if (KIND == WALK_PROM && in && e < found && v < lmn) lmn = v;
+            break;
+        }
+        if (KIND == WALK_PROM && in && v < lmn) lmn = v;
+        i = bstart + SUMBLK;
+    }
+    if (KIND == WALK_PROM) mn = wave_min(lmn);
+    return found;
+}
+
+// the walks of tv_prominence / tv_width with a step budget: false if a walk was cut short
+static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budget, double &prom)
+{
+    const double xp = tv_get(t, p);
+    double left_min = xp, right_min = xp;
+    int i = p, steps = 0;
+    while (i >= t.lo) {
+        if (++steps > budget) return false;
+        double v = tv_get(t, i);
+        if (!(v <= xp)) break;
+        if (v < left_min) left_min = v;
+        i--;
+    }
+    i = p; steps = 0;
+    while (i <= t.hi) {
+        if (++steps > budget) return false;
+        double v = tv_get(t, i);
+        if (!(v <= xp)) break;
+        if (v < right_min) right_min = v;
+        i++;
+    }
+    prom = xp - (left_min > right_min ? left_min : right_min);
+    return true;
+}
+static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, double rel, int budget, double &width)
+{
+    const double xp = tv_get(t, p);
+    const double height = xp - prom * rel;
+    int i = p, steps = 0;
+    while (i > t.lo) {
+        if (++steps > budget) return false;
+        if (!(height < tv_get(t, i))) break;
+        i--;
+    }
+    double left_ip = (double)i;
+    {
+        double xi = tv_get(t, i);
+        if (xi < height) left_ip += (height - xi) / (tv_get(t, i + 1) - xi);
+    }
+    i = p; steps = 0;
+    while (i < t.hi) {
+        if (++steps > budget) return false;
+        if (!(height < tv_get(t, i))) break;
+        i++;
+    }
+    double right_ip = (double)i;
+    {
+        double xi = tv_get(t, i);
+        if (xi < height) right_ip -= (height - xi) / (tv_get(t, i - 1) - xi);
+    }
+    width = right_ip - left_ip;
+    return true;
+}
+
+// Per lane: does the local maximum p (or -1: none) pass prominence >= pmin and width(rel) >= wmin?
+// Uniform call.  Short walks run privately in each lane, long ones cooperatively, one peak at a time.
+#define WALK_BUDGET 48
+static __device__ bool wave_peak_ok(const TraceView &t, int p, double pmin, double wmin, double rel)
+{
+    const int ln = lane_id();
+    double prom = 0.0;
+    bool have = p >= 0, done = true;
+    if (have) done = tv_prominence_budget(t, p, WALK_BUDGET, prom);
+    unsigned long long todo = __ballot(have && !done);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int pp = __shfl(p, src);
+        const double xp = tv_get(t, pp);
+        double lmin, rmin;
+        coop_find_down<WALK_PROM>(t, pp, t.lo, xp, 0.0, lmin);
+        coop_find_up<WALK_PROM>(t, pp, t.hi, xp, 0.0, rmin);
+        if (ln == src) prom = xp - (lmin > rmin ? lmin : rmin);
+    }
+    bool cand = have && (pmin <= prom);
+    double width = 0.0;
+    done = true;
+    if (cand) done = tv_width_budget(t, p, prom, rel, WALK_BUDGET, width);
+    todo = __ballot(cand && !done);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int pp = __shfl(p, src);
+        const double pr = __shfl(prom, src);
+        const double xp = tv_get(t, pp);
+        const double height = xp - pr * rel;
+        double dummy;
+        int il = coop_find_down<WALK_WIDTH>(t, pp, t.lo + 1, xp, height, dummy);
+        if (il < t.lo + 1) il = t.lo;
+        int ir = coop_find_up<WALK_WIDTH>(t, pp, t.hi - 1, xp, height, dummy);
+        if (ir > t.hi - 1) ir = t.hi;
+        double left_ip = (double)il, right_ip = (double)ir;
+        { double xi = tv_get(t, il); if (xi < height) left_ip += (height - xi) / (tv_get(t, il + 1) - xi); }
+        { double xi = tv_get(t, ir); if (xi < height) right_ip -= (height - xi) / (tv_get(t, ir - 1) - xi); }
+        if (ln == src) width = right_ip - left_ip;
+    }
+    return cand && (wmin <= width);
+}
+
 // First peak (lowest index) of find_peaks(x[lo..hi], prominence=pmin, width=wmin, rel_height=rel),
 // in full-trace coordinates, or -1.  Wave-cooperative: call from uniform control flow.
 static __device__ int wave_first_peak(const TraceView &t, double pmin, double wmin, double rel)
@@ -127,11 +321,7 @@ static __device__ int wave_first_peak(const TraceView &t, double pmin, double wm
     for (int base = t.lo + 1; base < t.hi; base += 64) {
         int i = base + ln;
         int p = (i < t.hi) ? tv_peak_at(t, i) : -1;
-        bool ok = false;
-        if (p >= 0) {
-            double prom = tv_prominence(t, p);
-            if (pmin <= prom) ok = (wmin <= tv_width(t, p, prom, rel));
-        }
+        const bool ok = wave_peak_ok(t, p, pmin, wmin, rel);
         unsigned long long mk = __ballot(ok);
         if (mk) return __shfl(p, __ffsll((long long)mk) - 1);
     }
@@ -162,8 +352,21 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
             double s1 = gstat[3 * r], s2 = gstat[3 * r + 1];
             int nnan = (int)gstat[3 * r + 2];
             double o1 = 0.0, o2 = 0.0; int onan = 0;
-            for (int i = ln; i < se.x; i += 64) { double v = g[i]; o1 += v; o2 += v * v; }
-            for (int i = se.y + ln; i < n; i += 64) { double v = g[i]; if (v == v) { o1 += v; o2 += v * v; } else onan++; }
+            // (eight loads in flight per lane: these two sweeps cover most of the trace of a typical read)
+            for (int i0 = 0; i0 < se.x; i0 += 512) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < se.x ? g[i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { o1 += v[u]; o2 += v[u] * v[u]; }
+            }
+            for (int i0 = se.y; i0 < n; i0 += 512) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < n ? g[i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { if (v[u] == v[u]) { o1 += v[u]; o2 += v[u] * v[u]; } else onan++; }
+            }
             o1 = wave_sum(o1); o2 = wave_sum(o2); onan = wave_sum(onan);
             const int cnt = cn - (nnan - onan);
             const double sum = s1 - o1, sq = s2 - o2;
@@ -369,11 +572,7 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
             for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += 64) {
                 int k = base + ln;
                 int i = (k < nkept) ? pk[k] : -1;
-                bool ok = false;
-                if (i >= 0) {
-                    double prom = tv_prominence(tv, i);
-                    if (1.0 <= prom) ok = (10.0 <= tv_width(tv, i, prom, 0.5));
-                }
+                const bool ok = wave_peak_ok(tv, i, 1.0, 10.0, 0.5);
                 unsigned long long m = __ballot(ok);
                 while (m && p1 < 0) {
                     int f = __ffsll((long long)m) - 1;
