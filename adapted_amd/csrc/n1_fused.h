@@ -70,24 +70,31 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
 
 struct N1FAcc { uint32_t nvalid, nbelow, ninner; };
 
-static __device__ __forceinline__ void n1f_account(float x, float med_s, float A0, float A1, float D0, float D1, N1FAcc &a,
-                                                   LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+// per sample, free of branches: the three counts, and whether the sample has to be copied out (1.5 % of them)
+static __device__ __forceinline__ uint32_t n1f_count(float x, float med_s, float A0, float A1, float D0, float D1, N1FAcc &a)
 {
     const float u = x - med_s;
     const float t = fabsf(u);
-    a.nvalid += (t == t) ? 1u : 0u;
-    a.nbelow += (u < A0) ? 1u : 0u;
+    const bool below = u < A0;
     const bool inner = t < D0;
+    a.nvalid += (t == t) ? 1u : 0u;
+    a.nbelow += below ? 1u : 0u;
     a.ninner += inner ? 1u : 0u;
-    if (inner) {
-        if (u >= A0 && u < A1) {
-            uint32_t slot = __hip_atomic_fetch_add(cnt2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < N1F_LDS_M) cbm[slot] = x;
-        }
-    } else if (t <= D1) {
-        uint32_t slot = __hip_atomic_fetch_add(cnt2 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (slot < N1F_LDS_B) cbb[slot] = x;
-    }
+    const bool take = inner ? (!below && u < A1) : (t <= D1); // (a NaN takes neither branch's condition)
+    return take ? 1u : 0u;
+}
+// the copy itself: median bracket -> first list, MAD band -> second
+static __device__ __forceinline__ void n1f_copy(float x, float med_s, float D0, LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+{
+    const bool inner = fabsf(x - med_s) < D0;
+    uint32_t slot = __hip_atomic_fetch_add(cnt2 + (inner ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (inner) { if (slot < N1F_LDS_M) cbm[slot] = x; }
+    else if (slot < N1F_LDS_B) cbb[slot] = x;
+}
+static __device__ __forceinline__ void n1f_account(float x, float med_s, float A0, float A1, float D0, float D1, N1FAcc &a,
+                                                   LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+{
+    if (n1f_count(x, med_s, A0, A1, D0, D1, a)) n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
 }
 
 // grid = (blocks_per_minibatch, n_minibatch); block = N1_THREADS
@@ -123,8 +130,18 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
             int i = threadIdx.x;
             for (; i + N1_THREADS < T4; i += 2 * N1_THREADS) { // two loads in flight per lane
                 float4 v = row4[i], w = row4[i + N1_THREADS];
-                ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w);
-                ACC(w.x); ACC(w.y); ACC(w.z); ACC(w.w);
+                const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
+                uint32_t fl = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) fl |= n1f_count(e[q], med_s, A0, A1, D0, D1, a) << q;
+                while (fl) { // the few samples to copy: one at a time, picked out of the eight registers
+                    const int q = __ffs(fl) - 1;
+                    fl &= fl - 1;
+                    float x = e[0];
+#pragma unroll
+                    for (int z = 1; z < 8; z++) x = (q == z) ? e[z] : x;
+                    n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
+                }
             }
             for (; i < T4; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
             for (int j = (T4 << 2) + threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
