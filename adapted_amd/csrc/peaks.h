@@ -20,6 +20,7 @@
 
 #define DBLMAX 1.7976931348623157e308
 extern __device__ int g_ablate;
+extern __device__ unsigned long long g_dbg[24]; // (debug tallies; 16-23: k_polya_peak in a -DADP_PHASE_TIMING build)
 
 struct TraceView {
     const double *x;     // trace of one read (full-trace coordinates)
@@ -214,26 +215,40 @@ static __device__ int coop_find_up(const TraceView &t, int start, int limit, dou
     return found;
 }
 
-// the walks of tv_prominence / tv_width with a step budget: false if a walk was cut short
+// the walks of tv_prominence / tv_width with a step budget: false if a walk was cut short.  Eight samples are
+// loaded per round trip to memory (the loads do not depend on the comparisons), then examined in walk order.
+#define WALK_CHUNK 8
 static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budget, double &prom)
 {
     const double xp = tv_get(t, p);
     double left_min = xp, right_min = xp;
-    int i = p, steps = 0;
-    while (i >= t.lo) {
-        if (++steps > budget) return false;
-        double v = tv_get(t, i);
-        if (!(v <= xp)) break;
-        if (v < left_min) left_min = v;
-        i--;
+    bool stopped = false;
+    for (int i0 = p, steps = 0; !stopped && i0 >= t.lo; i0 -= WALK_CHUNK, steps += WALK_CHUNK) {
+        if (steps >= budget) return false;
+        double v[WALK_CHUNK];
+#pragma unroll
+        for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 - u >= t.lo) ? tv_get(t, i0 - u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < WALK_CHUNK; u++) {
+            if (!stopped) {
+                if (i0 - u < t.lo || !(v[u] <= xp)) stopped = true;
+                else if (v[u] < left_min) left_min = v[u];
+            }
+        }
     }
-    i = p; steps = 0;
-    while (i <= t.hi) {
-        if (++steps > budget) return false;
-        double v = tv_get(t, i);
-        if (!(v <= xp)) break;
-        if (v < right_min) right_min = v;
-        i++;
+    stopped = false;
+    for (int i0 = p, steps = 0; !stopped && i0 <= t.hi; i0 += WALK_CHUNK, steps += WALK_CHUNK) {
+        if (steps >= budget) return false;
+        double v[WALK_CHUNK];
+#pragma unroll
+        for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 + u <= t.hi) ? tv_get(t, i0 + u) : 0.0;
+#pragma unroll
+        for (int u = 0; u < WALK_CHUNK; u++) {
+            if (!stopped) {
+                if (i0 + u > t.hi || !(v[u] <= xp)) stopped = true;
+                else if (v[u] < right_min) right_min = v[u];
+            }
+        }
     }
     prom = xp - (left_min > right_min ? left_min : right_min);
     return true;
@@ -242,28 +257,44 @@ static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, d
 {
     const double xp = tv_get(t, p);
     const double height = xp - prom * rel;
-    int i = p, steps = 0;
-    while (i > t.lo) {
-        if (++steps > budget) return false;
-        if (!(height < tv_get(t, i))) break;
-        i--;
-    }
-    double left_ip = (double)i;
+    // left: the first index i (descending from p, i > lo) with !(height < x[i]); lo if none
+    int il = t.lo;
     {
-        double xi = tv_get(t, i);
-        if (xi < height) left_ip += (height - xi) / (tv_get(t, i + 1) - xi);
+        bool stopped = false;
+        for (int i0 = p, steps = 0; !stopped && i0 > t.lo; i0 -= WALK_CHUNK, steps += WALK_CHUNK) {
+            if (steps >= budget) return false;
+            double v[WALK_CHUNK];
+#pragma unroll
+            for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 - u > t.lo) ? tv_get(t, i0 - u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < WALK_CHUNK; u++) {
+                if (!stopped) {
+                    if (i0 - u <= t.lo) { stopped = true; il = t.lo; }
+                    else if (!(height < v[u])) { stopped = true; il = i0 - u; }
+                }
+            }
+        }
     }
-    i = p; steps = 0;
-    while (i < t.hi) {
-        if (++steps > budget) return false;
-        if (!(height < tv_get(t, i))) break;
-        i++;
-    }
-    double right_ip = (double)i;
+    int ir = t.hi;
     {
-        double xi = tv_get(t, i);
-        if (xi < height) right_ip -= (height - xi) / (tv_get(t, i - 1) - xi);
+        bool stopped = false;
+        for (int i0 = p, steps = 0; !stopped && i0 < t.hi; i0 += WALK_CHUNK, steps += WALK_CHUNK) {
+            if (steps >= budget) return false;
+            double v[WALK_CHUNK];
+#pragma unroll
+            for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 + u < t.hi) ? tv_get(t, i0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < WALK_CHUNK; u++) {
+                if (!stopped) {
+                    if (i0 + u >= t.hi) { stopped = true; ir = t.hi; }
+                    else if (!(height < v[u])) { stopped = true; ir = i0 + u; }
+                }
+            }
+        }
     }
+    double left_ip = (double)il, right_ip = (double)ir;
+    { double xi = tv_get(t, il); if (xi < height) left_ip += (height - xi) / (tv_get(t, il + 1) - xi); }
+    { double xi = tv_get(t, ir); if (xi < height) right_ip -= (height - xi) / (tv_get(t, ir - 1) - xi); }
     width = right_ip - left_ip;
     return true;
 }
@@ -408,6 +439,9 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
 // ---------------------------------------------------------------- poly(A) end (P4)
 // 2-bit state per local maximum, by ORDINAL in the read's index-ordered list of maxima; transitions only clear
 // bits (one LDS atomic and): undecided 3 -> kept 2 / removed 1
+#ifndef PK_STEP
+#define PK_STEP 16 // kept maxima examined per step of step 4
+#endif
 #define PST_NONE 0u
 #define PST_REMOVED 1u
 #define PST_KEPT 2u
@@ -569,9 +603,11 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
             // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
             // survivors, compacted in index order (LDS state scan), then 64 candidates per step
             int p0 = -1, p1 = -1;
-            for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += 64) {
+            // (16 candidates per step: the second survivor is among the first 32 kept maxima of almost every read, and
+            // every candidate with a long walk costs the whole wave a cooperative scan)
+            for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += PK_STEP) {
                 int k = base + ln;
-                int i = (k < nkept) ? pk[k] : -1;
+                int i = (ln < PK_STEP && k < nkept) ? pk[k] : -1;
                 const bool ok = wave_peak_ok(tv, i, 1.0, 10.0, 0.5);
                 unsigned long long m = __ballot(ok);
                 while (m && p1 < 0) {
