@@ -526,13 +526,20 @@ __global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ tr
                 const bool valid = k >= 0 && k < npk;
                 const int p = valid ? pk[k] : (k < 0 ? -0x40000000 : 0x40000000);
                 const double v = valid ? tv_get(tv, p) : 0.0;
-                uint32_t mask = 0;
+                // forward neighbours k+j by shuffle; the backward relation of k to k-j is the forward one seen from
+                // k-j with the comparison reversed (the sanitised values hold no NaN), so it travels as one bit
+                uint32_t mask = 0, lower = 0; // lower bit j-1: k+j lies within 9 samples and is LOWER than k
 #pragma unroll
                 for (int j = 1; j <= 4; j++) {
                     const int pf = __shfl_down(p, j); const double vf = __shfl_down(v, j);
-                    const int pb = __shfl_up(p, j);   const double vb = __shfl_up(v, j);
-                    if (pf - p <= 9 && vf >= v) mask |= 1u << (j - 1);
-                    if (p - pb <= 9 && vb > v) mask |= 1u << (4 + j - 1);
+                    const bool within = pf - p <= 9;
+                    if (within && vf >= v) mask |= 1u << (j - 1);
+                    if (within && !(vf >= v)) lower |= 1u << (j - 1);
+                }
+#pragma unroll
+                for (int j = 1; j <= 4; j++) {
+                    const uint32_t lb = (uint32_t)__shfl_up((int)lower, j);
+                    if (lb >> (j - 1) & 1u) mask |= 1u << (4 + j - 1); // k-j is within 9 and k is lower than it
                 }
                 const bool out = valid && ln >= 4 && ln < 60;
                 if (out) {
