@@ -250,6 +250,13 @@ static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float 
         };
         const uint32_t n4 = n >> 2;
         uint32_t i = tid;
+        for (; i + 7 * 1024 < n4; i += 8 * 1024) { // eight 16-byte loads in flight per thread: one block per minibatch
+            float4 v[8];                             // has to pull its copied samples through a single CU
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = xs4[i + u * 1024];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { visit(v[u].x); visit(v[u].y); visit(v[u].z); visit(v[u].w); }
+        }
         for (; i + 1024 < n4; i += 2048) {
             float4 v = xs4[i], w = xs4[i + 1024];
             visit(v.x); visit(v.y); visit(v.z); visit(v.w); visit(w.x); visit(w.y); visit(w.z); visit(w.w);
