@@ -411,9 +411,9 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         }
         if (upto >= 4) {
             Scope s(h, "k_gains<1>");
-            hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+            hipLaunchKernelGGL(k_gains<1>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>());
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n);
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
@@ -424,9 +424,9 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         }
         if (upto >= 6) {
             Scope s(h, "k_gains<2>");
-            hipLaunchKernelGGL(k_gains<2>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+            hipLaunchKernelGGL(k_gains<2>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>());
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n);
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
@@ -628,9 +628,9 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>());
-    hipLaunchKernelGGL(k_gains<1>, dim3(n), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
+    hipLaunchKernelGGL(k_gains<1>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
-                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr);
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr, n);
     int grid = n < h->pslots ? n : h->pslots;
     hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)(((h->Lp / 2 + 1) + 8) / 16 + 2) * 4, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,

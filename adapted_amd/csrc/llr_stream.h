@@ -19,6 +19,7 @@
 #pragma once
 #include "common.h"
 #include "log_cr.h"
+#include "wave_stats.h"
 
 __device__ const double g_logcr_table[3 * LOGCR_N] = LOGCR_TABLE;
 
@@ -174,24 +175,28 @@ static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, doubl
 #ifndef GAINS_EU
 #define GAINS_EU 4
 #endif
-#ifndef GAINS_WPS
-#define GAINS_WPS 1
+#ifndef GAINS_WPB
+#define GAINS_WPB 4 // waves (reads) per block
 #endif
 template <int PASS>
-__global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
+__global__ void __launch_bounds__(64 * GAINS_WPB) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
                                               const double2 *__restrict__ ck, const double2 *__restrict__ tail,
                                               const int32_t *__restrict__ adapter_idx, int mbsize,
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
                                               int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
-                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat)
+                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat, int n_reads)
 {
-    __shared__ double sg[64 * (CK + 1)];
+    // GAINS_WPB waves (reads) per block share log_cr's table; everything else is private to a wave, so the only
+    // block-wide barrier is the one after the table copy
+    __shared__ double sg_[GAINS_WPB][64 * (CK + 1)];
     __shared__ double lt_[3 * LOGCR_N]; // log_cr's table
-    const int r = blockIdx.x;
+    LDS double *sg = (LDS double *)sg_[threadIdx.x >> 6];
+    const int r = blockIdx.x * GAINS_WPB + (threadIdx.x >> 6);
     const int ln = lane_id();
-    for (int i = ln; i < 3 * LOGCR_N; i += 64) lt_[i] = g_logcr_table[i];
+    for (int i = threadIdx.x; i < 3 * LOGCR_N; i += 64 * GAINS_WPB) lt_[i] = g_logcr_table[i];
     __syncthreads();
+    if (r >= n_reads) return;
     const LDS double *lt = (const LDS double *)lt_;
     auto flog = [&](double v) { return log_cr_impl(v, lt, [](double u) { return log(u); }); };
     if (mbs[r / mbsize].status != ADP_MB_OK) return;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
     for (int tb = 0; tb < n; tb += TRACE_TILE) {
         // each lane walks CK = 16 consecutive pooled samples: four float4 loads (rows start 256-byte aligned and
         // are padded to Lp, so the loads stay inside the row; samples at or beyond n are not used)
-        __syncthreads();
+        ws_sync();
         const int i0 = tb + ln * CK;
         const float4 *s4 = reinterpret_cast<const float4 *>(s + (i0 < Lp ? i0 : 0));
         double a = 0.0, b = 0.0;
@@ -292,7 +297,7 @@ __global__ void __launch_bounds__(64, GAINS_WPS) k_gains(const float *__restrict
                 bmin[(size_t)r * nsum + blk] = mn;
             }
         }
-        __syncthreads();
+        ws_sync();
 #pragma unroll GAINS_SU
         for (int k = 0; k < CK; k++) {
             int e = k * 64 + ln;
