@@ -546,7 +546,7 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
     if (rc) return rc;
     hipStream_t st = h->stream;
     HIPCHK(hipMemcpyAsync(h->bounds.p, bounds, (size_t)n_reads * (1 + k) * 8,
-                          (flags & ADP_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+                          ((flags & ADP_IN_DEVICE) && !(flags & ADP_BOUNDS_HOST)) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->topk_none.p, (flags & ADP_TOPK_NONE) ? 1 : 0, (size_t)n_reads, st));
     rc = launch_validate(h, dsig, dlen, n_reads, m, k, n_reads, false);
     if (rc) return rc;

@@ -133,6 +133,95 @@ static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, f
     }
 }
 
+// Both recurrences for one read inside a wave (k_validate: candidates whose series k_mvs_series did not prepare).
+// The wave copies the slice into LDS chunk by chunk with coalesced loads (plus the window's worth of history the
+// sliding steps subtract); lane 0 then runs move_var and lane 1 move_mean over the chunk from LDS, so the chains
+// wait for memory once per chunk instead of once per few samples.  Same arithmetic as bn_move_var / bn_move_mean.
+#define MV_CHUNK 768
+#define MV_HIST (WS_STAGE_FLOATS - MV_CHUNK) // longest window this path serves
+static __device__ void wave_move_series(const float *x_, int n, int wv, int wm, bool do_var, bool do_mean, float *svar_, float *smean_,
+                                        LDS WaveScratch *ws)
+{
+    const GLB float *x = (const GLB float *)x_;
+    GLB float *svar = (GLB float *)svar_;
+    GLB float *smean = (GLB float *)smean_;
+    const int ln = lane_id();
+    LDS float *buf = ws->stage;
+    float amean = 0.f, assqdm = 0.f, asum = 0.f; // lane 0: variance state; lane 1: sum
+    int count = 0;
+    const float inv_v = (float)(1.0 / (double)wv), inv_m = (float)(1.0 / (double)wm);
+    for (int i0 = 0; i0 < n; i0 += MV_CHUNK) {
+        const int lo = i0 >= MV_HIST ? i0 - MV_HIST : 0; // buf[k] = x[lo + k]
+        const int hi = min(n, i0 + MV_CHUNK);
+        ws_sync();
+        for (int k = ln; k < hi - lo; k += 64) buf[k] = x[lo + k];
+        ws_sync();
+        if (ln == 0 && do_var) {
+            int i = i0;
+            for (; i >= wv && i + 8 <= hi; i += 8) { // sliding steps, eight at a time: the LDS reads go first
+                float an[8], ao[8], res[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { an[j] = buf[i + j - lo]; ao[j] = buf[i + j - wv - lo]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    float ai = an[j], aold = ao[j];
+                    float delta = ai - aold;
+                    aold -= amean;
+                    amean += delta * inv_v;
+                    ai -= amean;
+                    assqdm += (ai + aold) * delta;
+                    if (assqdm < 0) assqdm = 0;
+                    res[j] = assqdm * inv_v;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) svar[i + j - wv + 1] = res[j];
+            }
+            for (; i < hi; i++) {
+                float ai = buf[i - lo];
+                if (i < wv) {
+                    count++;
+                    float delta = ai - amean;
+                    amean += delta / (float)count;
+                    assqdm += delta * (ai - amean);
+                    if (i == wv - 1) { if (assqdm < 0) assqdm = 0; svar[0] = assqdm / (float)count; }
+                } else {
+                    float aold = buf[i - wv - lo];
+                    float delta = ai - aold;
+                    aold -= amean;
+                    amean += delta * inv_v;
+                    ai -= amean;
+                    assqdm += (ai + aold) * delta;
+                    if (assqdm < 0) assqdm = 0;
+                    svar[i - wv + 1] = assqdm * inv_v;
+                }
+            }
+        }
+        if (ln == 1 && do_mean) {
+            int i = i0;
+            for (; i >= wm && i + 8 <= hi; i += 8) {
+                float an[8], ao[8], res[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { an[j] = buf[i + j - lo]; ao[j] = buf[i + j - wm - lo]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { asum += an[j] - ao[j]; res[j] = asum * inv_m; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) smean[i + j - wm + 1] = res[j];
+            }
+            for (; i < hi; i++) {
+                float ai = buf[i - lo];
+                if (i < wm) {
+                    asum += ai;
+                    if (i == wm - 1) smean[0] = asum / (float)wm;
+                } else {
+                    asum += ai - buf[i - wm - lo];
+                    smean[i - wm + 1] = asum * inv_m;
+                }
+            }
+        }
+    }
+    ws_sync();
+}
+
 // calc_partition_stats -> (start, len, mean, std, med, mad)
 static __device__ void partition_stats(const float *sig, int S, long long start, long long end, RowW &rw, int c_start,
                                        int c_len, LDS WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
@@ -177,8 +266,12 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     __syncthreads();
     if (pre_mean) { scr_mean = const_cast<float *>(pre_mean); scr_var = const_cast<float *>(pre_var); }
     else {
-        if (lane_id() == 0 && wvar && !(g_ablate & 128)) bn_move_var(x, n, cfg.pA_var_window, scr_var);
-        if (lane_id() == 1 && wmean && !(g_ablate & 128)) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+        if (cfg.pA_var_window <= MV_HIST && cfg.pA_mean_window <= MV_HIST) {
+            wave_move_series(x, n, cfg.pA_var_window, cfg.pA_mean_window, wvar, wmean, scr_var, scr_mean, ws);
+        } else {
+            if (lane_id() == 0 && wvar) bn_move_var(x, n, cfg.pA_var_window, scr_var);
+            if (lane_id() == 1 && wmean) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+        }
         __threadfence_block();
     }
     __syncthreads();
@@ -219,7 +312,11 @@ __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sig
     have[r] = 0;
     const long long fl = full_len[r];
     const int S = (int)(fl < m ? fl : m);
-    const long long a_e = bounds[(size_t)r * (1 + kmax)], p_e = kmax > 0 ? bounds[(size_t)r * (1 + kmax) + 1] : 0;
+    // the recurrences are causal: the series of the candidate with the LARGEST poly(A) end holds those of the
+    // others (same start, the adapter end) as prefixes -- one series serves all candidates of the read
+    const long long a_e = bounds[(size_t)r * (1 + kmax)];
+    long long p_e = 0;
+    for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
     if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return;
     if ((long long)S < a_e + cfg.median_shift_window) return;
     const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
@@ -354,12 +451,31 @@ __global__ void __launch_bounds__(64, 4) k_validate(ValidateIn in, adp_cfg cfg, 
                 } else if (range_empty(cfg.pA_mean_range)) exc = ADP_F_EXC_PA_RANGE;
                 if (!exc && topk_none) exc = ADP_F_EXC_TOPK_NONE;
                 if (exc) { row_exception(row, exc); exception = true; }
+                long long p_series = 0; // the poly(A) end the precomputed series reach (k_mvs_series)
+                if (in.series && in.have_series[r])
+                    for (int c = 0; c < in.kmax; c++) { const long long pc = bd[1 + c]; if (pc == 0) break; if (pc > p_series) p_series = pc; }
+                // several candidates, no prepared series: run the recurrences ONCE up to the largest candidate (they are
+                // causal: every other candidate's series is a prefix) into this slot's scratch
+                const float *own_mean = nullptr, *own_var = nullptr;
+                if (p_series == 0 && !exception && in.kmax > 1 && bd[1] != 0 && bd[2] != 0 && cfg.pA_var_window <= MV_HIST &&
+                    cfg.pA_mean_window <= MV_HIST && cfg.pA_var_window >= 1 && cfg.pA_mean_window >= 1) {
+                    long long pmx = 0;
+                    for (int c = 0; c < in.kmax; c++) { const long long pc = bd[1 + c]; if (pc == 0) break; if (pc > pmx) pmx = pc; }
+                    const int a = (int)(a_e < S ? a_e : S), b = (int)(pmx < S ? pmx : S);
+                    if (a_e != 0 && pmx > a_e && b - a >= cfg.pA_var_window && b - a >= cfg.pA_mean_window) {
+                        wave_move_series(sig + a, b - a, cfg.pA_var_window, cfg.pA_mean_window, true, true, scr_var, scr_mean, ws);
+                        __threadfence_block();
+                        __syncthreads();
+                        own_mean = scr_mean; own_var = scr_var; p_series = pmx;
+                    }
+                }
                 for (int c = 0; !exception && c < in.kmax; c++) {
                     long long p_e = bd[1 + c];
                     if (p_e == 0) break;
-                    const bool pre = (c == 0) && in.series && in.have_series[r];
-                    const float *pm = pre ? in.series + (size_t)r * 2 * MVS_CAP : nullptr;
-                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pm ? pm + MVS_CAP : nullptr);
+                    const bool pre = p_series > 0 && p_e <= p_series;
+                    const float *pm = !pre ? nullptr : (own_mean ? own_mean : in.series + (size_t)r * 2 * MVS_CAP);
+                    const float *pv = !pre ? nullptr : (own_var ? own_var : in.series + (size_t)r * 2 * MVS_CAP + MVS_CAP);
+                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pv);
                     if (o.exc) { row_exception(row, o.exc); exception = true; break; }
                     rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
                     rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);

@@ -21,7 +21,7 @@ NCOL = 38
 MAX_CAND = 16
 MAX_OPEN_PORES = 16
 
-ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK, ADP_TOPK_NONE = 1, 2, 4, 8
+ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK, ADP_TOPK_NONE, ADP_BOUNDS_HOST = 1, 2, 4, 8, 16
 MB_OK, MB_MAD_ZERO, MB_EMPTY_TRACE = 0, 1, 2
 
 COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len", "adapter_mean",
@@ -325,17 +325,9 @@ class Engine:
         k = b.shape[1] - 1
         rows = np.zeros(n, dtype=ROW_DTYPE)
         if device_ptrs:
-            # bounds stay on the host: stage them through a device buffer
-            nb = self.dev_alloc(b.nbytes)
-            try:
-                self.h2d(nb, b)
-                self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, C.c_void_p(nb), int(k), flags,
-                                                             rows.ctypes.data_as(C.c_void_p)))
-            finally:
-                self.dev_free(nb)
-        else:
-            self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, b.ctypes.data_as(C.c_void_p), int(k),
-                                                         flags, rows.ctypes.data_as(C.c_void_p)))
+            flags |= ADP_BOUNDS_HOST  # the signals are resident, the candidate table comes from the host
+        self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, b.ctypes.data_as(C.c_void_p), int(k),
+                                                     flags, rows.ctypes.data_as(C.c_void_p)))
         del keep
         return rows
 

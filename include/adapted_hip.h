@@ -57,6 +57,7 @@ extern "C" {
 #define ADP_OUT_DEVICE 2           /* rows_out is a device pointer */
 #define ADP_WITH_START_PEAK 4      /* LLR path: also fill the start_peak_* columns (extension) */
 #define ADP_TOPK_NONE 8            /* adp_validate_candidates: polya_end_topk is None (k must be 1) */
+#define ADP_BOUNDS_HOST 16         /* adp_validate_candidates: `bounds` is host memory even though ADP_IN_DEVICE is set */
 
 /* SigProcConfig, flattened.  Ranges are [lo, hi] with -inf/+inf for "None". */
 typedef struct adp_cfg {

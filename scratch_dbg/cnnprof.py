@@ -1,0 +1,26 @@
+import sys, time, cProfile, pstats, io
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from adapted_amd import lib
+from adapted_amd.detect import cnn as cnn_mod
+from bench import make_spc
+for T in (16000, 200000):
+    spc = make_spc(T)
+    spc.llr_boundaries.llr_detect = False
+    spc.cnn_boundaries.cnn_detect = True
+    spc.update_primary_method()
+    m = spc.sig_preload_size
+    mb = 1000
+    model = cnn_mod.load_cnn_model(spc.cnn_boundaries.model_name, device=0)
+    eng = lib.Engine(spc, mb, m, device=0)
+    sig = torch.empty((mb, m), dtype=torch.float32, device="cuda")
+    ln = torch.full((mb,), m, dtype=torch.int32, device="cuda")
+    eng.synth_fill(sig.data_ptr(), ln.data_ptr(), mb, seed=1, first_read=0, decorate=True)
+    lens_host = np.full(mb, m, dtype=np.int32)
+    f = lambda: cnn_mod.detect_rows_device(eng, sig.data_ptr(), ln.data_ptr(), mb, lens_host, model, spc)
+    f(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); rows = f(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("T=%d: %.3f s per 1000 reads (%.0f reads/s), pass %.2f" % (T, dt, mb / dt, rows["success"].mean()))
+    pr = cProfile.Profile(); pr.enable(); f(); torch.cuda.synchronize(); pr.disable()
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(14); print(s.getvalue()[:3500])
+    eng.close()
