@@ -19,6 +19,7 @@ __device__ unsigned long long g_dbg[24] = {0};
 #include "peaks.h"
 #include "synth.h"
 #include "validate.h"
+#include "cnn_topk.h"
 #include "wave_stats.h"
 
 static thread_local std::string g_err;
@@ -56,7 +57,7 @@ struct adp_handle {
     int max_reads = 0, m = 0;
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
-    DevBuf mbs, ghist, gbelow, gcnt, cbuf, fz, fcnt, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf mbs, ghist, gbelow, gcnt, cbuf, fz, fcnt, ct_pk, ct_pv, ct_out, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
     DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
@@ -158,7 +159,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -552,6 +553,33 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
     if (rc) return rc;
     rc = deliver_rows(h, n_reads, flags, rows_out);
     if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_pos_dev, const int64_t *polya_pos_dev,
+                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out, int32_t *flag_out)
+{
+    if (!h || !scores_dev || !adapter_pos_dev || !polya_pos_dev || !cand_out || !n_peaks_out || !flag_out || n_reads < 1 || Lo < 3 ||
+        k < 1 || k > ADP_MAX_CAND) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (Lo >= (1 << 27)) { g_err = "Lo too large"; return ADP_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const size_t half = (size_t)Lo / 2 + 1;
+    const size_t lds = (((half + 4) + 15) / 16 + 2) * 4;
+    if (lds > 60000) { g_err = "Lo too large for the LDS state of k_cnn_topk"; return ADP_ERR_UNSUPPORTED; }
+    if (h->ct_pk.ensure((size_t)n_reads * 2 * half * 4) || h->ct_pv.ensure((size_t)n_reads * half * 4) ||
+        h->ct_out.ensure(((size_t)n_reads * (k + 1) + 1) * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    int32_t *dcand = h->ct_out.as<int32_t>(), *dcnt = dcand + (size_t)n_reads * k, *dflag = dcnt + n_reads;
+    hipStream_t st = h->stream;
+    HIPCHK(hipMemsetAsync(dflag, 0, 4, st));
+    { Scope s(h, "k_cnn_topk");
+      hipLaunchKernelGGL(k_cnn_topk, dim3(n_reads), dim3(64), lds, st, scores_dev, (const long long *)adapter_pos_dev,
+                         (const long long *)polya_pos_dev, n_reads, Lo, k, h->ct_pk.as<int32_t>(), h->ct_pv.as<float>(), dcand, dcnt, dflag); }
+    HIPCHK(hipMemcpyAsync(cand_out, dcand, (size_t)n_reads * k * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(n_peaks_out, dcnt, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(flag_out, dflag, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return ADP_OK;

@@ -125,7 +125,10 @@ def _topk_candidates(ch1: np.ndarray, k: int) -> np.ndarray:
     return out
 
 
-def cnn_predict(batch_of_prepared_signals, model, params, core_params) -> np.ndarray:
+def cnn_predict(batch_of_prepared_signals, model, params, core_params, engine=None) -> np.ndarray:
+    """engine: with a HIP engine at hand the top-k candidate extraction runs on the device (adp_cnn_topk); batches
+    holding a case only scipy's formulation settles (exact ties, plateaus: the kernel reports them) take the host
+    formulation below, which is the reference's own."""
     torch = _torch()
     scores = cnn_score(batch_of_prepared_signals, model)
     n, _, Lo = scores.shape
@@ -141,6 +144,17 @@ def cnn_predict(batch_of_prepared_signals, model, params, core_params) -> np.nda
         polya_pos = torch.zeros(n, dtype=torch.int64, device=scores.device)
     a = adapter_pos.cpu().numpy().astype(np.int64)
     if k > 1:
+        if engine is not None and scores.is_cuda and scores.is_contiguous():
+            torch.cuda.current_stream(scores.device).synchronize()  # the engine works on its own stream
+            apos = adapter_pos.to(torch.int64).contiguous()
+            ppos = polya_pos.to(torch.int64).contiguous()
+            cand, cnt, flag = engine.cnn_topk(scores.data_ptr(), apos.data_ptr(), ppos.data_ptr(), n, Lo, k)
+            if flag == 0:
+                # the reference writes the group of the i-th read THAT HAS PEAKS into row i (cnn.py:150-158)
+                topk = np.zeros((n, k), dtype=np.int64)
+                nz = np.flatnonzero(cnt > 0)
+                topk[: nz.size] = cand[nz]
+                return np.column_stack((a[:, None], topk))
         ch1 = torch.where(pos > polya_pos[:, None], torch.full_like(ch1, SCORE_EXCL), ch1)
         topk = _topk_candidates(ch1.cpu().numpy(), k)
         return np.column_stack((a[:, None], topk))
@@ -150,7 +164,7 @@ def cnn_predict(batch_of_prepared_signals, model, params, core_params) -> np.nda
 def cnn_detect(batch_of_signals: np.ndarray, model, params, core_params, spc=None, engine=None) -> np.ndarray:
     prepared = prepare_data(batch_of_signals, core_params, spc=spc, engine=engine)
     prepared = prepared.to(_model_device(model))
-    preds = (cnn_predict(prepared, model, params, core_params) * core_params.downscale_factor
+    preds = (cnn_predict(prepared, model, params, core_params, engine=engine) * core_params.downscale_factor
              + core_params.min_obs_adapter).astype(int)
     preds[preds == core_params.min_obs_adapter] = 0  # where the prediction was zero, set back to zero
     return preds
@@ -170,7 +184,7 @@ def detect_rows_device(eng, dsig: int, dlen: int, n: int, lens_host: np.ndarray,
     Lc = (m - core.min_obs_adapter + core.downscale_factor - 1) // core.downscale_factor
     x = torch.empty((n, 1, Lc), dtype=torch.float32, device=torch.device("cuda", eng.device))
     eng.cnn_prepare(dsig, n, x.data_ptr(), device_ptrs=True)
-    preds = (cnn_predict(x.to(_model_device(model)), model, spc.cnn_boundaries, core) * core.downscale_factor
+    preds = (cnn_predict(x.to(_model_device(model)), model, spc.cnn_boundaries, core, engine=eng) * core.downscale_factor
              + core.min_obs_adapter).astype(int)
     preds[preds == core.min_obs_adapter] = 0
     bounds = np.ascontiguousarray(preds, dtype=np.int64)

@@ -116,7 +116,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_destroy", "adp_set_config", "adp_stream", "adp_synchronize", "adp_detect_llr", "adp_detect_start_peak",
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
-           "adp_debug_llr_upto", "adp_debug_log"]
+           "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk"]
 
 
 def _rng(r):
@@ -330,6 +330,16 @@ class Engine:
                                                      flags, rows.ctypes.data_as(C.c_void_p)))
         del keep
         return rows
+
+    def cnn_topk(self, scores_ptr: int, adapter_pos_ptr: int, polya_pos_ptr: int, n: int, Lo: int, k: int):
+        """C3 on the device: (cand int32 [n, k], n_peaks int32 [n], flag).  All three inputs are device pointers."""
+        cand = np.zeros((n, k), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        flag = np.zeros(1, dtype=np.int32)
+        self._check(self.lib.adp_cnn_topk(self._h, C.c_void_p(int(scores_ptr)), C.c_void_p(int(adapter_pos_ptr)),
+                                          C.c_void_p(int(polya_pos_ptr)), int(n), int(Lo), int(k), cand.ctypes.data_as(C.c_void_p),
+                                          cnt.ctypes.data_as(C.c_void_p), flag.ctypes.data_as(C.c_void_p)))
+        return cand, cnt, int(flag[0])
 
     def cnn_prepare(self, signals, n: int, out_dev_ptr: int, device_ptrs: bool = False):
         """C1 into a device buffer float32 [n, Lc] (e.g. a torch tensor's data_ptr)."""

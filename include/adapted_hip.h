@@ -162,6 +162,14 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
 /* CNN head, device-side pre/post-processing around the PyTorch conv stack.
  * prepared_out: float32 [n_reads, Lc] with Lc = ceil((m - min_obs_adapter)/downscale_factor). */
 int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out);
+/* C3, the k > 1 part of cnn_predict (adapted/detect/cnn.py:136-160): per read the k best poly(A) candidates among the
+ * distance-5 peaks of the masked channel-1 scores.  scores: DEVICE float32 [n, 2, Lo] (the conv net's output);
+ * adapter_pos / polya_pos: DEVICE int64 [n] (the two arg-maxes cnn_predict takes first).  Host outputs:
+ * cand int32 [n, k] (positions, zero padded), n_peaks int32 [n] (peaks of the read after the distance rule),
+ * *flag != 0 when the batch contains a case only the reference's scipy formulation settles (exact ties,
+ * plateaus, reads meeting across the row boundary of the flattened array): the caller then runs that. */
+int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_pos_dev, const int64_t *polya_pos_dev,
+                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out, int32_t *flag_out);
 /* Validate with explicit primary boundaries: bounds int64 [n_reads, 1 + k] = adapter_end, k poly(A)
  * candidates (0 terminates), exactly what cnn_detect_boundaries hands to validate_boundaries. */
 int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,

@@ -62,3 +62,85 @@ def test_cnn_single_read_returns_bare_result(setup):
     s = setup
     r = combined_detect_cnn(s["sig"][:1], s["lens"][:1], s["model"], s["spc"])
     assert isinstance(r, DetectResults)
+
+
+def _host_topk(scores, apos, ppos, k):
+    """the reference's formulation of C3 (adapted_amd.detect.cnn._topk_candidates) on explicit arg-max positions"""
+    from adapted_amd.detect import cnn as cnn_mod
+
+    n, _, Lo = scores.shape
+    pos = np.arange(Lo)[None, :]
+    ch1 = scores[:, 1, :].copy()
+    ch1[(pos < apos[:, None]) | (pos > ppos[:, None])] = cnn_mod.SCORE_EXCL
+    return cnn_mod._topk_candidates(ch1, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lo,n", [(257, 40), (1650, 64), (20050, 12)])
+def test_device_topk_equals_scipy_formulation(Lo, n):
+    """adp_cnn_topk (k_cnn_topk) against the host numpy/scipy formulation of cnn_predict's top-k on random scores,
+    including reads without any peak (the row-misalignment quirk) and reads whose stretch touches the row ends."""
+    import torch
+    from adapted_amd import lib
+    from util import make_spc
+    from golden_cases import CASES
+
+    spc = make_spc(CASES["rna004_cnn_default"])
+    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+    rng = np.random.default_rng(Lo)
+    k = 10
+    scores = rng.normal(0.0, 2.0, (n, 2, Lo)).astype(np.float32)
+    apos = rng.integers(1, Lo // 3, n).astype(np.int64)
+    apos[1] = 0                             # no masked prefix
+    scores[5:9, 1, :] -= 8.0                # most scores below the mask level (-5)
+    scores[9, 1, :] = -9.0 - rng.random(Lo).astype(np.float32)  # ALL below it: the arg-max is a masked sample, nothing
+    scores[2, 1, Lo - 1] = 50.0             # is unmasked, a read without peaks (rows shift up, cnn.py:150-158); arg-max at the row end
+    pos = np.arange(Lo)[None, :]
+    # polya_pos as cnn_predict takes it: the (first) arg-max of the scores masked before the adapter position
+    ppos = np.argmax(np.where(pos < apos[:, None], np.float32(-5.0), scores[:, 1, :]), axis=1).astype(np.int64)
+    assert ppos[9] < apos[9] and ppos[2] == Lo - 1
+    dsc = torch.from_numpy(scores).cuda()
+    da, dp = torch.from_numpy(apos).cuda(), torch.from_numpy(ppos).cuda()
+    torch.cuda.synchronize()
+    cand, cnt, flag = eng.cnn_topk(dsc.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
+    assert flag == 0
+    got = np.zeros((n, k), dtype=np.int64)
+    nz = np.flatnonzero(cnt > 0)
+    got[: nz.size] = cand[nz]
+    want = _host_topk(scores, apos, ppos, k)
+    assert (got == want).all(), np.argwhere(got != want)[:5]
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plateau", "tie", "below_mask", "boundary", "empty"])
+def test_device_topk_reports_what_only_scipy_settles(kind):
+    import torch
+    from adapted_amd import lib
+    from util import make_spc
+    from golden_cases import CASES
+
+    spc = make_spc(CASES["rna004_cnn_default"])
+    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+    n, Lo, k = 6, 300, 10
+    rng = np.random.default_rng(3)
+    scores = rng.normal(0.0, 2.0, (n, 2, Lo)).astype(np.float32)
+    apos = np.full(n, 20, dtype=np.int64); ppos = np.full(n, 250, dtype=np.int64)
+    scores[:, 1, 20] = 1.0
+    scores[:, 1, 250] = 30.0  # the arg-max of every read
+    if kind == "plateau":
+        scores[2, 1, 100] = scores[2, 1, 101] = 9.0
+    elif kind == "tie":
+        scores[2, 1, 100] = 9.0; scores[2, 1, 101] = 0.0; scores[2, 1, 102] = 9.0; scores[2, 1, 99] = 0.0; scores[2, 1, 103] = 0.0
+    elif kind == "below_mask":
+        apos[2] = 0; scores[2, 1, :] = -6.0 - rng.random(Lo).astype(np.float32); ppos[2] = int(np.argmax(scores[2, 1, :]))
+    elif kind == "boundary":
+        scores[2, 1, Lo - 2] = 40.0; ppos[2] = Lo - 2; apos[3] = 1
+    elif kind == "empty":
+        scores[2, 1, 250] = -5.0; scores[2, 1, 20:250] = -7.0  # the maximum equals the mask level: a plateau with the mask
+    dsc = torch.from_numpy(scores).cuda()
+    da, dp = torch.from_numpy(apos).cuda(), torch.from_numpy(ppos).cuda()
+    torch.cuda.synchronize()
+    _, _, flag = eng.cnn_topk(dsc.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
+    assert flag != 0, kind
+    eng.close()
