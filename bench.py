@@ -104,14 +104,20 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
     dist = None
+    # ADP_BENCH_BACKEND=gloo rehearses the N > 1 code path on fewer GPUs than ranks (ranks share devices, the row gather
+    # goes through host memory); the real multi-GPU run uses RCCL ("nccl"), one GPU per rank
+    backend = os.environ.get("ADP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from adapted_amd import lib
 
@@ -141,7 +147,7 @@ def main():
                      first_read=rank * R + k * Rs, decorate=True)
     gathered = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(rows_t) for _ in range(world)]
+        gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
 
     import threading
 
@@ -168,7 +174,7 @@ def main():
             for t in ths:
                 t.join()
         if world > 1:
-            dist.gather(rows_t, gathered, dst=0)
+            dist.gather(rows_t if backend == "nccl" else rows_t.cpu(), gathered, dst=0)
 
     def sync():
         if world > 1:
@@ -192,7 +198,7 @@ def main():
     for e in engines:
         e.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_reads = R * world * args.steps
