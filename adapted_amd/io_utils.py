@@ -62,20 +62,31 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
 
 
 def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                      preload_size: int) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
+                      preload_size: int, buffers=None) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
+    """buffers: optional callable returning (signals float32 [batch_size, preload_size], lengths int32 [batch_size]) to
+    fill IN PLACE for the next minibatch (pinned staging memory of adapted_amd.pipeline); called when the first read of
+    a minibatch arrives, never while the previous minibatch's arrays may still be in use by the consumer of the yield."""
     if read_ids_incl and read_ids_excl:
         read_ids_incl = read_ids_incl.difference(read_ids_excl)
         read_ids_excl = set()
     selection = list(read_ids_incl) if read_ids_incl else None
     N, m = batch_size, preload_size
-    sig = np.empty((N, m), dtype=np.float32)
-    lens = np.empty(N, dtype=np.int32)
-    ids = np.empty(N, dtype=object)
+
+    def fresh():
+        if buffers is not None:
+            sig, lens = buffers()
+            assert sig.shape == (N, m) and sig.dtype == np.float32 and lens.shape == (N,) and lens.dtype == np.int32
+            return sig, lens, np.empty(N, dtype=object)
+        return np.empty((N, m), dtype=np.float32), np.empty(N, dtype=np.int32), np.empty(N, dtype=object)
+
+    sig = lens = ids = None
     k = 0
     for fn in files:
         for rid, n_samples, signal in _iter_reads(fn, selection):
             if rid in read_ids_excl:
                 continue
+            if sig is None:
+                sig, lens, ids = fresh()
             s = np.asarray(signal[:m], dtype=np.float32)
             take = min(m, n_samples, s.size)
             sig[k, :take] = s[:take]
@@ -86,9 +97,7 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
             k += 1
             if k == N:
                 yield sig, lens, ids
-                sig = np.empty((N, m), dtype=np.float32)
-                lens = np.empty(N, dtype=np.int32)
-                ids = np.empty(N, dtype=object)
+                sig = None
                 k = 0
     if k:
         yield sig[:k], lens[:k], ids[:k]

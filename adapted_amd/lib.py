@@ -119,6 +119,14 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk"]
 
 
+class MinibatchDropped(RuntimeError):
+    """batch-level failure of one minibatch (the reference drops it and logs): status = ADP_MB_*"""
+
+    def __init__(self, status: int):
+        super().__init__("minibatch dropped (status %d)" % status)
+        self.status = status
+
+
 def _rng(r):
     lo = -np.inf if r is None or r[0] is None else float(r[0])
     hi = np.inf if r is None or r[1] is None else float(r[1])

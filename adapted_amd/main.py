@@ -118,29 +118,29 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
 
         model = _cnn.load_cnn_model(spc.cnn_boundaries.model_name)
     m = spc.sig_preload_size
-    eng = lib.Engine(spc, minibatch, m, device=device)
     writer = _Writer(run_dir, batch_out, bidx_pass, bidx_fail) if rank == 0 else None
     t0 = time.time()
-    n_total = 0
     my_rows, my_ids = [], []
-    for i, (sig, lens, ids) in enumerate(yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch, m)):
-        if ws > 1 and i % ws != rank:
-            continue  # round-robin whole minibatches (the stream length is unknown up front)
-        n = sig.shape[0]
-        try:
-            if primary == "llr":
-                rows, mbs = eng.detect_llr_rows(sig, lens, n, n, with_start_peak=start_peak)
-                if mbs[0] != lib.MB_OK:
-                    logging.error("minibatch %d dropped: %s", i, {1: "MAD normalization failed: scale is 0",
-                                                                  2: "a read has no signal after min_obs_adapter"}[int(mbs[0])])
-                    continue
-            elif primary == "start_peak":
-                rows = eng.detect_start_peak_rows(sig, lens, n, n)
-            else:
-                rows = _cnn.detect_rows(eng, sig, lens, model, spc)
-        except lib.HipLibraryError:
-            raise
-        n_total += n
+    dropped_text = {1: "MAD normalization failed: scale is 0", 2: "a read has no signal after min_obs_adapter"}
+    from .pipeline import HostPipeline
+
+    # pinned staging slots filled in place by a producer thread, H2D overlapped with the detect call, CSV writing in
+    # a third thread (adapted_amd/pipeline.py); ranks take whole minibatches round-robin
+    pipe = HostPipeline(spc, minibatch, m, device=device, primary=primary, with_start_peak=start_peak,
+                        model=model if primary == "cnn" else None)
+
+    def fill(get_buffers):
+        it = yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch, m, buffers=get_buffers if ws == 1 else None)
+        for i, (sig, lens, ids) in enumerate(it):
+            if ws > 1:
+                if i % ws != rank:
+                    continue  # (the stream length is unknown up front)
+                bs, bl = get_buffers()
+                bs[: sig.shape[0]] = sig
+                bl[: sig.shape[0]] = lens
+            yield sig.shape[0], ids.copy()
+
+    def on_rows(ids, rows):
         if ws > 1:
             my_rows.append(rows)
             my_ids.extend(ids.tolist())
@@ -148,6 +148,14 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
             res = lib.rows_to_results(rows, primary)
             writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
                         for rid, r in zip(ids, res)])
+
+    def on_dropped(ids, status):
+        logging.error("minibatch of %d reads dropped: %s", len(ids), dropped_text.get(status, status))
+
+    try:
+        pipe.run(fill, on_rows, on_dropped)
+    finally:
+        pipe.close()
     if ws > 1:
         import torch.distributed as dist
 
@@ -167,7 +175,6 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
                      tot / max(time.time() - t0, 1e-9), ws)
         if tot:
             logging.info("Pass: %d (%.2f%%), fail: %d", writer.n[True], 100.0 * writer.n[True] / tot, writer.n[False])
-    eng.close()
 
 
 def main(argv=None):

@@ -1,0 +1,146 @@
+"""Host-side streaming pipeline for `adapted detect`.
+
+The reference moves minibatches between processes through pickling Manager queues
+(adapted/file_proc.py:612-823); at MI355X speeds the detect step takes ~1.5 ms per 1000 reads, so the
+host side is all that is left: assembling the float32 [N, m] minibatch and getting it across PCIe
+(806 KB per read at the 200 k window -> about 78 k reads/s per GPU at 63 GB/s).  This module keeps that
+path busy and nothing else in the way:
+
+  producer thread   fills pinned (page-locked) staging slots in place -- no intermediate copy -- from any
+                    iterator of (signals, lengths, ids) writers (io_utils.yield_minibatches(buffers=...));
+  transfer/compute  (caller's thread) per slot: one asynchronous H2D copy on a copy stream, the detect call
+                    on device pointers, the 528-byte result rows back; the H2D of slot k+1 is started
+                    BEFORE the detect call of slot k, so copies and kernels overlap;
+  consumer          `on_rows(ids, rows)` (CSV writer) runs in a third thread.
+
+PyTorch provides the pinned memory, the device buffers and the copy stream (plumbing); the compute is the
+HIP library's.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Callable, Iterable, Optional, Tuple
+
+import numpy as np
+
+from . import lib
+
+
+class HostPipeline:
+    def __init__(self, spc, minibatch: int, m: int, device: int = 0, n_slots: int = 3, primary: str = "llr",
+                 with_start_peak: bool = False, model=None):
+        import torch
+
+        self.torch = torch
+        self.spc, self.N, self.m, self.device = spc, int(minibatch), int(m), int(device)
+        self.primary, self.with_start_peak, self.model = primary, with_start_peak, model
+        self.dev = torch.device("cuda", self.device)
+        torch.cuda.set_device(self.device)
+        self.eng = lib.Engine(spc, self.N, self.m, device=self.device)
+        self.copy_stream = torch.cuda.Stream(device=self.dev)
+        self.slots = []
+        for _ in range(max(2, n_slots)):
+            hs = torch.empty((self.N, self.m), dtype=torch.float32, pin_memory=True)
+            hl = torch.empty((self.N,), dtype=torch.int32, pin_memory=True)
+            ds = torch.empty((self.N, self.m), dtype=torch.float32, device=self.dev)
+            dl = torch.empty((self.N,), dtype=torch.int32, device=self.dev)
+            self.slots.append({"hs": hs, "hl": hl, "ds": ds, "dl": dl, "sig": hs.numpy(), "lens": hl.numpy(),
+                               "ev": torch.cuda.Event()})
+        self.free: "queue.Queue[int]" = queue.Queue()
+        for i in range(len(self.slots)):
+            self.free.put(i)
+
+    def close(self):
+        self.eng.close()
+
+    # -- stages -------------------------------------------------------------------------------
+    def _start_h2d(self, j: int, n: int):
+        torch = self.torch
+        s = self.slots[j]
+        with torch.cuda.stream(self.copy_stream):
+            s["ds"][:n].copy_(s["hs"][:n], non_blocking=True)
+            s["dl"][:n].copy_(s["hl"][:n], non_blocking=True)
+            s["ev"].record(self.copy_stream)
+
+    def _detect(self, j: int, n: int) -> np.ndarray:
+        s = self.slots[j]
+        s["ev"].synchronize()  # the engine works on its own stream: wait for the copy on the host
+        dsig, dlen = s["ds"].data_ptr(), s["dl"].data_ptr()
+        if self.primary == "llr":
+            rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, n, with_start_peak=self.with_start_peak, device_ptrs=True)
+            if mbs[0] != lib.MB_OK:
+                raise lib.MinibatchDropped(int(mbs[0]))
+            return rows
+        if self.primary == "start_peak":
+            return self.eng.detect_start_peak_rows(dsig, dlen, n, n, device_ptrs=True)
+        from .detect import cnn as _cnn
+
+        return _cnn.detect_rows_device(self.eng, dsig, dlen, n, s["lens"][:n], self.model, self.spc)
+
+    # -- driver -------------------------------------------------------------------------------
+    def run(self, fill: Callable[[Callable[[], Tuple[np.ndarray, np.ndarray]]], Iterable[Tuple[int, object]]],
+            on_rows: Callable[[object, np.ndarray], None], on_dropped: Optional[Callable[[object, int], None]] = None) -> int:
+        """fill(get_buffers) -> iterator of (n, ids): every item announces that the buffers handed out by the LAST
+        get_buffers() call now hold n reads.  Returns the number of reads processed."""
+        filled: "queue.Queue" = queue.Queue(maxsize=len(self.slots))
+        done: "queue.Queue" = queue.Queue(maxsize=4 * len(self.slots))
+        err = []
+        cur = {"j": None}
+
+        def get_buffers():
+            j = self.free.get()
+            cur["j"] = j
+            return self.slots[j]["sig"], self.slots[j]["lens"]
+
+        def producer():
+            try:
+                for n, ids in fill(get_buffers):
+                    filled.put((cur["j"], int(n), ids))
+            except BaseException as e:  # noqa: BLE001 -- handed to the caller's thread
+                err.append(e)
+            finally:
+                filled.put(None)
+
+        def consumer():
+            while True:
+                item = done.get()
+                if item is None:
+                    return
+                try:
+                    on_rows(*item)
+                except BaseException as e:  # noqa: BLE001
+                    err.append(e)
+
+        tp = threading.Thread(target=producer, daemon=True)
+        tc = threading.Thread(target=consumer, daemon=True)
+        tp.start()
+        tc.start()
+        total = 0
+        pending = None  # slot whose H2D is in flight
+        try:
+            while True:
+                item = filled.get()
+                if item is not None:
+                    self._start_h2d(item[0], item[1])
+                if pending is not None:
+                    j, n, ids = pending
+                    try:
+                        rows = self._detect(j, n)
+                        done.put((ids, rows))
+                        total += n
+                    except lib.MinibatchDropped as e:
+                        if on_dropped:
+                            on_dropped(ids, e.status)
+                    self.free.put(j)
+                pending = item
+                if item is None:
+                    break
+                if err:
+                    break
+        finally:
+            done.put(None)
+            tc.join()
+        if err:
+            raise err[0]
+        return total

@@ -208,3 +208,35 @@ def test_row_gather_two_ranks_gloo(tmp_path):
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK 7300" in r.stdout
+
+
+def test_minibatches_fill_caller_buffers_in_place(tmp_path):
+    """io_utils.yield_minibatches(buffers=...) writes into the arrays the caller hands out (the pipeline's pinned staging
+    slots) and asks for the next pair only when the next minibatch starts."""
+    from adapted_amd import io_utils
+
+    rng = np.random.default_rng(0)
+    n, m = 7, 50
+    lens = np.array([60, 50, 20, 55, 10, 70, 50], dtype=np.int32)
+    sigs = np.full((n, 80), np.nan, dtype=np.float32)
+    for i, L in enumerate(lens):
+        sigs[i, :L] = rng.normal(90, 10, L)
+    f = tmp_path / "a.npz"
+    np.savez(f, signals=sigs, full_lengths=lens, read_ids=np.array(["r%d" % i for i in range(n)]))
+    handed = []
+
+    def buffers():
+        pair = (np.zeros((3, m), dtype=np.float32), np.zeros(3, dtype=np.int32))
+        handed.append(pair)
+        return pair
+
+    plain = list(io_utils.yield_minibatches([str(f)], set(), set(), 3, m))
+    seen = 0
+    for k, (sig, ln, ids) in enumerate(io_utils.yield_minibatches([str(f)], set(), set(), 3, m, buffers=buffers)):
+        assert len(handed) == k + 1                      # one pair per minibatch, handed out lazily
+        assert np.shares_memory(sig, handed[k][0]) and np.shares_memory(ln, handed[k][1])
+        np.testing.assert_array_equal(sig, plain[k][0])
+        np.testing.assert_array_equal(ln, plain[k][1])
+        assert list(ids) == list(plain[k][2])
+        seen += sig.shape[0]
+    assert seen == n and len(handed) == 3
