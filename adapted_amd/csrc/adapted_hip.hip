@@ -53,6 +53,8 @@ struct ProfEntry { const char *name; hipEvent_t a, b; };
 struct adp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // side stream: the start-peak scan (HBM-bound) beside the float64 gains (ALU-bound)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     adp_cfg cfg;
     int max_reads = 0, m = 0;
     // geometry of the LLR path
@@ -147,7 +149,9 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
     h->m = m;
     int rc = geom(h);
     if (rc) { delete h; return rc; }
-    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
     rc = alloc_all(h);
     if (rc) { adp_destroy(h); return rc; }
     *out = h;
@@ -164,6 +168,9 @@ int adp_destroy(adp_handle *h)
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ADP_OK;
@@ -210,16 +217,16 @@ static hipEvent_t next_event(adp_handle *h)
     return h->ev_pool[h->ev_used++];
 }
 struct Scope {
-    adp_handle *h; hipEvent_t b = nullptr;
-    Scope(adp_handle *h_, const char *name) : h(h_)
+    adp_handle *h; hipEvent_t b = nullptr; hipStream_t st;
+    Scope(adp_handle *h_, const char *name, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream)
     {
         if (!h->profiling || !name) return;
         hipEvent_t a = next_event(h);
         b = next_event(h);
-        (void)hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, st);
         h->prof.push_back({name, a, b});
     }
-    ~Scope() { if (b) (void)hipEventRecord(b, h->stream); }
+    ~Scope() { if (b) (void)hipEventRecord(b, st); }
 };
 
 // ---- input staging -----------------------------------------------------------------
@@ -392,6 +399,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 8, st));
     HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n_mb * 8 * N1_NCNT, st));
     const int T = h->T;
+    bool sp_forked = false;
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
@@ -405,6 +413,16 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         }
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);
+        if (upto >= 8 && (flags & ADP_WITH_START_PEAK)) {
+            // the start-peak scan depends on nothing computed here: it streams the signal on the side stream while the
+            // main stream runs the ALU-bound cumulative sums and gains
+            HIPCHK(hipEventRecord(h->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+            { Scope s(h, "k_start_peak", h->stream2);
+              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, h->stream2, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+            HIPCHK(hipEventRecord(h->ev_join, h->stream2));
+            sp_forked = true;
+        }
         if (upto >= 3) {
             Scope s(h, "k_cumsum");
             hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
@@ -444,8 +462,11 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         rc = launch_validate(h, dsig, dlen, n, m, 1, minibatch, true);
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
-            { Scope s(h, "k_start_peak");
-              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+            if (sp_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
+            else {
+                Scope s(h, "k_start_peak");
+                hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>());
+            }
             hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
                                (const int32_t *)nullptr);
         }
