@@ -104,3 +104,37 @@ def test_full_size_properties_and_sampled_oracle(oracle_mod):
     eng.dev_free(dsig)
     eng.dev_free(dlen)
     eng.close()
+
+
+def test_full_size_permutation_and_composition_properties():
+    """Size-independent properties at the north-star shape (no oracle involved):
+    (1) N1 is a statistic of the minibatch as a SET: permuting the reads of a minibatch permutes the rows and nothing else;
+    (2) a read's row depends on the other reads only through its minibatch: replacing ANOTHER minibatch's reads leaves it alone;
+    (3) idempotence: the same call twice gives the same bytes (no state leaks between calls through the handle)."""
+    from adapted_amd import lib
+
+    spc = _spc200k()
+    m = spc.sig_preload_size
+    mb, n = 1000, 2000
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+    eng.h2d(dlen, np.full(n, m, dtype=np.int32))
+    eng.synth_fill(dsig, dlen, n, seed=21, first_read=100)
+    rows, _ = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True, with_start_peak=True)
+    rows2, _ = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True, with_start_peak=True)
+    assert rows.tobytes() == rows2.tobytes()                                   # (3)
+    # (1) reverse the first minibatch on the device (row by row through a host bounce of one minibatch)
+    first = np.zeros((mb, m), dtype=np.float32)
+    eng.d2h(first, dsig)
+    eng.h2d(dsig, np.ascontiguousarray(first[::-1]))
+    rows_p, _ = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True, with_start_peak=True)
+    assert rows_p[:mb][::-1].tobytes() == rows[:mb].tobytes()
+    assert rows_p[mb:].tobytes() == rows[mb:].tobytes()                        # (2) the other minibatch did not notice
+    # (2) overwrite the first minibatch with different reads: the second minibatch's rows stay
+    eng.synth_fill(dsig, dlen, mb, seed=99, first_read=7)
+    rows_q, _ = eng.detect_llr_rows(dsig, dlen, n, mb, device_ptrs=True, with_start_peak=True)
+    assert rows_q[mb:].tobytes() == rows[mb:].tobytes()
+    assert rows_q[:mb].tobytes() != rows[:mb].tobytes()
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
