@@ -77,6 +77,7 @@ static int geom(adp_handle *h)
     }
     if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
     if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
+    if (h->m > BS_MAXCHUNK * 8192) { g_err = "preload longer than 1 Mi samples: k_partition_stats keeps one chunk sum per 8192 samples in LDS"; return ADP_ERR_UNSUPPORTED; }
     if ((c.max_obs_trace - c.min_obs_adapter) / c.downscale_factor > 400000) { g_err = "max_obs_trace too large for the LDS state of k_polya_peak"; return ADP_ERR_UNSUPPORTED; }
     h->T = c.max_obs_trace < h->m ? c.max_obs_trace : h->m;
     h->off = c.min_obs_adapter;

@@ -31,6 +31,7 @@
 #define BS_KSH 12         // key >> 12 = 20-bit bucket index
 #define BS_MEDCAP 1024    // samples of the median's bucket kept in LDS
 #define BS_MADCAP 4096    // samples of the MAD bracket kept in LDS (they reuse the histogram's storage)
+#define BS_MAXCHUNK 128   // whole 8192-sample chunks per segment (1 Mi samples); longer segments take the generic path
 #define BS_BINS18 2048    // fallback passes C/D: 18-bit buckets, collect capacity 2048
 
 // (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
@@ -48,7 +49,7 @@ struct BlockScratch {
     } u;
     uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
     float collect[BS_MEDCAP]; // samples of the median's bucket
-    float leafsum[64];
+    float chunk_sum[BS_MAXCHUNK]; // sums of the whole numpy chunks of the segment under way
     float tleaf[128]; // leaf sums of a ragged chunk, by tree slot
     int scan[8];
     int bin, before, ncollect, nmad, flag;
@@ -221,24 +222,33 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
     uint32_t aux = 0, aux2 = 0;
     float total = 0.0f; // meaningful in wave 0
     int s = 0;
-    // Each WAVE owns 8 consecutive leaves (1024 samples) of every half chunk: it stages, sums and folds them
-    // without block-wide barriers; the 8 wave partials of a chunk meet once per 8192 samples.
+    // Each WAVE owns whole numpy chunks (8192 samples; wave w takes chunks w, w+4, ...): it streams the chunk in eight
+    // slabs of 1024 samples (8 leaves), stages each slab in its own LDS rows, runs the 8 x 8 accumulator chains, folds
+    // them by shuffles and keeps the slab sums in lanes 0..7; a last butterfly over those lanes is the top of numpy's
+    // balanced tree.  No block-wide barrier inside the stream: the chunk sums meet once, in order, at the end.
     const int w = tid >> 6, ln = tid & 63;
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
-    int parity = 0;
-    const int nhalf = (n / 8192) * 2; // half chunks of 4096 samples inside whole numpy chunks
-    f4u v[4], vn[4];
-    if (nhalf > 0) {
-        const GLB f4u *p = reinterpret_cast<const GLB f4u *>(x + w * 1024);
+    const int nchunk = n / 8192;
+    const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
+    auto slab_ptr = [&](int q) { return reinterpret_cast<const GLB f4u *>(x + (size_t)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024); };
+    // software pipeline, two slabs deep: a wave keeps 8 KB of loads in flight
+    f4u v[4], vn[4], vnn[4];
+    if (myslabs > 0) {
+        const GLB f4u *p = slab_ptr(0);
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = p[u * 64 + ln];
     }
-    for (int hc = 0; hc < nhalf; hc++) {
-        const int half = hc & 1;
-        if (hc + 1 < nhalf) { // software pipeline: the next half chunk's loads fly while this one is summed
-            const GLB f4u *p = reinterpret_cast<const GLB f4u *>(x + (size_t)(hc + 1) * 4096 + w * 1024);
+    if (myslabs > 1) {
+        const GLB f4u *p = slab_ptr(1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = p[u * 64 + ln];
+        for (int u = 0; u < 4; u++) vn[u] = p[u * 64 + ln];
+    }
+    float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
+    for (int q = 0; q < myslabs; q++) {
+        if (q + 2 < myslabs) {
+            const GLB f4u *p = slab_ptr(q + 2);
+#pragma unroll
+            for (int u = 0; u < 4; u++) vnn[u] = p[u * 64 + ln];
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;
@@ -260,31 +270,31 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
                 bs_copy_exact(wstage[(e >> 7) * BS_LEAF_STRIDE + (e & 127)], param, bs);
             } while (flags);
         }
-        const LDS float *q = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
-        float r = bs_x2(q[0], mode, c);
+        const LDS float *qq = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
+        float r = bs_x2(qq[0], mode, c);
 #pragma unroll
-        for (int t = 1; t < 16; t++) r += bs_x2(q[8 * t], mode, c);
+        for (int t = 1; t < 16; t++) r += bs_x2(qq[8 * t], mode, c);
         r = r + __shfl_xor(r, 1);   // the 8 accumulators of a leaf
         r = r + __shfl_xor(r, 2);
         r = r + __shfl_xor(r, 4);
-        r = r + __shfl_xor(r, 8);   // the wave's 8 leaves: three levels of numpy's balanced tree
+        r = r + __shfl_xor(r, 8);   // the slab's 8 leaves: three levels of numpy's balanced tree
         r = r + __shfl_xor(r, 16);
         r = r + __shfl_xor(r, 32);
-        if (ln == 0) bs->leafsum[parity * 8 + half * 4 + w] = r;
-        if (half == 1) {
-            __syncthreads();
-            if (tid < 64) {
-                const LDS float *pp = bs->leafsum + parity * 8;
-                float h0 = (pp[0] + pp[1]) + (pp[2] + pp[3]);
-                float h1 = (pp[4] + pp[5]) + (pp[6] + pp[7]);
-                total += h0 + h1;
-            }
-            parity ^= 1;
+        if (ln == (q & 7)) slabsum = r;
+        if ((q & 7) == 7) { // chunk complete: the top three levels over its 8 slab sums (lanes 0..7)
+            float cs = slabsum;
+            cs = cs + __shfl_xor(cs, 1);
+            cs = cs + __shfl_xor(cs, 2);
+            cs = cs + __shfl_xor(cs, 4);
+            const int ch = w + 4 * (q >> 3);
+            if (ln == 0) bs->chunk_sum[ch & (BS_MAXCHUNK - 1)] = cs;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = vn[u];
+        for (int u = 0; u < 4; u++) { v[u] = vn[u]; vn[u] = vnn[u]; }
     }
-    s = (nhalf / 2) * 8192;
+    __syncthreads();
+    if (tid == 0) for (int ch = 0; ch < nchunk; ch++) total += bs->chunk_sum[ch]; // numpy adds the chunk sums in sequence
+    s = nchunk * 8192;
     __syncthreads();
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
