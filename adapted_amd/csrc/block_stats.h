@@ -236,19 +236,19 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
     if (myslabs > 0) {
         const GLB f4u *p = slab_ptr(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = p[u * 64 + ln];
+        for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
     }
     if (myslabs > 1) {
         const GLB f4u *p = slab_ptr(1);
 #pragma unroll
-        for (int u = 0; u < 4; u++) vn[u] = p[u * 64 + ln];
+        for (int u = 0; u < 4; u++) vn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
     }
     float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
     for (int q = 0; q < myslabs; q++) {
         if (q + 2 < myslabs) {
             const GLB f4u *p = slab_ptr(q + 2);
 #pragma unroll
-            for (int u = 0; u < 4; u++) vnn[u] = p[u * 64 + ln];
+            for (int u = 0; u < 4; u++) vnn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;

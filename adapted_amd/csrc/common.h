@@ -31,6 +31,15 @@ struct MbState {
     int32_t pad;
 };
 
+// streaming loads of samples that are not read again soon: the non-temporal hint (nt) keeps them from displacing
+// the caches' useful lines; measured +6 % on a pure streaming read (6.8 vs 6.4 TB/s)
+typedef float adp_v4f __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float4 ld_stream4(const float4 *p)
+{
+    const adp_v4f v = __builtin_nontemporal_load(reinterpret_cast<const adp_v4f *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // order-preserving float32 <-> uint32 key

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
             for (int q = threadIdx.x; q < tile_n / 4; q += 256) {
                 const int idx = base + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // np.pad(..., mode="constant") for a ragged tail
-                if (idx + 3 < Lseg) { v = row4[q]; v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
+                if (idx + 3 < Lseg) { v = ld_stream4(&row4[q]); v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
                 else {
                     if (idx < Lseg) v.x = norm1(row[idx]);
                     if (idx + 1 < Lseg) v.y = norm1(row[idx + 1]);

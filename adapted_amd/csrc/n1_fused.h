@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
             const float4 *row4 = reinterpret_cast<const float4 *>(row);
             int i = threadIdx.x;
             for (; i + N1_THREADS < T4; i += 2 * N1_THREADS) { // two loads in flight per lane
-                float4 v = row4[i], w = row4[i + N1_THREADS];
+                float4 v = ld_stream4(&row4[i]), w = ld_stream4(&row4[i + N1_THREADS]);
                 const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
                 uint32_t fl = 0;
 #pragma unroll
