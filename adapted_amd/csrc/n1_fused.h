@@ -22,8 +22,8 @@
 #pragma once
 #include "n1_select.h"
 
-#define N1F_LDS_M 2048            // per-block staging (floats) of the median bracket, flushed after every row
-#define N1F_LDS_B 6144            // ... of the MAD band
+#define N1F_LDS_M 768             // per-block staging (floats) of the median bracket, flushed after every quarter row
+#define N1F_LDS_B 2304            // ... of the MAD band
 #define N1F_MCAP (N1_CB_CAP / 4)  // copied samples kept per minibatch: median bracket ...
 #define N1F_BCAP (N1_CB_CAP - N1F_MCAP) // ... and MAD band (the two lists share the minibatch's slice of cbuf)
 #define N1F_BINS 32768            // finish: LDS counting histogram (128 KB)
@@ -122,33 +122,8 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
     float *dstm = cbuf + (size_t)mb * N1_CB_CAP;
     float *dstb = dstm + N1F_MCAP;
 #define ACC(xx) n1f_account(xx, med_s, A0, A1, D0, D1, a, cbm, cbb, cnt2)
-    for (int r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
-        const float *row = sig + (size_t)r * m;
-        if (vec) {
-            const int T4 = T >> 2;
-            const float4 *row4 = reinterpret_cast<const float4 *>(row);
-            int i = threadIdx.x;
-            for (; i + N1_THREADS < T4; i += 2 * N1_THREADS) { // two loads in flight per lane
-                float4 v = ld_stream4(&row4[i]), w = ld_stream4(&row4[i + N1_THREADS]);
-                const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
-                uint32_t fl = 0;
-#pragma unroll
-                for (int q = 0; q < 8; q++) fl |= n1f_count(e[q], med_s, A0, A1, D0, D1, a) << q;
-                while (fl) { // the few samples to copy: one at a time, picked out of the eight registers
-                    const int q = __ffs(fl) - 1;
-                    fl &= fl - 1;
-                    float x = e[0];
-#pragma unroll
-                    for (int z = 1; z < 8; z++) x = (q == z) ? e[z] : x;
-                    n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
-                }
-            }
-            for (; i < T4; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
-            for (int j = (T4 << 2) + threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
-        } else {
-            for (int j = threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
-        }
-        // hand the row's copied samples to the minibatch's lists: one global atomic per list, row and block
+    // hand the copied samples to the minibatch's lists: one global atomic per list, per block and per quarter row
+    auto flush = [&]() {
         __syncthreads();
         const uint32_t cm = cnt2_[0], cbn = cnt2_[1];
         if (threadIdx.x == 0) {
@@ -167,6 +142,40 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
         __syncthreads();
         if (threadIdx.x < 2) cnt2_[threadIdx.x] = 0;
         __syncthreads();
+    };
+    for (int r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
+        const float *row = sig + (size_t)r * m;
+        if (vec) {
+            const int T4 = T >> 2;
+            const float4 *row4 = reinterpret_cast<const float4 *>(row);
+            // the row in four quarters, the staging lists flushed after each: small lists leave LDS for 8 blocks per CU
+            const int q4 = ((T4 + 3) / 4 + 2 * N1_THREADS - 1) / (2 * N1_THREADS) * (2 * N1_THREADS);
+            for (int seg = 0; seg < T4; seg += q4) {
+                const int send = min(T4, seg + q4);
+                int i = seg + threadIdx.x;
+                for (; i + N1_THREADS < send; i += 2 * N1_THREADS) { // two loads in flight per lane
+                    float4 v = ld_stream4(&row4[i]), w = ld_stream4(&row4[i + N1_THREADS]);
+                    const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
+                    uint32_t fl = 0;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) fl |= n1f_count(e[q], med_s, A0, A1, D0, D1, a) << q;
+                    while (fl) { // the few samples to copy: one at a time, picked out of the eight registers
+                        const int q = __ffs(fl) - 1;
+                        fl &= fl - 1;
+                        float x = e[0];
+#pragma unroll
+                        for (int z = 1; z < 8; z++) x = (q == z) ? e[z] : x;
+                        n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
+                    }
+                }
+                for (; i < send; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
+                if (send == T4) for (int j = (T4 << 2) + threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+                flush();
+            }
+        } else {
+            for (int j = threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+            flush();
+        }
     }
 #undef ACC
     unsigned long long nv = (unsigned long long)wave_sum((int)a.nvalid), nb = (unsigned long long)wave_sum((int)a.nbelow),
