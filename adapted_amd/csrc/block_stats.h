@@ -27,12 +27,12 @@
 
 #define BS_THREADS 256
 #define BS_LEAF_STRIDE 136
-#define BS_BINS 4096      // 20-bit key buckets in the window of pass A
+#define BS_BINS 3072      // 20-bit key buckets in the window of pass A (1.5 octaves, centred on the pivot)
 #define BS_KSH 12         // key >> 12 = 20-bit bucket index
-#define BS_MEDCAP 1024    // samples of the median's bucket kept in LDS
-#define BS_MADCAP 4096    // samples of the MAD bracket kept in LDS (they reuse the histogram's storage)
+#define BS_MEDCAP 512     // samples of the median's bucket kept in LDS (behind the MAD bracket's, in the histogram's storage)
+#define BS_MADCAP 2560    // samples of the MAD bracket kept in LDS (they reuse the histogram's storage)
 #define BS_MAXCHUNK 128   // whole 8192-sample chunks per segment (1 Mi samples); longer segments take the generic path
-#define BS_BINS18 2048    // fallback passes C/D: 18-bit buckets, collect capacity 2048
+#define BS_BINS18 1536    // fallback passes C/D: 18-bit buckets, collect capacity 1536
 
 // (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
 extern __device__ int g_ablate;
@@ -48,7 +48,6 @@ struct BlockScratch {
         WaveScratch ws; // generic wave-level fallbacks reuse the staging area
     } u;
     uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
-    float collect[BS_MEDCAP]; // samples of the median's bucket
     float chunk_sum[BS_MAXCHUNK]; // sums of the whole numpy chunks of the segment under way
     float tleaf[128]; // leaf sums of a ragged chunk, by tree slot
     int scan[8];
@@ -59,6 +58,9 @@ struct BlockScratch {
     short leaf_off[132], leaf_len[132], leaf_slot[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk, and their tree slots
     unsigned char slot_used[128];
 };
+
+// samples of the median's bucket: behind the MAD bracket's in the histogram's storage (BS_MADCAP + BS_MEDCAP <= BS_BINS)
+static __device__ __forceinline__ LDS float *bs_collect(LDS BlockScratch *bs) { return (LDS float *)bs->hist + BS_MADCAP; }
 
 static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
 {
@@ -143,7 +145,7 @@ static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS 
         uint32_t kb = key >> BS_KSH;
         if (kb == p.key) {
             int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (slot < BS_MEDCAP) bs->collect[slot] = v;
+            if (slot < BS_MEDCAP) bs_collect(bs)[slot] = v;
         }
         if (p.do_mad) {
             float dt = fabsf(v - p.c);
@@ -181,7 +183,7 @@ static __device__ __forceinline__ void bs_copy_exact(float v, const SideParam &p
 {
     if ((f2key(v) >> BS_KSH) == p.key) {
         int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (slot < BS_MEDCAP) bs->collect[slot] = v;
+        if (slot < BS_MEDCAP) bs_collect(bs)[slot] = v;
     }
     if (p.do_mad) {
         const float dt = fabsf(v - p.c);
@@ -231,24 +233,19 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
     const int nchunk = n / 8192;
     const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
     auto slab_ptr = [&](int q) { return reinterpret_cast<const GLB f4u *>(x + (size_t)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024); };
-    // software pipeline, two slabs deep: a wave keeps 8 KB of loads in flight
-    f4u v[4], vn[4], vnn[4];
+    // software pipeline: the next slab's loads fly while this one is summed
+    f4u v[4], vn[4];
     if (myslabs > 0) {
         const GLB f4u *p = slab_ptr(0);
 #pragma unroll
         for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
     }
-    if (myslabs > 1) {
-        const GLB f4u *p = slab_ptr(1);
-#pragma unroll
-        for (int u = 0; u < 4; u++) vn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
-    }
     float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
     for (int q = 0; q < myslabs; q++) {
-        if (q + 2 < myslabs) {
-            const GLB f4u *p = slab_ptr(q + 2);
+        if (q + 1 < myslabs) {
+            const GLB f4u *p = slab_ptr(q + 1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) vnn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
+            for (int u = 0; u < 4; u++) vn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;
@@ -290,7 +287,7 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
             if (ln == 0) bs->chunk_sum[ch & (BS_MAXCHUNK - 1)] = cs;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { v[u] = vn[u]; vn[u] = vnn[u]; }
+        for (int u = 0; u < 4; u++) v[u] = vn[u];
     }
     __syncthreads();
     if (tid == 0) for (int ch = 0; ch < nchunk; ch++) total += bs->chunk_sum[ch]; // numpy adds the chunk sums in sequence
@@ -571,7 +568,7 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     if (!have_medmad) {
         float a = x[n / 4], b = x[n / 2], c3 = x[(3 * (long long)n) / 4];
         float pivot = fmaxf(fminf(a, b), fminf(fmaxf(a, b), c3));
-        wlo = bs_window_lo<BS_KSH>(pivot);
+        { const uint32_t kb = f2key(pivot) >> BS_KSH; wlo = kb >= BS_BINS / 2 ? kb - BS_BINS / 2 : 0u; } // centred on the pivot
     }
     __syncthreads();
     for (int i = tid; i < BS_BINS; i += BS_THREADS) bs->hist[i] = 0;
@@ -624,7 +621,7 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     } else {
         uint32_t below_key = 0;
         if ((n & 1) == 0 && rk == 0) below_key = bs_max_key_below(x, n, (wlo + (uint32_t)bin) << BS_KSH, bs); // (rare)
-        o.med = bs_median_from_bucket(bs, bs->collect, bs->ncollect, n, rk, below_key);
+        o.med = bs_median_from_bucket(bs, bs_collect(bs), bs->ncollect, n, rk, below_key);
     }
     phase(3);
     // ---- MAD inside the bracket, if it can be proven ---------------------------------------------
@@ -651,6 +648,11 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
             __syncthreads();
         }
     }
+#ifdef ADP_PHASE_TIMING
+    if (tid == 0 && n >= 8192) { atomicMax(&g_dbg[14], (unsigned long long)bs->nmad); atomicMax(&g_dbg[15], (unsigned long long)bs->ncollect);
+                                 atomicAdd(&g_dbg[16], (unsigned long long)bs->nmad); atomicAdd(&g_dbg[17], (unsigned long long)bs->ncollect);
+                                 if (bs->nmad > 2048) atomicAdd(&g_dbg[18], 1ull); if (bs->nmad > 3072) atomicAdd(&g_dbg[19], 1ull); }
+#endif
     if (tid == 0 && n >= 8192) { // tallies for the large segments only
         atomicAdd(&g_dbg[0], 1ull);
         if (done) atomicAdd(&g_dbg[1], 1ull);
@@ -674,7 +676,7 @@ struct PartReq {
 };
 
 // grid = n_reads blocks of 256 threads
-__global__ void __launch_bounds__(BS_THREADS, 4) k_partition_stats(const float *__restrict__ sigs, int m, const PartReq *__restrict__ req,
+__global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(const float *__restrict__ sigs, int m, const PartReq *__restrict__ req,
                                                                adp_row *__restrict__ rows)
 {
     __shared__ BlockScratch bs_;
