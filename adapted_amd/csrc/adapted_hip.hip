@@ -114,7 +114,7 @@ static int alloc_all(adp_handle *h)
     bad |= h->have_series.ensure(R);
     bad |= h->sp.ensure(R * sizeof(SpOut));
     bad |= h->any_none.ensure(64);
-    h->vslots = (int)(R < 4096 ? R : 4096);
+    h->vslots = (int)(R < 6144 ? R : 6144);
     h->vstride = ((h->m + 63) / 64) * 64;
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
     h->pslots = (int)(R < 8192 ? R : 8192);

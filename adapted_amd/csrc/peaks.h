@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
 //
 // Strict local maxima are at least two samples apart, so at most four of them lie within the minimum distance
 // (|dp| <= 9) on either side of a maximum: the neighbourhood is the ordinals k-4 .. k+4, whatever the positions.
-__global__ void __launch_bounds__(64) k_polya_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
+__global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
                                                    const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                    const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
                                                    const MbState *__restrict__ mbs, int32_t *__restrict__ pk_all,

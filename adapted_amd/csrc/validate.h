@@ -346,7 +346,7 @@ static __device__ void row_exception(adp_row *row, int code)
 }
 
 // persistent grid: blockIdx.x = slot, block = 64 threads
-__global__ void __launch_bounds__(64, 4) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows,
+__global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows,
                                                  PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;
