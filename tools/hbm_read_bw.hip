@@ -1,3 +1,7 @@
+// hbm_read_bw.hip -- what a kernel that does nothing but read can pull from HBM on this device: the practical ceiling
+// the streaming passes of the detect path are compared with in DESIGN.md section 5 (6.3-6.5 TB/s with plain float4
+// loads, 6.8 TB/s with non-temporal ones; flat and one-block-per-row layouts).
+//   hipcc --offload-arch=gfx950 -O3 -o hbm_read_bw tools/hbm_read_bw.hip && ./hbm_read_bw
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

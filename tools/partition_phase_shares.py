@@ -1,5 +1,11 @@
+"""Shares of k_partition_stats' phases (pass A, bucket search / MAD prediction, pass B, median, MAD selection) from the cycle
+tallies of a -DADP_PHASE_TIMING build of the library:
+
+    hipcc <flags of adapted_amd/build.py> -DADP_PHASE_TIMING -o /tmp/phase.so adapted_amd/csrc/adapted_hip.hip
+    ADAPTED_HIP_LIB=/tmp/phase.so python tools/partition_phase_shares.py
+"""
 import sys, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 from adapted_amd import lib
 from bench import make_spc
