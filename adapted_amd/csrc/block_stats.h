@@ -563,6 +563,29 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     auto phase = [](int) {};
 #endif
     SideParam sp; sp.key = 0; sp.c = 0.f; sp.P = 0.f; sp.Q = 0.f; sp.do_mad = 0;
+    if (!have_medmad && n <= BS_BINS) {
+        // a segment that fits the histogram's storage (the poly(A) slice): two plain numpy-ordered sums, then the exact
+        // median and MAD by direct selection on an LDS copy -- none of the bucket / bracket machinery
+        SumAux s1 = block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp);
+        o.mean = s1.sum / (float)n;
+        SumAux s2 = block_np_sum<SIDE_NONE>(x, n, 2, o.mean, bs, sp);
+        o.sd = sqrtf(s2.sum / (float)n);
+        LDS float *cp = (LDS float *)bs->hist;
+        __syncthreads();
+        for (int i = tid; i < n; i += BS_THREADS) cp[i] = x[i];
+        __syncthreads();
+        if (tid < 64) {
+            float vk, vkm1;
+            wave_select2_lds(cp, n, k1, 0, 0.f, &bs->u.ws, vk, vkm1);
+            const float med = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+            wave_select2_lds(cp, n, k1, 1, med, &bs->u.ws, vk, vkm1);
+            if (tid == 0) { bs->bcast[1] = med; bs->bcast[2] = (n & 1) ? vk : (vkm1 + vk) / 2.0f; }
+        }
+        __syncthreads();
+        o.med = bs->bcast[1]; o.mad = bs->bcast[2];
+        __syncthreads();
+        return o;
+    }
     // ---- pass A: mean + bucket histogram --------------------------------------------------
     uint32_t wlo = 0;
     if (!have_medmad) {
