@@ -114,8 +114,15 @@ static int alloc_all(adp_handle *h)
     bad |= h->have_series.ensure(R);
     bad |= h->sp.ensure(R * sizeof(SpOut));
     bad |= h->any_none.ensure(64);
-    h->vslots = (int)(R < 6144 ? R : 6144);
     h->vstride = ((h->m + 63) / 64) * 64;
+    // k_validate: 6 waves per SIMD = 6144 resident waves; each slot owns two series of up to m floats (moving mean and
+    // variance of slices k_mvs_series did not prepare): the slot count is bounded so that this scratch stays below 10 GB
+    {
+        size_t cap = (size_t)10000000000ull / ((size_t)8 * h->vstride);
+        if (cap < 256) cap = 256;
+        size_t want = R < 6144 ? R : 6144;
+        h->vslots = (int)(want < cap ? want : cap);
+    }
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
     h->pslots = (int)(R < 8192 ? R : 8192);
     bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
