@@ -53,6 +53,8 @@ struct ProfEntry { const char *name; hipEvent_t a, b; };
 struct adp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream3 = nullptr;          // copy stream (adp_memcpy_h2d_async)
+    hipEvent_t ev_copy[16] = {};            // adp_copy_mark / adp_copy_wait
     hipStream_t stream2 = nullptr;          // side stream: the start-peak scan (HBM-bound) beside the float64 gains (ALU-bound)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     adp_cfg cfg;
@@ -158,6 +160,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
     int rc = geom(h);
     if (rc) { delete h; return rc; }
     if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess ||
+        hipStreamCreate(&h->stream3) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
     rc = alloc_all(h);
@@ -177,6 +180,8 @@ int adp_destroy(adp_handle *h)
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    for (int i = 0; i < 16; i++) if (h->ev_copy[i]) (void)hipEventDestroy(h->ev_copy[i]);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -737,6 +742,41 @@ int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+int adp_host_alloc(adp_handle *h, uint64_t bytes, void **out)
+{
+    if (!h || !out) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return ADP_OK;
+}
+int adp_host_free(adp_handle *h, void *p)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipHostFree(p));
+    return ADP_OK;
+}
+int adp_memcpy_h2d_async(adp_handle *h, void *dst, const void *src_pinned, uint64_t bytes)
+{
+    if (!h) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, h->stream3));
+    return ADP_OK;
+}
+int adp_copy_mark(adp_handle *h, int slot)
+{
+    if (!h || slot < 0 || slot >= 16) return ADP_ERR_INVALID;
+    if (!h->ev_copy[slot]) HIPCHK(hipEventCreateWithFlags(&h->ev_copy[slot], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(h->ev_copy[slot], h->stream3));
+    return ADP_OK;
+}
+int adp_copy_wait(adp_handle *h, int slot)
+{
+    if (!h || slot >= 16) return ADP_ERR_INVALID;
+    if (slot < 0) { HIPCHK(hipStreamSynchronize(h->stream3)); return ADP_OK; }
+    if (!h->ev_copy[slot]) return ADP_ERR_INVALID;
+    HIPCHK(hipEventSynchronize(h->ev_copy[slot]));
     return ADP_OK;
 }
 int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes)

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -101,6 +102,11 @@ def load():
         return _LIB
     try:
         path = os.environ.get("ADAPTED_HIP_LIB") or _build.build()  # (override: a developer's experimental build)
+        # PyTorch-ROCm wheels carry their own HIP runtime; when both runtimes end up in one process, torch's has to claim
+        # the GPU first or it finds none afterwards.  If torch is already imported, let it do so now.
+        _torch = sys.modules.get("torch")
+        if _torch is not None and getattr(_torch, "cuda", None) is not None and _torch.cuda.is_available():
+            _torch.cuda.init()
         lib = C.CDLL(path)
     except Exception as e:  # no CPU fallback by design
         raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
@@ -116,7 +122,8 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_destroy", "adp_set_config", "adp_stream", "adp_synchronize", "adp_detect_llr", "adp_detect_start_peak",
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
-           "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk"]
+           "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
+           "adp_copy_mark", "adp_copy_wait"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -226,6 +233,7 @@ class Engine:
         self.cfg = make_cfg(spc)
         self.max_reads, self.m, self.device = int(max_reads), int(m), int(device)
         self._h = C.c_void_p()
+        self._pinned = {}
         self._check(self.lib.adp_create(self.device, C.byref(self.cfg), self.max_reads, self.m, C.byref(self._h)))
 
     # -- plumbing ---------------------------------------------------------------------
@@ -272,6 +280,32 @@ class Engine:
 
     def dev_free(self, ptr: int):
         self._check(self.lib.adp_dev_free(self._h, C.c_void_p(ptr)))
+
+    def host_alloc(self, shape, dtype) -> np.ndarray:
+        """page-locked host array (staging for h2d_async); release with host_free(arr)"""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        self._check(self.lib.adp_host_alloc(self._h, C.c_uint64(max(1, n * dt.itemsize)), C.byref(p)))
+        buf = (C.c_char * (n * dt.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = self._pinned.pop(arr.ctypes.data)
+        self._check(self.lib.adp_host_free(self._h, C.c_void_p(p)))
+
+    def h2d_async(self, dst: int, arr: np.ndarray, nbytes: Optional[int] = None):
+        """copy from a PINNED host array on the handle's copy stream; copy_mark(slot) then copy_wait(slot) before use"""
+        self._check(self.lib.adp_memcpy_h2d_async(self._h, C.c_void_p(dst), arr.ctypes.data_as(C.c_void_p),
+                                                  C.c_uint64(arr.nbytes if nbytes is None else nbytes)))
+
+    def copy_mark(self, slot: int):
+        self._check(self.lib.adp_copy_mark(self._h, int(slot)))
+
+    def copy_wait(self, slot: int = -1):
+        self._check(self.lib.adp_copy_wait(self._h, int(slot)))
 
     def h2d(self, dst: int, arr: np.ndarray):
         a = np.ascontiguousarray(arr)

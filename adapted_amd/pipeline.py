@@ -13,8 +13,8 @@ path busy and nothing else in the way:
                     BEFORE the detect call of slot k, so copies and kernels overlap;
   consumer          `on_rows(ids, rows)` (CSV writer) runs in a third thread.
 
-PyTorch provides the pinned memory, the device buffers and the copy stream (plumbing); the compute is the
-HIP library's.
+Pinned memory, device buffers and the copy stream come from the HIP library itself (adp_host_alloc,
+adp_dev_alloc, adp_memcpy_h2d_async on the handle's copy stream): the LLR / start-peak path needs no PyTorch.
 """
 from __future__ import annotations
 
@@ -30,43 +30,39 @@ from . import lib
 class HostPipeline:
     def __init__(self, spc, minibatch: int, m: int, device: int = 0, n_slots: int = 3, primary: str = "llr",
                  with_start_peak: bool = False, model=None):
-        import torch
-
-        self.torch = torch
         self.spc, self.N, self.m, self.device = spc, int(minibatch), int(m), int(device)
         self.primary, self.with_start_peak, self.model = primary, with_start_peak, model
-        self.dev = torch.device("cuda", self.device)
-        torch.cuda.set_device(self.device)
         self.eng = lib.Engine(spc, self.N, self.m, device=self.device)
-        self.copy_stream = torch.cuda.Stream(device=self.dev)
         self.slots = []
-        for _ in range(max(2, n_slots)):
-            hs = torch.empty((self.N, self.m), dtype=torch.float32, pin_memory=True)
-            hl = torch.empty((self.N,), dtype=torch.int32, pin_memory=True)
-            ds = torch.empty((self.N, self.m), dtype=torch.float32, device=self.dev)
-            dl = torch.empty((self.N,), dtype=torch.int32, device=self.dev)
-            self.slots.append({"hs": hs, "hl": hl, "ds": ds, "dl": dl, "sig": hs.numpy(), "lens": hl.numpy(),
-                               "ev": torch.cuda.Event()})
+        for _ in range(min(16, max(2, n_slots))):
+            sig = self.eng.host_alloc((self.N, self.m), np.float32)
+            lens = self.eng.host_alloc((self.N,), np.int32)
+            self.slots.append({"sig": sig, "lens": lens, "ds": self.eng.dev_alloc(self.N * self.m * 4),
+                               "dl": self.eng.dev_alloc(self.N * 4)})
         self.free: "queue.Queue[int]" = queue.Queue()
         for i in range(len(self.slots)):
             self.free.put(i)
 
     def close(self):
+        for s in self.slots:
+            self.eng.host_free(s["sig"])
+            self.eng.host_free(s["lens"])
+            self.eng.dev_free(s["ds"])
+            self.eng.dev_free(s["dl"])
+        self.slots = []
         self.eng.close()
 
     # -- stages -------------------------------------------------------------------------------
     def _start_h2d(self, j: int, n: int):
-        torch = self.torch
         s = self.slots[j]
-        with torch.cuda.stream(self.copy_stream):
-            s["ds"][:n].copy_(s["hs"][:n], non_blocking=True)
-            s["dl"][:n].copy_(s["hl"][:n], non_blocking=True)
-            s["ev"].record(self.copy_stream)
+        self.eng.h2d_async(s["ds"], s["sig"], n * self.m * 4)
+        self.eng.h2d_async(s["dl"], s["lens"], n * 4)
+        self.eng.copy_mark(j)
 
     def _detect(self, j: int, n: int) -> np.ndarray:
         s = self.slots[j]
-        s["ev"].synchronize()  # the engine works on its own stream: wait for the copy on the host
-        dsig, dlen = s["ds"].data_ptr(), s["dl"].data_ptr()
+        self.eng.copy_wait(j)  # this slot's copies only: the next slot's may still be in flight
+        dsig, dlen = s["ds"], s["dl"]
         if self.primary == "llr":
             rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, n, with_start_peak=self.with_start_peak, device_ptrs=True)
             if mbs[0] != lib.MB_OK:

@@ -91,8 +91,9 @@ def host_pipeline_bench(args, spc, device):
     m, mb = spc.sig_preload_size, args.minibatch
     pipe = HostPipeline(spc, mb, m, device=device, primary="llr", with_start_peak=not args.no_start_peak)
     pool = []
-    d = torch.empty((mb, m), dtype=torch.float32, device=pipe.dev)
-    dl = torch.full((mb,), m, dtype=torch.int32, device=pipe.dev)
+    dev = torch.device("cuda", device)
+    d = torch.empty((mb, m), dtype=torch.float32, device=dev)
+    dl = torch.full((mb,), m, dtype=torch.int32, device=dev)
     for k in range(3):
         pipe.eng.synth_fill(d.data_ptr(), dl.data_ptr(), mb, seed=args.seed, first_read=k * mb, decorate=True)
         torch.cuda.synchronize()

@@ -191,6 +191,15 @@ int adp_dev_alloc(adp_handle *h, uint64_t bytes, void **out);
 int adp_dev_free(adp_handle *h, void *p);
 int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes);
 int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes);
+/* Streaming input (adapted_amd/pipeline.py): page-locked host staging memory, and a host-to-device copy on the handle's
+ * COPY stream (neither the compute stream nor its side stream), so that the copy of the next minibatch overlaps the
+ * detect call of the current one.  adp_copy_mark(slot) marks the copies issued so far (slot in [0, 16));
+ * adp_copy_wait(slot) blocks the host until the copies marked by that slot have landed (slot < 0: all copies). */
+int adp_host_alloc(adp_handle *h, uint64_t bytes, void **out);
+int adp_host_free(adp_handle *h, void *p);
+int adp_memcpy_h2d_async(adp_handle *h, void *dst, const void *src_pinned, uint64_t bytes);
+int adp_copy_mark(adp_handle *h, int slot);
+int adp_copy_wait(adp_handle *h, int slot);
 
 /* Per-kernel timing of the LAST detect call, measured with HIP events on the handle's stream.
  * Enable with adp_set_profiling(h, 1).  names_out: up to cap pointers to static strings. */

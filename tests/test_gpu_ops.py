@@ -88,3 +88,48 @@ def test_cli_detect_writes_reference_csv(tmp_path):
     # `continue` finds every read already processed and writes nothing new
     cli.main(["continue", str(rd)])
     assert sorted(os.listdir(rd / "boundaries")) == ["detected_boundaries_0.csv"]
+
+
+def test_host_pipeline_equals_direct_calls_and_reports_dropped_minibatches():
+    """adapted_amd.pipeline.HostPipeline (pinned staging slots, H2D overlapped with detect, writer thread): the rows of
+    every minibatch equal a direct engine call on the same reads; a minibatch whose MAD is zero is reported through
+    on_dropped and skipped (the reference drops it and logs), the stream goes on; the last, partial minibatch is served."""
+    from adapted_amd import lib, synth
+    from adapted_amd.pipeline import HostPipeline
+
+    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    m = spc.sig_preload_size
+    N = 16
+    batches = []
+    for k, n in enumerate([N, N, N, 5]):               # 3 full minibatches and a partial one
+        ln = np.full(n, m, dtype=np.int32)
+        s, _ = synth.synth_batch(11 + k, 0, n, m, ln)
+        batches.append((s, ln, np.array(["b%d_%d" % (k, i) for i in range(n)], dtype=object)))
+    batches[1][0][:, :] = np.float32(80.0)              # constant minibatch: MAD == 0 -> dropped
+
+    eng = lib.Engine(spc, N, m, device=0)
+    direct = {}
+    for k, (s, ln, ids) in enumerate(batches):
+        rows, mbs = eng.detect_llr_rows(s, ln, s.shape[0], s.shape[0], with_start_peak=True)
+        direct[k] = (rows, int(mbs[0]))
+    eng.close()
+    assert direct[1][1] == lib.MB_MAD_ZERO and all(direct[k][1] == lib.MB_OK for k in (0, 2, 3))
+
+    pipe = HostPipeline(spc, N, m, device=0, primary="llr", with_start_peak=True, n_slots=2)
+    got, dropped = {}, []
+
+    def fill(get_buffers):
+        for k, (s, ln, ids) in enumerate(batches):
+            bs, bl = get_buffers()
+            bs[: s.shape[0]] = s
+            bl[: s.shape[0]] = ln
+            yield s.shape[0], (k, ids)
+
+    total = pipe.run(fill, lambda tag, rows: got.__setitem__(tag[0], (tag[1], rows.copy())),
+                     lambda tag, status: dropped.append((tag[0], status)))
+    pipe.close()
+    assert dropped == [(1, lib.MB_MAD_ZERO)]
+    assert sorted(got) == [0, 2, 3] and total == N + N + 5
+    for k in (0, 2, 3):
+        assert list(got[k][0]) == list(batches[k][2])
+        assert got[k][1].tobytes() == direct[k][0].tobytes()
