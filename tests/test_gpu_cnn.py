@@ -85,6 +85,7 @@ def test_device_topk_equals_scipy_formulation(Lo, n):
     from util import make_spc
     from golden_cases import CASES
 
+    torch.cuda.init()  # (torch's bundled HIP runtime has to claim the GPU before the library's does)
     spc = make_spc(CASES["rna004_cnn_default"])
     eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
     rng = np.random.default_rng(Lo)
@@ -120,6 +121,7 @@ def test_device_topk_reports_what_only_scipy_settles(kind):
     from util import make_spc
     from golden_cases import CASES
 
+    torch.cuda.init()
     spc = make_spc(CASES["rna004_cnn_default"])
     eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
     n, Lo, k = 6, 300, 10
