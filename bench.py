@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): synthetic RNA004 reads, 200 000-sample trac
 (--max_obs_trace 200000 -> preload m = 201 500 float32 samples = 806 000 B per read), LLR
 primary detector + start-peak scan + boundary validation, minibatches of 1000 reads
 (normalisation is per minibatch, as in the reference).  A "step" is one pass of the hot path
-over one HBM-resident batch of --reads reads per GPU; inputs are generated on the device
+over one HBM-resident batch of --reads reads per GPU (default 96 000: sized for the 288 GB HBM); inputs are generated on the device
 before the timed region (bit-identical host twin: adapted_amd/synth.py).
 
     python bench.py --gpus 1 --steps 8 --warmup 1
@@ -137,7 +137,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=32000, help="reads per step per GPU (whole minibatches)")
+    ap.add_argument("--reads", type=int, default=96000,
+                    help="reads per step per GPU (whole minibatches); 96 000 x 806 KB = 77 GB of signal + ~55 GB of workspace in the 288 GB HBM")
     ap.add_argument("--minibatch", type=int, default=1000)
     ap.add_argument("--max_obs_trace", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
