@@ -528,6 +528,35 @@ int adp_debug_log(adp_handle *h, const double *host_in, double *host_out, int n)
     return ADP_OK;
 }
 
+// fdiv_shared against the IEEE division for `count` consecutive float bit patterns from `first_bits` on (both signs)
+__global__ void k_debug_divcheck(float d, uint32_t first_bits, uint32_t count, unsigned long long *mism)
+{
+    const float y = 1.0f / d;
+    unsigned long long bad = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const float a = __uint_as_float(first_bits + i);
+        if (a != a || __builtin_isinf(a)) continue;
+        const float q = fdiv_shared(a, d, y), w = a / d;
+        const float qn = fdiv_shared(-a, d, y), wn = -a / d;
+        if (__float_as_uint(q) != __float_as_uint(w) || __float_as_uint(qn) != __float_as_uint(wn)) bad++;
+    }
+    if (bad) atomicAdd(mism, bad);
+}
+
+int adp_debug_divcheck(adp_handle *h, float d, uint32_t first_bits, uint32_t count, uint64_t *mismatches_out)
+{
+    if (!h || !mismatches_out) return ADP_ERR_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long *dm = nullptr;
+    HIPCHK(hipMalloc(&dm, 8));
+    HIPCHK(hipMemsetAsync(dm, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_debug_divcheck, dim3(4096), dim3(256), 0, h->stream, d, first_bits, count, dm);
+    HIPCHK(hipMemcpyAsync(mismatches_out, dm, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(dm));
+    return ADP_OK;
+}
+
 int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch,
                        int flags, int stage)
 {

@@ -40,6 +40,22 @@ static __device__ __forceinline__ float4 ld_stream4(const float4 *p)
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
+// a / d in float32 for MANY numerators and ONE divisor: with y = RN(1/d) (one IEEE division), q0 = RN(a y) is within
+// an ulp of the quotient, r = a - d q0 is exact in one fma, and RN(q0 + r y) is the correctly rounded quotient
+// (Markstein's theorem; it needs y correctly rounded, which fails only for a significand of all ones, and no
+// underflow of r).  fdiv_ok(d) says whether the divisor qualifies; tests/test_gpu_ops.py checks 4e9 quotients.
+static __device__ __forceinline__ bool fdiv_ok(float d)
+{
+    const uint32_t u = __float_as_uint(d), e = (u >> 23) & 0xffu;
+    return (u & 0x7fffffu) != 0x7fffffu && e > 40u && e < 215u; // normal, far from the ends of the exponent range
+}
+static __device__ __forceinline__ float fdiv_shared(float a, float d, float y)
+{
+    const float q0 = a * y;
+    const float r = __builtin_fmaf(-d, q0, a);
+    return __builtin_fmaf(r, y, q0);
+}
+
 static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // order-preserving float32 <-> uint32 key

@@ -53,10 +53,14 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
     int my_nan = 0;
     const int tile_n = NP_TILE * ds; // samples per tile (NP_TILE pooled outputs, 2 per thread)
     const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) && ((tile_n & 3) == 0);
+    // every sample of the minibatch is divided by the same MAD: one IEEE division for its reciprocal, then three
+    // operations per sample that return the bits of the IEEE quotient (fdiv_shared, common.h)
+    const bool fast_div = fdiv_ok(mad);
+    const float rmad = 1.0f / mad;
     auto norm1 = [&](float c) {
         c = c < lo ? lo : c; // np.clip; NaN stays NaN
         c = c > hi ? hi : c;
-        return (c - med) / mad;
+        return fast_div ? fdiv_shared(c - med, mad, rmad) : (c - med) / mad;
     };
     for (int tb = 0; tb < L; tb += NP_TILE) {
         const int base = tb * ds;

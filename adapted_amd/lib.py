@@ -123,7 +123,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
-           "adp_copy_mark", "adp_copy_wait"]
+           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -404,6 +404,11 @@ class Engine:
         return out, st
 
     # -- debug (tests) ------------------------------------------------------------------------
+    def debug_divcheck(self, d: float, first_bits: int, count: int) -> int:
+        out = C.c_uint64(0)
+        self._check(self.lib.adp_debug_divcheck(self._h, C.c_float(d), C.c_uint32(first_bits), C.c_uint32(count), C.byref(out)))
+        return int(out.value)
+
     def debug_log(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty_like(x)

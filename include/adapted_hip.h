@@ -215,6 +215,9 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes);
 int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                        int minibatch, int flags, int stage);
 
+/* fdiv_shared (adapted_amd/csrc/common.h: float32 division by a divisor shared by many numerators) against the IEEE
+ * division, for `count` consecutive float bit patterns from first_bits on and their negatives (tests only) */
+int adp_debug_divcheck(adp_handle *h, float d, uint32_t first_bits, uint32_t count, uint64_t *mismatches_out);
 /* log_cr (adapted_amd/csrc/log_cr.h), the logarithm of the gains kernels, applied to n host doubles (tests only) */
 int adp_debug_log(adp_handle *h, const double *host_in, double *host_out, int n);
 

@@ -133,3 +133,24 @@ def test_host_pipeline_equals_direct_calls_and_reports_dropped_minibatches():
     for k in (0, 2, 3):
         assert list(got[k][0]) == list(batches[k][2])
         assert got[k][1].tobytes() == direct[k][0].tobytes()
+
+
+def test_shared_reciprocal_division_equals_ieee_division():
+    """k_norm_pool divides every sample of a minibatch by the same MAD: fdiv_shared (q0 = a*y, r = a - d*q0, q = q0 + r*y
+    with y = RN(1/d)) must return the bits of the IEEE division.  Checked for 240 divisors (MAD-like and random) over
+    16.7 M consecutive numerators each around the clip range (both signs): 8e9 quotients."""
+    from adapted_amd import lib
+
+    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+    rng = np.random.default_rng(5)
+    ds = np.concatenate([rng.uniform(5.0, 20.0, 160), 10.0 ** rng.uniform(-3, 4, 60), [1.0, 2.0, 3.0, 7.0, 9.999999, 10.0, 0.1, 1.5,
+                        float(np.float32(13.37)), 8.0, 12.5, 1e-2, 255.0, 1023.0, 0.3, 6.0, 11.0, 17.0, 19.0, 100.0]]).astype(np.float32)
+    bad = 0
+    for d in ds:
+        # numerators from d * 2^-8 upwards: 2^24 consecutive floats cover two binades around |a| ~ d/256 .. ; plus a block
+        # near 5 d (the clip bound) and a block of tiny values
+        for start in (np.float32(d) * np.float32(2.0 ** -8), np.float32(d) * np.float32(4.0), np.float32(1e-6)):
+            bad += eng.debug_divcheck(float(d), int(np.float32(start).view(np.uint32)), 1 << 24)
+    assert bad == 0
+    eng.close()
