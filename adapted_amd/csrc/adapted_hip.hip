@@ -292,6 +292,20 @@ __global__ void k_mb_params_out(const MbState *mbs, int n_mb, double *out)
     }
 }
 
+// developer switch ADP_ABLATE (bit mask that skips parts of kernels in timing experiments; results are wrong when set):
+// the device copy is refreshed only when the environment value changes
+static void sync_ablate(hipStream_t st)
+{
+    static int current = 0;
+    const char *ab = getenv("ADP_ABLATE");
+    const int want = ab ? atoi(ab) : 0;
+    if (want != current) {
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &want, sizeof(int), 0, hipMemcpyHostToDevice, st);
+        (void)hipStreamSynchronize(st);
+        current = want;
+    }
+}
+
 static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
                            bool gate_mb)
 {
@@ -309,15 +323,11 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
         (void)hipMemsetAsync(h->have_series.p, 0, (size_t)n, h->stream);
     }
     int grid = n < h->vslots ? n : h->vslots;
-    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
-      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
+    sync_ablate(h->stream);
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
-    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
-      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, h->stream); }
     { Scope s(h, "k_partition_stats");
-      const char *sm = getenv("ADP_PART_SMEM"); size_t smb = sm ? (size_t)atoi(sm) : 0;
-      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), smb, h->stream, dsig, m, h->preq.as<PartReq>(),
+      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
     return 0;
 }
@@ -404,8 +414,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         g_err = "device allocation failed"; return ADP_ERR_HIP;
     }
     hipStream_t st = h->stream;
-    { const char *ab = getenv("ADP_ABLATE"); int abv = ab ? atoi(ab) : 0;
-      (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_ablate), &abv, sizeof(int), 0, hipMemcpyHostToDevice, st); }
+    sync_ablate(st);
     MbState *mbs = h->mbs.as<MbState>();
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
