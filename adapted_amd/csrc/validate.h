@@ -46,6 +46,30 @@ struct RowW {
 // the chain, so they are issued eight steps at a time, a block AHEAD of the arithmetic: otherwise every step
 // would wait for its own round trip to memory.
 #define BN_BLK 8
+// eight consecutive samples as two 16-byte accesses (gfx950 needs dword alignment only): with one LANE per read every
+// access of the wave touches 64 different rows, so the number of memory instructions is what the kernel costs
+typedef float bn_f4 __attribute__((ext_vector_type(4), aligned(4)));
+static __device__ __forceinline__ void bn_load8(float (&dst)[BN_BLK], const GLB float *a, int i, int n, int back)
+{
+    if (i + BN_BLK <= n) {
+        const bn_f4 v0 = *reinterpret_cast<const GLB bn_f4 *>(a + i - back), v1 = *reinterpret_cast<const GLB bn_f4 *>(a + i - back + 4);
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) dst[j] = (i + j < n) ? a[i + j - back] : 0.f;
+    }
+}
+static __device__ __forceinline__ void bn_store8(GLB float *out, int o, const float (&res)[BN_BLK], int i, int n)
+{
+    if (i + BN_BLK <= n) {
+        const bn_f4 v0 = {res[0], res[1], res[2], res[3]}, v1 = {res[4], res[5], res[6], res[7]};
+        *reinterpret_cast<GLB bn_f4 *>(out + o) = v0;
+        *reinterpret_cast<GLB bn_f4 *>(out + o + 4) = v1;
+    } else {
+#pragma unroll
+        for (int j = 0; j < BN_BLK; j++) if (i + j < n) out[o + j] = res[j];
+    }
+}
 
 // bottleneck.move_mean(a, window=w) for i >= w-1 (float32, NaN-free input) -- single lane
 static __device__ __noinline__ void bn_move_mean(const float *a_, int n, int w, float *out_)
@@ -63,19 +87,18 @@ static __device__ __noinline__ void bn_move_mean(const float *a_, int n, int w, 
     out[0] = asum / (float)w;
     const float inv = (float)(1.0 / (double)w);
     float cn[BN_BLK], co[BN_BLK], nn[BN_BLK], no[BN_BLK];
-#pragma unroll
-    for (int j = 0; j < BN_BLK; j++) { const int i = w + j; cn[j] = i < n ? a[i] : 0.f; co[j] = i < n ? a[i - w] : 0.f; }
+    bn_load8(cn, a, w, n, 0);
+    bn_load8(co, a, w, n, w);
     for (int i0 = w; i0 < n; i0 += BN_BLK) {
-#pragma unroll
-        for (int j = 0; j < BN_BLK; j++) { const int i = i0 + BN_BLK + j; nn[j] = i < n ? a[i] : 0.f; no[j] = i < n ? a[i - w] : 0.f; }
+        bn_load8(nn, a, i0 + BN_BLK, n, 0);
+        bn_load8(no, a, i0 + BN_BLK, n, w);
         float res[BN_BLK];
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) {
             asum += cn[j] - co[j];
             res[j] = asum * inv;
         }
-#pragma unroll
-        for (int j = 0; j < BN_BLK; j++) if (i0 + j < n) out[i0 + j - w + 1] = res[j];
+        bn_store8(out, i0 - w + 1, res, i0, n);
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) { cn[j] = nn[j]; co[j] = no[j]; }
     }
@@ -107,12 +130,12 @@ static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, f
     out[0] = assqdm / (float)count;
     const float ddof_inv = (float)(1.0 / (double)count), count_inv = ddof_inv;
     float cn[BN_BLK], co[BN_BLK], nn[BN_BLK], no[BN_BLK];
-#pragma unroll
-    for (int j = 0; j < BN_BLK; j++) { const int i = w + j; cn[j] = i < n ? a[i] : 0.f; co[j] = i < n ? a[i - w] : 0.f; }
+    bn_load8(cn, a, w, n, 0);
+    bn_load8(co, a, w, n, w);
     for (int i0 = w; i0 < n; i0 += BN_BLK) {
-#pragma unroll
-        for (int j = 0; j < BN_BLK; j++) { const int i = i0 + BN_BLK + j; nn[j] = i < n ? a[i] : 0.f; no[j] = i < n ? a[i - w] : 0.f; }
-        float res[BN_BLK];
+        bn_load8(nn, a, i0 + BN_BLK, n, 0);
+        bn_load8(no, a, i0 + BN_BLK, n, w);
+        float res[BN_BLK] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) {
             if (i0 + j < n) { // (the padding of the last block must not touch the state)
@@ -126,8 +149,7 @@ static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, f
                 res[j] = assqdm * ddof_inv;
             }
         }
-#pragma unroll
-        for (int j = 0; j < BN_BLK; j++) if (i0 + j < n) out[i0 + j - w + 1] = res[j];
+        bn_store8(out, i0 - w + 1, res, i0, n);
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) { cn[j] = nn[j]; co[j] = no[j]; }
     }
