@@ -782,6 +782,34 @@ int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes)
     HIPCHK(hipStreamSynchronize(h->stream));
     return ADP_OK;
 }
+// grid = (ceil(m / 1024), n); block = 256: four samples per thread
+__global__ void __launch_bounds__(256) k_calibrate_i16(const int16_t *__restrict__ raw, const int32_t *__restrict__ full_len,
+                                                        const float *__restrict__ scale, const float *__restrict__ offset, int m,
+                                                        float *__restrict__ out)
+{
+    const int r = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= m) return;
+    const int len = full_len[r] < m ? full_len[r] : m;
+    const float sc = scale[r], of = offset[r];
+    const int16_t *src = raw + (size_t)r * m + i0;
+    float *dst = out + (size_t)r * m + i0;
+    const float nanv = __builtin_nanf("");
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (i0 + j < m) dst[j] = (i0 + j < len) ? sc * ((float)src[j] + of) : nanv;
+}
+
+int adp_calibrate_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len, const float *scale, const float *offset,
+                      int n_reads, int m, float *signals_out)
+{
+    if (!h || !raw || !full_len || !scale || !offset || !signals_out || n_reads < 1 || m < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_calibrate_i16, dim3((m + 1023) / 1024, n_reads), dim3(256), 0, h->stream, raw, full_len, scale, offset, m, signals_out);
+    HIPCHK(hipGetLastError());
+    return ADP_OK;
+}
+
 int adp_host_alloc(adp_handle *h, uint64_t bytes, void **out)
 {
     if (!h || !out) return ADP_ERR_INVALID;

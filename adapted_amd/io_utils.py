@@ -101,3 +101,69 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
                 k = 0
     if k:
         yield sig[:k], lens[:k], ids[:k]
+
+
+def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
+    """yield (read_id, n_samples, int16 signal accessor, scale, offset)"""
+    if filename.endswith(".npz"):
+        z = np.load(filename, allow_pickle=True)
+        if "raw" not in z and "raw_0" not in z:
+            raise ValueError("%s holds no raw ADC samples (keys raw / raw_<i>, scale, offset)" % filename)
+        ids = [str(x) for x in z["read_ids"]]
+        lens, scale, offset = z["full_lengths"], z["scale"], z["offset"]
+        for i, rid in enumerate(ids):
+            if selection is not None and rid not in selection:
+                continue
+            sig = z["raw"][i] if "raw" in z else z["raw_%d" % i]
+            yield rid, int(lens[i]), sig, float(scale[i]), float(offset[i])
+    else:
+        try:
+            from pod5 import Reader
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
+        with Reader(filename) as fh:
+            for rec in fh.reads(selection=selection, missing_ok=True):
+                yield str(rec.read_id), int(rec.num_samples), rec.signal, float(rec.calibration.scale), float(rec.calibration.offset)
+
+
+def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
+                          preload_size: int, buffers=None):
+    """Raw-ADC twin of yield_minibatches for the int16 ingestion path (adapted_amd.pipeline, int16_input=True):
+    yields (raw int16 [n, preload_size] -- the tail of a short read is left untouched, the device writes NaN there --,
+    lengths int32, scale float32, offset float32, ids).  pA = scale * (float32(adc) + offset) is applied on the device."""
+    if read_ids_incl and read_ids_excl:
+        read_ids_incl = read_ids_incl.difference(read_ids_excl)
+        read_ids_excl = set()
+    selection = list(read_ids_incl) if read_ids_incl else None
+    N, m = batch_size, preload_size
+
+    def fresh():
+        if buffers is not None:
+            raw, lens, sc, of = buffers()
+            return raw, lens, sc, of, np.empty(N, dtype=object)
+        return (np.zeros((N, m), dtype=np.int16), np.empty(N, dtype=np.int32), np.empty(N, dtype=np.float32),
+                np.empty(N, dtype=np.float32), np.empty(N, dtype=object))
+
+    cur = None
+    k = 0
+    for fn in files:
+        for rid, n_samples, signal, scale, offset in _iter_reads_i16(fn, selection):
+            if rid in read_ids_excl:
+                continue
+            if cur is None:
+                cur = fresh()
+            raw, lens, sc, of, ids = cur
+            s = np.asarray(signal[:m], dtype=np.int16)
+            take = min(m, n_samples)
+            if s.size < take:
+                raise ValueError("read %s: %d samples stored, %d announced" % (rid, s.size, n_samples))
+            raw[k, :take] = s[:take]
+            lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
+            k += 1
+            if k == N:
+                yield raw, lens, sc, of, ids
+                cur = None
+                k = 0
+    if k:
+        raw, lens, sc, of, ids = cur
+        yield raw[:k], lens[:k], sc[:k], of[:k], ids[:k]

@@ -48,6 +48,9 @@ def build_parser() -> argparse.ArgumentParser:
     d.add_argument("-s", "--minibatch_size", type=int, default=1000, help="Number of reads per minibatch (normalisation unit).")
     d.add_argument("--start_peak", action="store_true", help="(extension) also fill the start_peak_* columns on the LLR path")
     d.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    d.add_argument("--int16_ingest", action="store_true",
+                   help="(extension) move raw int16 ADC samples + calibration to the GPU and compute pA there "
+                        "(pA = scale * (float32(adc) + offset)); .pod5 inputs or .npz bundles with raw/scale/offset")
     return p
 
 
@@ -101,7 +104,7 @@ class _Writer:
 
 
 def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, batch_out, device, start_peak=False,
-               bidx_pass=0, bidx_fail=0):
+               bidx_pass=0, bidx_fail=0, int16_ingest=False):
     rank, ws, local = parallel.world()
     if device is None:
         device = local
@@ -126,11 +129,29 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
 
     # pinned staging slots filled in place by a producer thread, H2D overlapped with the detect call, CSV writing in
     # a third thread (adapted_amd/pipeline.py); ranks take whole minibatches round-robin
+    GROUP = 4  # minibatches per staging slot and detect call (normalisation stays per minibatch)
     pipe = HostPipeline(spc, minibatch, m, device=device, primary=primary, with_start_peak=start_peak,
-                        model=model if primary == "cnn" else None)
+                        model=model if primary == "cnn" else None, int16_input=int16_ingest, group=GROUP)
+
+    def fill_i16(get_buffers):
+        # raw ADC samples + calibration travel to the device, pA values are made there (extension, see pipeline.py)
+        from .io_utils import yield_minibatches_i16
+
+        it = yield_minibatches_i16(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, buffers=get_buffers if ws == 1 else None)
+        for i, (raw, lens, sc, of, ids) in enumerate(it):
+            if ws > 1:
+                if i % ws != rank:
+                    continue
+                braw, bl, bsc, bof = get_buffers()
+                k = raw.shape[0]
+                braw[:k], bl[:k], bsc[:k], bof[:k] = raw, lens, sc, of
+            yield raw.shape[0], ids.copy()
 
     def fill(get_buffers):
-        it = yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch, m, buffers=get_buffers if ws == 1 else None)
+        if int16_ingest:
+            yield from fill_i16(get_buffers)
+            return
+        it = yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, buffers=get_buffers if ws == 1 else None)
         for i, (sig, lens, ids) in enumerate(it):
             if ws > 1:
                 if i % ws != rank:
@@ -227,7 +248,8 @@ def main(argv=None):
         bp, bf = mp + 1, mf + 1
         logging.info("Found %d previously processed reads.", len(excl))
     run_detect(files, set(read_ids), excl, spc, run_dir, args.minibatch_size, args.batch_size, args.device,
-               start_peak=getattr(args, "start_peak", False), bidx_pass=bp, bidx_fail=bf)
+               start_peak=getattr(args, "start_peak", False), bidx_pass=bp, bidx_fail=bf,
+               int16_ingest=getattr(args, "int16_ingest", False))
     logging.info("Done.")
 
 

@@ -29,16 +29,27 @@ from . import lib
 
 class HostPipeline:
     def __init__(self, spc, minibatch: int, m: int, device: int = 0, n_slots: int = 3, primary: str = "llr",
-                 with_start_peak: bool = False, model=None):
-        self.spc, self.N, self.m, self.device = spc, int(minibatch), int(m), int(device)
-        self.primary, self.with_start_peak, self.model = primary, with_start_peak, model
+                 with_start_peak: bool = False, model=None, int16_input: bool = False, group: int = 1):
+        """int16_input: the staging slots hold raw ADC samples (int16) plus per-read (scale, offset); they are calibrated
+        to float32 pA on the device (adp_calibrate_i16), so only 2 bytes per sample cross PCIe.  get_buffers() then hands
+        out (raw, lengths, scale, offset) instead of (signals, lengths)."""
+        """group: minibatches per staging slot and per detect call (a call over several minibatches fills the GPU better
+        than one over 1000 reads; normalisation stays per minibatch)."""
+        self.spc, self.mb, self.m, self.device = spc, int(minibatch), int(m), int(device)
+        self.N = self.mb * max(1, int(group))  # reads per slot
+        self.primary, self.with_start_peak, self.model, self.i16 = primary, with_start_peak, model, bool(int16_input)
         self.eng = lib.Engine(spc, self.N, self.m, device=self.device)
         self.slots = []
+        self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4) if self.i16 else None  # calibrated minibatch (one: detect is serial)
         for _ in range(min(16, max(2, n_slots))):
-            sig = self.eng.host_alloc((self.N, self.m), np.float32)
+            sig = self.eng.host_alloc((self.N, self.m), np.int16 if self.i16 else np.float32)
             lens = self.eng.host_alloc((self.N,), np.int32)
-            self.slots.append({"sig": sig, "lens": lens, "ds": self.eng.dev_alloc(self.N * self.m * 4),
-                               "dl": self.eng.dev_alloc(self.N * 4)})
+            slot = {"sig": sig, "lens": lens, "ds": self.eng.dev_alloc(self.N * self.m * (2 if self.i16 else 4)),
+                    "dl": self.eng.dev_alloc(self.N * 4)}
+            if self.i16:
+                slot["cal"] = self.eng.host_alloc((2, self.N), np.float32)  # scale, offset
+                slot["dcal"] = self.eng.dev_alloc(2 * self.N * 4)
+            self.slots.append(slot)
         self.free: "queue.Queue[int]" = queue.Queue()
         for i in range(len(self.slots)):
             self.free.put(i)
@@ -49,36 +60,47 @@ class HostPipeline:
             self.eng.host_free(s["lens"])
             self.eng.dev_free(s["ds"])
             self.eng.dev_free(s["dl"])
+            if "cal" in s:
+                self.eng.host_free(s["cal"])
+                self.eng.dev_free(s["dcal"])
+        if self.dsig16:
+            self.eng.dev_free(self.dsig16)
+            self.dsig16 = None
         self.slots = []
         self.eng.close()
 
     # -- stages -------------------------------------------------------------------------------
     def _start_h2d(self, j: int, n: int):
         s = self.slots[j]
-        self.eng.h2d_async(s["ds"], s["sig"], n * self.m * 4)
+        self.eng.h2d_async(s["ds"], s["sig"], n * self.m * (2 if self.i16 else 4))
         self.eng.h2d_async(s["dl"], s["lens"], n * 4)
+        if self.i16:
+            self.eng.h2d_async(s["dcal"], s["cal"])
         self.eng.copy_mark(j)
 
-    def _detect(self, j: int, n: int) -> np.ndarray:
+    def _detect(self, j: int, n: int):
+        """-> (rows, per-minibatch status or None)"""
         s = self.slots[j]
         self.eng.copy_wait(j)  # this slot's copies only: the next slot's may still be in flight
         dsig, dlen = s["ds"], s["dl"]
+        if self.i16:  # raw ADC -> float32 pA, NaN beyond the read, on the engine's stream ahead of the detect kernels
+            self.eng.calibrate_i16(dsig, dlen, s["dcal"], s["dcal"] + self.N * 4, n, self.dsig16)
+            dsig = self.dsig16
         if self.primary == "llr":
-            rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, n, with_start_peak=self.with_start_peak, device_ptrs=True)
-            if mbs[0] != lib.MB_OK:
-                raise lib.MinibatchDropped(int(mbs[0]))
-            return rows
+            rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, self.mb, with_start_peak=self.with_start_peak, device_ptrs=True)
+            return rows, mbs
         if self.primary == "start_peak":
-            return self.eng.detect_start_peak_rows(dsig, dlen, n, n, device_ptrs=True)
+            return self.eng.detect_start_peak_rows(dsig, dlen, n, self.mb, device_ptrs=True), None
         from .detect import cnn as _cnn
 
-        return _cnn.detect_rows_device(self.eng, dsig, dlen, n, s["lens"][:n], self.model, self.spc)
+        return _cnn.detect_rows_device(self.eng, dsig, dlen, n, s["lens"][:n], self.model, self.spc), None
 
     # -- driver -------------------------------------------------------------------------------
     def run(self, fill: Callable[[Callable[[], Tuple[np.ndarray, np.ndarray]]], Iterable[Tuple[int, object]]],
             on_rows: Callable[[object, np.ndarray], None], on_dropped: Optional[Callable[[object, int], None]] = None) -> int:
         """fill(get_buffers) -> iterator of (n, ids): every item announces that the buffers handed out by the LAST
-        get_buffers() call now hold n reads.  Returns the number of reads processed."""
+        get_buffers() call now hold n reads (up to group * minibatch; ids: a sequence of n ids, sliced per minibatch when
+        one is dropped -- or any tag when group == 1).  Returns the number of reads processed."""
         filled: "queue.Queue" = queue.Queue(maxsize=len(self.slots))
         done: "queue.Queue" = queue.Queue(maxsize=4 * len(self.slots))
         err = []
@@ -87,6 +109,8 @@ class HostPipeline:
         def get_buffers():
             j = self.free.get()
             cur["j"] = j
+            if self.i16:
+                return self.slots[j]["sig"], self.slots[j]["lens"], self.slots[j]["cal"][0], self.slots[j]["cal"][1]
             return self.slots[j]["sig"], self.slots[j]["lens"]
 
         def producer():
@@ -121,13 +145,19 @@ class HostPipeline:
                     self._start_h2d(item[0], item[1])
                 if pending is not None:
                     j, n, ids = pending
-                    try:
-                        rows = self._detect(j, n)
+                    rows, mbs = self._detect(j, n)
+                    if mbs is None or (mbs == lib.MB_OK).all():
                         done.put((ids, rows))
                         total += n
-                    except lib.MinibatchDropped as e:
-                        if on_dropped:
-                            on_dropped(ids, e.status)
+                    else:  # some minibatch of the group was dropped (the reference logs it and goes on)
+                        for q, st in enumerate(mbs):
+                            a, b = q * self.mb, min(n, (q + 1) * self.mb)
+                            sub = ids[a:b] if hasattr(ids, "__getitem__") and not isinstance(ids, tuple) else ids
+                            if st == lib.MB_OK:
+                                done.put((sub, rows[a:b]))
+                                total += b - a
+                            elif on_dropped:
+                                on_dropped(sub, int(st))
                     self.free.put(j)
                 pending = item
                 if item is None:

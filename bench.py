@@ -89,15 +89,22 @@ def host_pipeline_bench(args, spc, device):
     from adapted_amd.pipeline import HostPipeline
 
     m, mb = spc.sig_preload_size, args.minibatch
-    pipe = HostPipeline(spc, mb, m, device=device, primary="llr", with_start_peak=not args.no_start_peak)
+    i16 = bool(args.int16)
+    G = max(1, args.group)
+    pipe = HostPipeline(spc, mb, m, device=device, primary="llr", with_start_peak=not args.no_start_peak, int16_input=i16, group=G)
+    mb = mb * G  # reads per slot from here on
     pool = []
     dev = torch.device("cuda", device)
     d = torch.empty((mb, m), dtype=torch.float32, device=dev)
     dl = torch.full((mb,), m, dtype=torch.int32, device=dev)
+    sc, of = np.float32(0.17), np.float32(-12.0)  # a typical pod5 calibration
     for k in range(3):
         pipe.eng.synth_fill(d.data_ptr(), dl.data_ptr(), mb, seed=args.seed, first_read=k * mb, decorate=True)
         torch.cuda.synchronize()
-        pool.append(d.cpu().numpy().copy())
+        if i16:  # the ADC codes whose calibrated values are (to the code's resolution) the synthetic pA samples
+            pool.append(torch.clamp(torch.round(d / float(sc) - float(of)), -32768, 32767).to(torch.int16).cpu().numpy().copy())
+        else:
+            pool.append(d.cpu().numpy().copy())
     lens = np.full(mb, m, dtype=np.int32)
     ids = np.arange(mb).astype(object)
     n_ok = [0]
@@ -105,7 +112,11 @@ def host_pipeline_bench(args, spc, device):
 
     def fill(get_buffers, count, assemble=True):
         for i in range(count):
-            sig, ln = get_buffers()
+            bufs = get_buffers()
+            sig, ln = bufs[0], bufs[1]
+            if i16:
+                bufs[2][:] = sc
+                bufs[3][:] = of
             if assemble:  # (one thread's memcpy: the stand-in for a reader writing the minibatch)
                 np.copyto(sig, pool[i % len(pool)])
             ln[:] = lens
@@ -124,12 +135,14 @@ def host_pipeline_bench(args, spc, device):
     total2 = pipe.run(lambda gb: fill(gb, args.host_pipeline, assemble=False), on_rows)  # staging slots already filled
     dt2 = time.perf_counter() - t1
     pipe.close()
-    gb = total * m * 4 / 1e9
+    bps = 2 if i16 else 4
+    gb = total * m * bps / 1e9
     print(json.dumps({"metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads, HOST buffers (PCIe-inclusive; not the headline)",
                       "value": total / dt, "unit": "reads/s", "n_gpus": 1, "minibatches": args.host_pipeline,
                       "h2d_GB_per_s": gb / dt, "pass_rate": n_ok[0] / max(total + total2, 1),
-                      "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * m * 4 / 1e9 / dt2},
-                      "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d" % (m, mb)}}))
+                      "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * m * bps / 1e9 / dt2},
+                      "input": "int16 ADC + device calibration" if i16 else "float32 pA",
+                      "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}}))
 
 
 def main():
@@ -151,6 +164,8 @@ def main():
     ap.add_argument("--host-pipeline", type=int, default=0, metavar="N",
                     help="instead of the resident benchmark: stream N minibatches from HOST memory through adapted_amd.pipeline "
                          "(pinned staging, H2D overlapped with detect) and print the PCIe-inclusive rate -- never the headline value")
+    ap.add_argument("--group", type=int, default=4, help="with --host-pipeline: minibatches per staging slot / detect call")
+    ap.add_argument("--int16", action="store_true", help="with --host-pipeline: stream raw int16 ADC samples and calibrate on the device")
     args = ap.parse_args()
 
     import torch

@@ -191,6 +191,15 @@ int adp_dev_alloc(adp_handle *h, uint64_t bytes, void **out);
 int adp_dev_free(adp_handle *h, void *p);
 int adp_memcpy_h2d(adp_handle *h, void *dst, const void *src, uint64_t bytes);
 int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes);
+/* int16 ingestion (an EXTENSION of the boundary: the reference's operators take calibrated float32):
+ * raw ADC samples int16 [n, m] + per-read calibration -> the float32 [n, m] NaN-padded minibatch the detect entry points
+ * take, on the device, so that only 2 bytes per sample cross PCIe.  pA = scale * (float32(adc) + offset), both
+ * operations rounded to float32 -- pod5's calibrate_signal_array; pod5 is not in this build's container, so the formula
+ * is unpinned against it and stated here.  Samples at or beyond min(full_len, m) become NaN (minibatch layout B0,
+ * adapted/file_proc.py:170-174).  All pointers are DEVICE pointers. */
+int adp_calibrate_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len, const float *scale, const float *offset,
+                      int n_reads, int m, float *signals_out);
+
 /* Streaming input (adapted_amd/pipeline.py): page-locked host staging memory, and a host-to-device copy on the handle's
  * COPY stream (neither the compute stream nor its side stream), so that the copy of the next minibatch overlaps the
  * detect call of the current one.  adp_copy_mark(slot) marks the copies issued so far (slot in [0, 16));

@@ -154,3 +154,70 @@ def test_shared_reciprocal_division_equals_ieee_division():
             bad += eng.debug_divcheck(float(d), int(np.float32(start).view(np.uint32)), 1 << 24)
     assert bad == 0
     eng.close()
+
+
+def test_int16_ingestion_equals_float32_path(tmp_path):
+    """adp_calibrate_i16 (raw ADC int16 + per-read scale/offset -> float32 pA on the device, NaN beyond the read) returns
+    the bits of numpy's scale * (adc.astype(float32) + offset), and the int16 pipeline's rows equal the float32 path's
+    on the same reads -- through the CLI too (--int16_ingest)."""
+    from adapted_amd import lib, main as cli
+    from adapted_amd.pipeline import HostPipeline
+
+    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    m = spc.sig_preload_size
+    n = case["n"]
+    rng = np.random.default_rng(8)
+    scale = rng.uniform(0.14, 0.2, n).astype(np.float32)
+    offset = rng.uniform(-20.0, 20.0, n).astype(np.float32)
+    # raw samples whose calibrated values resemble the golden case's signal; lengths as in the case (some reads are short)
+    raw = np.zeros((n, m), dtype=np.int16)
+    for i in range(n):
+        L = min(int(lens[i]), m)
+        raw[i, :L] = np.clip(np.rint(np.nan_to_num(sig[i, :L]) / scale[i] - offset[i]), -32768, 32767).astype(np.int16)
+    pa = np.full((n, m), np.nan, dtype=np.float32)
+    for i in range(n):
+        L = min(int(lens[i]), m)
+        pa[i, :L] = scale[i] * (raw[i, :L].astype(np.float32) + offset[i])
+
+    eng = lib.Engine(spc, n, m, device=0)
+    d_raw, d_len, d_cal, d_out = eng.dev_alloc(raw.nbytes), eng.dev_alloc(n * 4), eng.dev_alloc(2 * n * 4), eng.dev_alloc(n * m * 4)
+    eng.h2d(d_raw, raw); eng.h2d(d_len, lens.astype(np.int32)); eng.h2d(d_cal, np.stack([scale, offset]))
+    eng.calibrate_i16(d_raw, d_len, d_cal, d_cal + n * 4, n, d_out)
+    got = np.zeros((n, m), dtype=np.float32)
+    eng.d2h(got, d_out)
+    assert got.view(np.uint32)[~np.isnan(pa)].tobytes() == pa.view(np.uint32)[~np.isnan(pa)].tobytes()
+    assert (np.isnan(got) == np.isnan(pa)).all()
+    rows_f32, _ = eng.detect_llr_rows(pa, lens.astype(np.int32), n, case["minibatch"], with_start_peak=False)
+    for p in (d_raw, d_len, d_cal, d_out):
+        eng.dev_free(p)
+    eng.close()
+
+    mb = case["minibatch"]
+    pipe = HostPipeline(spc, mb, m, device=0, primary="llr", int16_input=True)
+    out = {}
+
+    def fill(get_buffers):
+        for k in range(0, n, mb):
+            braw, bl, bsc, bof = get_buffers()
+            kk = min(mb, n - k)
+            braw[:kk], bl[:kk], bsc[:kk], bof[:kk] = raw[k:k + kk], lens[k:k + kk], scale[k:k + kk], offset[k:k + kk]
+            yield kk, k
+
+    pipe.run(fill, lambda k, rows: out.__setitem__(k, rows.copy()))
+    pipe.close()
+    rows_i16 = np.concatenate([out[k] for k in sorted(out)])
+    assert rows_i16.tobytes() == rows_f32.tobytes()
+
+    # the CLI: a float32 bundle and the raw bundle of the same reads give the same CSV files
+    ids = np.array(["read_%04d" % i for i in range(n)], dtype=object)
+    np.savez(tmp_path / "f32_0.npz", signals=pa, full_lengths=lens, read_ids=ids)
+    np.savez(tmp_path / "raw_0.npz", raw=raw, scale=scale, offset=offset, full_lengths=lens, read_ids=ids)
+    cfg = tmp_path / "cfg.toml"
+    spc.to_toml(str(cfg))
+    texts = []
+    for name, extra in (("f32_0.npz", []), ("raw_0.npz", ["--int16_ingest"])):
+        o = tmp_path / ("out_" + name)
+        cli.main(["detect", "-i", str(tmp_path / name), "-o", str(o), "--config", str(cfg), "-s", str(mb), "-b", "4000"] + extra)
+        rd = o / [d for d in os.listdir(o) if d.startswith("adapted_")][0]
+        texts.append(((rd / "boundaries" / "detected_boundaries_0.csv").read_text(), (rd / "failed_reads" / "failed_reads_0.csv").read_text()))
+    assert texts[0] == texts[1]
