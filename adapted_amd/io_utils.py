@@ -46,10 +46,12 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
         z = np.load(filename, allow_pickle=True)
         ids = [str(x) for x in z["read_ids"]]
         lens = z["full_lengths"]
+        dense = z["signals"] if "signals" in z else None  # (an NpzFile re-reads the array on every access: fetch it once)
+        sel = set(selection) if selection is not None else None
         for i, rid in enumerate(ids):
-            if selection is not None and rid not in selection:
+            if sel is not None and rid not in sel:
                 continue
-            sig = z["signals"][i] if "signals" in z else z["signal_%d" % i]
+            sig = dense[i] if dense is not None else z["signal_%d" % i]
             yield rid, int(lens[i]), sig
     else:
         try:
@@ -111,10 +113,12 @@ def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
             raise ValueError("%s holds no raw ADC samples (keys raw / raw_<i>, scale, offset)" % filename)
         ids = [str(x) for x in z["read_ids"]]
         lens, scale, offset = z["full_lengths"], z["scale"], z["offset"]
+        dense = z["raw"] if "raw" in z else None
+        sel = set(selection) if selection is not None else None
         for i, rid in enumerate(ids):
-            if selection is not None and rid not in selection:
+            if sel is not None and rid not in sel:
                 continue
-            sig = z["raw"][i] if "raw" in z else z["raw_%d" % i]
+            sig = dense[i] if dense is not None else z["raw_%d" % i]
             yield rid, int(lens[i]), sig, float(scale[i]), float(offset[i])
     else:
         try:
