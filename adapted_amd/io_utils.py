@@ -63,8 +63,19 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
                 yield str(rec.read_id), int(rec.num_samples), rec.signal_pa
 
 
+def _copy_pool(workers: Optional[int]):
+    """row copies of a minibatch run on a small thread pool (numpy releases the GIL while it copies): one thread moves
+    ~10 GB/s = 12 k reads/s of 200 k-sample float32 reads, far below what PCIe and the GPU take"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    if workers is None:
+        workers = min(8, os.cpu_count() or 1)
+    return ThreadPoolExecutor(max_workers=workers) if workers > 1 else None
+
+
 def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                      preload_size: int, buffers=None) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
+                      preload_size: int, buffers=None, workers: Optional[int] = None
+                      ) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
     """buffers: optional callable returning (signals float32 [batch_size, preload_size], lengths int32 [batch_size]) to
     fill IN PLACE for the next minibatch (pinned staging memory of adapted_amd.pipeline); called when the first read of
     a minibatch arrives, never while the previous minibatch's arrays may still be in use by the consumer of the yield."""
@@ -81,28 +92,48 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
             return sig, lens, np.empty(N, dtype=object)
         return np.empty((N, m), dtype=np.float32), np.empty(N, dtype=np.int32), np.empty(N, dtype=object)
 
+    pool = _copy_pool(workers)
+    pending = []
+
+    def put_row(dst, signal, n_samples):
+        s = np.asarray(signal[:m], dtype=np.float32)
+        take = min(m, n_samples, s.size)
+        dst[:take] = s[:take]
+        if take < m:
+            dst[take:] = np.nan
+
+    def finish():
+        for f in pending:
+            f.result()
+        pending.clear()
+
     sig = lens = ids = None
     k = 0
-    for fn in files:
-        for rid, n_samples, signal in _iter_reads(fn, selection):
-            if rid in read_ids_excl:
-                continue
-            if sig is None:
-                sig, lens, ids = fresh()
-            s = np.asarray(signal[:m], dtype=np.float32)
-            take = min(m, n_samples, s.size)
-            sig[k, :take] = s[:take]
-            if take < m:
-                sig[k, take:] = np.nan
-            lens[k] = n_samples
-            ids[k] = rid
-            k += 1
-            if k == N:
-                yield sig, lens, ids
-                sig = None
-                k = 0
-    if k:
-        yield sig[:k], lens[:k], ids[:k]
+    try:
+        for fn in files:
+            for rid, n_samples, signal in _iter_reads(fn, selection):
+                if rid in read_ids_excl:
+                    continue
+                if sig is None:
+                    sig, lens, ids = fresh()
+                if pool is not None:
+                    pending.append(pool.submit(put_row, sig[k], signal, n_samples))
+                else:
+                    put_row(sig[k], signal, n_samples)
+                lens[k] = n_samples
+                ids[k] = rid
+                k += 1
+                if k == N:
+                    finish()
+                    yield sig, lens, ids
+                    sig = None
+                    k = 0
+        if k:
+            finish()
+            yield sig[:k], lens[:k], ids[:k]
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
 
 
 def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
@@ -131,7 +162,7 @@ def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
 
 
 def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                          preload_size: int, buffers=None):
+                          preload_size: int, buffers=None, workers: Optional[int] = None):
     """Raw-ADC twin of yield_minibatches for the int16 ingestion path (adapted_amd.pipeline, int16_input=True):
     yields (raw int16 [n, preload_size] -- the tail of a short read is left untouched, the device writes NaN there --,
     lengths int32, scale float32, offset float32, ids).  pA = scale * (float32(adc) + offset) is applied on the device."""
@@ -148,26 +179,46 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
         return (np.zeros((N, m), dtype=np.int16), np.empty(N, dtype=np.int32), np.empty(N, dtype=np.float32),
                 np.empty(N, dtype=np.float32), np.empty(N, dtype=object))
 
+    pool = _copy_pool(workers)
+    pending = []
+
+    def put_row(dst, signal, n_samples, rid):
+        s = np.asarray(signal[:m], dtype=np.int16)
+        take = min(m, n_samples)
+        if s.size < take:
+            raise ValueError("read %s: %d samples stored, %d announced" % (rid, s.size, n_samples))
+        dst[:take] = s[:take]
+
+    def finish():
+        for f in pending:
+            f.result()
+        pending.clear()
+
     cur = None
     k = 0
-    for fn in files:
-        for rid, n_samples, signal, scale, offset in _iter_reads_i16(fn, selection):
-            if rid in read_ids_excl:
-                continue
-            if cur is None:
-                cur = fresh()
+    try:
+        for fn in files:
+            for rid, n_samples, signal, scale, offset in _iter_reads_i16(fn, selection):
+                if rid in read_ids_excl:
+                    continue
+                if cur is None:
+                    cur = fresh()
+                raw, lens, sc, of, ids = cur
+                if pool is not None:
+                    pending.append(pool.submit(put_row, raw[k], signal, n_samples, rid))
+                else:
+                    put_row(raw[k], signal, n_samples, rid)
+                lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
+                k += 1
+                if k == N:
+                    finish()
+                    yield raw, lens, sc, of, ids
+                    cur = None
+                    k = 0
+        if k:
+            finish()
             raw, lens, sc, of, ids = cur
-            s = np.asarray(signal[:m], dtype=np.int16)
-            take = min(m, n_samples)
-            if s.size < take:
-                raise ValueError("read %s: %d samples stored, %d announced" % (rid, s.size, n_samples))
-            raw[k, :take] = s[:take]
-            lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
-            k += 1
-            if k == N:
-                yield raw, lens, sc, of, ids
-                cur = None
-                k = 0
-    if k:
-        raw, lens, sc, of, ids = cur
-        yield raw[:k], lens[:k], sc[:k], of[:k], ids[:k]
+            yield raw[:k], lens[:k], sc[:k], of[:k], ids[:k]
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)

@@ -110,6 +110,11 @@ def host_pipeline_bench(args, spc, device):
     n_ok = [0]
     lock = threading.Lock()
 
+    from concurrent.futures import ThreadPoolExecutor
+
+    K = max(1, args.fill_threads)
+    ex = ThreadPoolExecutor(K) if K > 1 else None
+
     def fill(get_buffers, count, assemble=True):
         for i in range(count):
             bufs = get_buffers()
@@ -117,8 +122,13 @@ def host_pipeline_bench(args, spc, device):
             if i16:
                 bufs[2][:] = sc
                 bufs[3][:] = of
-            if assemble:  # (one thread's memcpy: the stand-in for a reader writing the minibatch)
-                np.copyto(sig, pool[i % len(pool)])
+            if assemble:  # (host memcpy: the stand-in for a reader writing the minibatch)
+                src = pool[i % len(pool)]
+                if ex is None:
+                    np.copyto(sig, src)
+                else:
+                    step = (mb + K - 1) // K
+                    list(ex.map(lambda a: np.copyto(sig[a:a + step], src[a:a + step]), range(0, mb, step)))
             ln[:] = lens
             yield mb, ids
 
@@ -141,7 +151,7 @@ def host_pipeline_bench(args, spc, device):
                       "value": total / dt, "unit": "reads/s", "n_gpus": 1, "minibatches": args.host_pipeline,
                       "h2d_GB_per_s": gb / dt, "pass_rate": n_ok[0] / max(total + total2, 1),
                       "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * m * bps / 1e9 / dt2},
-                      "input": "int16 ADC + device calibration" if i16 else "float32 pA",
+                      "input": "int16 ADC + device calibration" if i16 else "float32 pA", "fill_threads": K,
                       "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}}))
 
 
@@ -165,6 +175,7 @@ def main():
                     help="instead of the resident benchmark: stream N minibatches from HOST memory through adapted_amd.pipeline "
                          "(pinned staging, H2D overlapped with detect) and print the PCIe-inclusive rate -- never the headline value")
     ap.add_argument("--group", type=int, default=4, help="with --host-pipeline: minibatches per staging slot / detect call")
+    ap.add_argument("--fill-threads", type=int, default=1, help="with --host-pipeline: host threads copying a slot's reads (the stand-in reader)")
     ap.add_argument("--int16", action="store_true", help="with --host-pipeline: stream raw int16 ADC samples and calibrate on the device")
     args = ap.parse_args()
 
