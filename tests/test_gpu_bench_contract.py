@@ -1,0 +1,36 @@
+"""bench.py prints ONE JSON line with the fields the driver reads (metric/value/unit/n_gpus/steps/warmup/ms_per_step/
+higher_is_better/scaling/vs_baseline/dtype/data/config) plus the roofline and cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_json_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "2000", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample", "40"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2000 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert "differ from it in 0 fields" in c["sample"]
