@@ -17,6 +17,7 @@
 // so every lane reproduces the reference's partial sums exactly while 64 split points are
 // evaluated in parallel.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "log_cr.h"
 #include "wave_stats.h"
@@ -159,6 +160,8 @@ static __device__ __forceinline__ double div_by_len(double a, double b, double y
     return __builtin_fma(r, y, q0);
 }
 
+// the library log for zero / negative / subnormal / non-finite arguments: out of line, it is next to never called
+static __device__ __noinline__ double gains_log_slow(double u) { return log(u); }
 static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, int len)
 {
     const double dl = (double)len, y = recip_refined(dl);
@@ -183,7 +186,7 @@ static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, doubl
 #define GAINS_WPB 4 // waves (reads) per block
 #endif
 template <int PASS>
-__global__ void __launch_bounds__(64 * GAINS_WPB) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
+__global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int nck,
                                               const double2 *__restrict__ ck, const double2 *__restrict__ tail,
                                               const int32_t *__restrict__ adapter_idx, int mbsize,
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
@@ -202,7 +205,7 @@ __global__ void __launch_bounds__(64 * GAINS_WPB) k_gains(const float *__restric
     __syncthreads();
     if (r >= n_reads) return;
     const LDS double *lt = (const LDS double *)lt_;
-    auto flog = [&](double v) { return log_cr_impl(v, lt, [](double u) { return log(u); }); };
+    auto flog = [&](double v) { return log_cr_impl(v, lt, [](double u) { return gains_log_slow(u); }); };
     if (mbs[r / mbsize].status != ADP_MB_OK) return;
     const int n = nvalid[r];
     if (n <= 0) return;
@@ -251,42 +254,65 @@ __global__ void __launch_bounds__(64 * GAINS_WPB) k_gains(const float *__restric
         double a = 0.0, b = 0.0;
         if (i0 < n) { double2 p = c[i0 / CK]; a = p.x; b = p.y; }
         double mx = -__builtin_inf(), mn = __builtin_inf();
-#pragma unroll GAINS_UNROLL
-        for (int tq = 0; tq < CK / 4; tq++) {
-            const float4 q4 = s4[tq];
-            const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int t = tq * 4 + u;
-            const int i = i0 + t;
+        // INTERIOR tiles -- every point has both segments and lies inside the read -- take a body without the range
+        // tests, and the rare values (NaN, infinities) leave the straight path through branches: the kernel is bound
+        // by float64 instruction issue, and scalar branches cost no vector slots where selects do.
+        auto point = [&](auto interior_c, int t, int i, float qf) {
+            constexpr bool INTERIOR = decltype(interior_c)::value;
             double gi = 0.0;
-            if (i < n) {
-                if (i >= start + oh && i < E - ot) {
+            if (INTERIOR || i < n) {
+                if (INTERIOR || (i >= start + oh && i < E - ot)) {
                     double vh = var_seg(b, c2s, a, cs, i - start);
                     double vt = var_seg(te.y, b, te.x, a, E - i);
-                    double h = (double)(i - start) * flog(vh);
-                    double tl = (double)(E - i) * flog(vt);
+                    // both logarithms side by side (independent instruction streams), exceptions patched afterwards
+                    double lh = log_cr_fast(vh, lt), ll = log_cr_fast(vt, lt);
+                    if (!(log_cr_ok(vh) && log_cr_ok(vt))) {
+                        if (!log_cr_ok(vh)) lh = gains_log_slow(vh);
+                        if (!log_cr_ok(vt)) ll = gains_log_slow(vt);
+                    }
+                    double h = (double)(i - start) * lh;
+                    double tl = (double)(E - i) * ll;
                     gi = vs - (h + tl);
                 }
-                if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = max(last_pos, i); }
+                if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = i; } // (i grows along a lane)
+                const bool finite = __builtin_fabs(gi) < __builtin_inf();
                 if (PASS == 1) { if (gi == gi) { st_s1 += gi; st_s2 += gi * gi; } else st_nan++; }
                 if (PASS == 1 && !sanitize) {
-                    double m1 = (gi != gi) ? __builtin_inf() : gi;
-                    mx = m1 > mx ? m1 : mx;
-                    if (gi == gi) mn = gi < mn ? gi : mn;
+                    if (finite) { mx = gi > mx ? gi : mx; mn = gi < mn ? gi : mn; }
+                    else {
+                        double m1 = (gi != gi) ? __builtin_inf() : gi;
+                        mx = m1 > mx ? m1 : mx;
+                        if (gi == gi) mn = gi < mn ? gi : mn;
+                    }
                 } else {
                     double x = gi;
-                    if (x != x) x = 0.0;
-                    else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+                    if (!finite) x = (x != x) ? 0.0 : (x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308);
                     mx = x > mx ? x : mx;
                     mn = x < mn ? x : mn;
                 }
-                double v = (double)qv[u];
+                double v = (double)qf;
                 a += v;
                 b += v * v;
             }
             sg[ln * (CK + 1) + t] = gi;
-        }
+        };
+        const bool interior = tb >= start + oh && tb + TRACE_TILE <= E - ot; // (then also tb + TRACE_TILE <= n)
+        if (interior) {
+#pragma unroll GAINS_UNROLL
+            for (int tq = 0; tq < CK / 4; tq++) {
+                const float4 q4 = s4[tq];
+                const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) point(std::true_type{}, tq * 4 + u, i0 + tq * 4 + u, qv[u]);
+            }
+        } else {
+#pragma unroll GAINS_UNROLL
+            for (int tq = 0; tq < CK / 4; tq++) {
+                const float4 q4 = s4[tq];
+                const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int u = 0; u < 4; u++) point(std::false_type{}, tq * 4 + u, i0 + tq * 4 + u, qv[u]);
+            }
         }
         // 4 lanes = one 64-point summary block
         {
