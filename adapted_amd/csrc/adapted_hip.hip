@@ -77,7 +77,11 @@ static int geom(adp_handle *h)
     if (c.downscale_factor < 1 || c.downscale_factor > 32 || c.sp_downscale_factor < 1 || c.sp_downscale_factor > 64) {
         g_err = "downscale_factor must be in [1, 32]"; return ADP_ERR_UNSUPPORTED;
     }
-    if (c.mvs_detect_overwrite) { g_err = "mvs_detect_overwrite=true is not implemented"; return ADP_ERR_UNSUPPORTED; }
+    if (c.mvs_detect_overwrite && c.mvs_detect_check) {
+        // mvs.py:264-266 reads the series at 2 * offset when nothing is found: an IndexError in the reference otherwise
+        const int off = c.pA_mean_window > c.pA_var_window ? c.pA_mean_window : c.pA_var_window;
+        if (c.search_window <= off || c.search_window < 1) { g_err = "mvs_detect_overwrite needs search_window > max(pA_mean_window, pA_var_window)"; return ADP_ERR_UNSUPPORTED; }
+    }
     if (c.polya_cand_k > ADP_MAX_CAND - 1) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
     if (h->m > BS_MAXCHUNK * 8192) { g_err = "preload longer than 1 Mi samples: k_partition_stats keeps one chunk sum per 8192 samples in LDS"; return ADP_ERR_UNSUPPORTED; }
     if ((c.max_obs_trace - c.min_obs_adapter) / c.downscale_factor > 400000) { g_err = "max_obs_trace too large for the LDS state of k_polya_peak"; return ADP_ERR_UNSUPPORTED; }
@@ -315,7 +319,7 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
     in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
     in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>();
-    if (h->cfg.mvs_detect_check) {
+    if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
         Scope s(h, "k_mvs_series");
         hipLaunchKernelGGL(k_mvs_series, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                            h->series.as<float>(), h->have_series.as<int8_t>());

@@ -695,7 +695,8 @@ struct PartReq {
     int32_t S;          // samples available: min(full_len, m)
     int64_t a_s, a_e, p_e;
     float adapter_med, adapter_mad;
-    int32_t have_adapter_medmad, pad;
+    int32_t have_adapter_medmad;
+    int32_t p_none;     // polya_end is None (mvs_detect_overwrite): poly(A) keeps its start only, the RNA partition is all None
 };
 
 // grid = n_reads blocks of 256 threads
@@ -719,9 +720,10 @@ __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(const float *
     const int c_len[3] = {ADP_C_ADAPTER_LEN, ADP_C_POLYA_LEN, ADP_C_RNA_LEN};
     for (int p = 0; p < 3; p++) {
         const long long st = starts[p], en = ends[p];
+        if (p == 2 && q.p_none) continue;
         if (threadIdx.x == 0) row->col[c_start[p]] = (double)st;
         present |= 1ull << c_start[p];
-        if (en <= st) continue;
+        if (en <= st || (p == 1 && q.p_none)) continue;
         long long a = st < S ? st : S, b = en < S ? en : S;
         int n = (int)(b - a);
         SegStats s;

@@ -320,6 +320,66 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     return o;
 }
 
+// mvs_detect_overwrite: mean_var_shift_polyA_detect_at_loc(signal, loc = adapter_end, less_signal_ok = False)
+// (reference adapted/detect/mvs.py:181-338).  The moving mean / variance of signal[loc - offset, loc + search_window)
+// (offset = the longer window) are scanned for the first position with both in range; the array comparisons are
+// float32 against the bounds cast to float32 (numpy 1.x value-based casting, utils.py:26), the scalar checks float64.
+struct MvsLoc { int ok, exc; long long idx; double mean, var, med, lrange, shift; };
+
+static __device__ __forceinline__ bool in_range_f32(float v, double lo, double hi) { return (float)lo <= v && v <= (float)hi; }
+
+static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S, long long loc, const adp_cfg &cfg, double pr0, double pr1,
+                                                        LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
+                                                        float med_before_loc)
+{
+    MvsLoc o; o.ok = 0; o.exc = 0; o.idx = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
+    const int wm = cfg.pA_mean_window, wv = cfg.pA_var_window;
+    const int offset = wm > wv ? wm : wv;
+    const int tailw = cfg.median_shift_window > cfg.polyA_window ? cfg.median_shift_window : cfg.polyA_window;
+    if ((long long)S < loc + cfg.search_window + tailw) return o; // not enough signal after loc (:216-231)
+    if (loc < offset) return o;                                   // ... or before it (:234-247)
+    const int n = offset + cfg.search_window;
+    const float *x = sig + (loc - offset);
+    if (wm < 1 || wv < 1) { o.exc = ADP_F_EXC_MOVE_WINDOW; return o; } // (windows longer than the slice cannot occur)
+    __syncthreads();
+    // the series hold the outputs from index window-1 on (the first window-1 are NaN in bottleneck: never in range)
+    if (wv <= MV_HIST && wm <= MV_HIST) wave_move_series(x, n, wv, wm, true, true, scr_var, scr_mean, ws);
+    else {
+        if (lane_id() == 0) bn_move_var(x, n, wv, scr_var);
+        if (lane_id() == 1) bn_move_mean(x, n, wm, scr_mean);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (sc && lane_id() == 0) sc->n = 0;
+    __syncthreads();
+    int idx = 0;
+    for (int base = offset - 1; base < n; base += 64) {
+        const int i = base + lane_id();
+        const bool hit = i < n && in_range_f32(scr_mean[i - wm + 1], pr0, pr1) &&
+                         in_range_f32(scr_var[i - wv + 1], cfg.pA_var_range[0], cfg.pA_var_range[1]);
+        const unsigned long long mk = __ballot(hit);
+        if (mk) { idx = base + __ffsll((long long)mk) - 1; break; }
+    }
+    const int at = idx > 0 ? idx : 2 * offset; // not found: the values one window lag behind loc (set_config: 2*offset < n)
+    o.mean = (double)scr_mean[at - wm + 1];
+    o.var = (double)scr_var[at - wv + 1];
+    long long ix = idx > 0 ? (long long)idx + loc - offset : 0;
+    o.idx = ix;
+    const long long loc_ = loc > ix ? loc : ix;
+    long long e1 = loc_ + cfg.polyA_window; if (e1 > S) e1 = S;
+    long long e2 = loc_ + cfg.median_shift_window; if (e2 > S) e2 = S;
+    const float *y = sig + loc_;
+    const float fmed = wave_median(y, (int)(e1 - loc_), 0, 0.f, ws, sc);
+    o.med = (double)fmed;
+    o.lrange = wave_percentile(y, (int)(e1 - loc_), 85.0, ws, sc) - wave_percentile(y, (int)(e1 - loc_), 15.0, ws, sc);
+    const float before = (loc_ == loc) ? med_before_loc : wave_median(sig, (int)loc_, 0, 0.f, ws, sc);
+    o.shift = (double)(wave_median(y, (int)(e2 - loc_), 0, 0.f, ws, sc) - before);
+    o.ok = idx > 0 && in_range_d(o.med, cfg.polyA_med_range[0], cfg.polyA_med_range[1]) &&
+           in_range_d(o.lrange, cfg.polyA_local_range[0], cfg.polyA_local_range[1]) &&
+           in_range_d(o.shift, cfg.median_shift_range[0], cfg.median_shift_range[1]);
+    return o;
+}
+
 // ---------------------------------------------------------------- V4 moving mean / variance series, ahead of time
 // The bottleneck recurrences are strictly sequential per read; inside k_validate they would occupy one
 // lane of a wave.  They only depend on (adapter_end, first poly(A) candidate), which are known before
@@ -390,6 +450,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
         const long long p_in = in.kmax > 0 ? bd[1] : 0;
         const bool topk_none = in.topk_none ? in.topk_none[r] != 0 : false;
         long long a_s = 0, a_e = a_in, p_best = p_in;
+        bool p_none = false; // polya_end_best became None (mvs_detect_overwrite)
         int success = 1, fail = ADP_F_NONE, mvs_mask = 0;
         float adapter_med = 0.f, adapter_mad = 0.f;
         bool have_med = false;
@@ -479,7 +540,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
                 // several candidates, no prepared series: run the recurrences ONCE up to the largest candidate (they are
                 // causal: every other candidate's series is a prefix) into this slot's scratch
                 const float *own_mean = nullptr, *own_var = nullptr;
-                if (p_series == 0 && !exception && in.kmax > 1 && bd[1] != 0 && bd[2] != 0 && cfg.pA_var_window <= MV_HIST &&
+                if (p_series == 0 && !exception && !cfg.mvs_detect_overwrite && in.kmax > 1 && bd[1] != 0 && bd[2] != 0 && cfg.pA_var_window <= MV_HIST &&
                     cfg.pA_mean_window <= MV_HIST && cfg.pA_var_window >= 1 && cfg.pA_mean_window >= 1) {
                     long long pmx = 0;
                     for (int c = 0; c < in.kmax; c++) { const long long pc = bd[1 + c]; if (pc == 0) break; if (pc > pmx) pmx = pc; }
@@ -494,6 +555,24 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
                 for (int c = 0; !exception && c < in.kmax; c++) {
                     long long p_e = bd[1 + c];
                     if (p_e == 0) break;
+                    if (cfg.mvs_detect_overwrite) {
+                        // combined.py:517-562: the adapter end moves to the position the MVS scan finds behind it
+                        const MvsLoc o = mvs_detect_at_loc(sig, S, a_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, adapter_med);
+                        if (o.exc) { row_exception(row, o.exc); exception = true; break; }
+                        rw.set(ADP_C_MVS_ADAPTER_END, (double)o.idx);
+                        rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
+                        rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);
+                        rw.set(ADP_C_MVS_MED_SHIFT, o.shift);
+                        if (!o.ok) { success = 0; fail = ADP_F_NO_ADAPTER_MVS; break; } // (the other candidates would repeat this evaluation)
+                        if (o.idx - a_e > 0) {
+                            a_e = o.idx;
+                            // Boundaries.polya_end_adjust / .polya_truncated / .trace_early_stop_pos are None on every call
+                            // path of v0.2.4: a poly(A) end behind the new adapter end becomes None (combined.py:546-561)
+                            if (a_e > p_e) { p_none = true; mvs_mask |= ADP_MVS_TO_EARLY_STOP; }
+                        }
+                        p_best = p_e;
+                        break;
+                    }
                     const bool pre = p_series > 0 && p_e <= p_series;
                     const float *pm = !pre ? nullptr : (own_mean ? own_mean : in.series + (size_t)r * 2 * MVS_CAP);
                     const float *pv = !pre ? nullptr : (own_var ? own_var : in.series + (size_t)r * 2 * MVS_CAP + MVS_CAP);
@@ -526,11 +605,11 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
             PartReq q;
             q.valid = 1; q.S = S; q.a_s = a_s; q.a_e = a_e; q.p_e = p_best;
             q.adapter_med = adapter_med; q.adapter_mad = adapter_mad;
-            q.have_adapter_medmad = (have_med && a_s == 0) ? 1 : 0; q.pad = 0;
+            q.have_adapter_medmad = (have_med && a_s == 0 && a_e == a_in) ? 1 : 0; q.p_none = p_none ? 1 : 0;
             preq[r] = q;
         }
         rw.set(ADP_C_ADAPTER_END, (double)a_e);
-        rw.set(ADP_C_POLYA_END, (double)p_best);
+        if (!p_none) rw.set(ADP_C_POLYA_END, (double)p_best);
         rw.set(ADP_C_SIGNAL_LEN, (double)full_len);
         rw.set(ADP_C_PRELOADED, (double)S);
         rw.set(ADP_C_PRIMARY_ADAPTER_END, (double)a_in);

@@ -191,7 +191,7 @@ def detect_rows_device(eng, dsig: int, dlen: int, n: int, lens_host: np.ndarray,
     rows = eng.validate_rows(dsig, dlen, n, bounds, device_ptrs=True)
     if spc.cnn_boundaries.fallback_to_llr_short_reads:
         ae, pe = bounds[:, 0], bounds[:, 1]
-        need = ((rows["success"] == 0) & (rows["fail_code"] < 9) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
+        need = ((rows["success"] == 0) & ~((rows["fail_code"] >= 9) & (rows["fail_code"] <= 14)) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
                 & (lens_host.astype(np.int64) < 2 * core.max_obs_adapter))
         idx = np.flatnonzero(need)
         if idx.size:
@@ -228,7 +228,7 @@ def detect_rows(eng, sig: np.ndarray, lens: np.ndarray, model, spc) -> np.ndarra
     if spc.cnn_boundaries.fallback_to_llr_short_reads:
         # C4 "hail mary" for short reads (combined.py:251-301)
         ae, pe = bounds[:, 0], bounds[:, 1]
-        need = ((rows["success"] == 0) & (rows["fail_code"] < 9) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
+        need = ((rows["success"] == 0) & ~((rows["fail_code"] >= 9) & (rows["fail_code"] <= 14)) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
                 & (lens.astype(np.int64) < 2 * spc.core.max_obs_adapter))
         idx = np.flatnonzero(need)
         if idx.size:

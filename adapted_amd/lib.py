@@ -18,7 +18,7 @@ from .container_types import DetectResults
 
 _LIB = None
 
-NCOL = 38
+NCOL = 39
 MAX_CAND = 16
 MAX_OPEN_PORES = 16
 
@@ -34,9 +34,9 @@ COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len"
         "{primary}_adapter_end", "{primary}_polya_end", "mvs_detect_mean_at_loc",
         "mvs_detect_var_at_loc", "mvs_detect_polya_med", "mvs_detect_polya_local_range",
         "mvs_detect_med_shift", "real_adapter_mean_start", "real_adapter_mean_end",
-        "real_adapter_local_range"]
+        "real_adapter_local_range", "mvs_adapter_end"]
 assert len(COLS) == NCOL
-_INT_COLS = {0, 1, 2, 3, 4, 9, 10, 11, 16, 17, 22, 24, 26, 28, 29}
+_INT_COLS = {0, 1, 2, 3, 4, 9, 10, 11, 16, 17, 22, 24, 26, 28, 29, 38}
 # columns the reference holds as numpy float32 scalars (kept as float32 so that the CSV
 # writer rounds them like pandas does)
 _F32_COLS = {23, 25, 27}
@@ -61,6 +61,7 @@ FAIL_REASONS = {
     12: "pA_mean_range is not specified",
     13: "attempt to get argmin of an empty sequence",
     14: "MAD normalization failed: scale is 0",
+    15: "No adapter detected in range (mvs_detect)",
 }
 _MVS_NAMES = ["mean", "var", "med", "range", "shift"]
 START_PEAK_TYPES = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
@@ -187,7 +188,7 @@ def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
     names = [c.format(primary=primary) for c in COLS]
     for r in rows:
         fc = int(r["fail_code"])
-        if fc >= 9:  # the reference raised inside its per-read try block
+        if 9 <= fc <= 14:  # the reference raised inside its per-read try block
             out.append(DetectResults(success=False, fail_reason=fail_reason_of(r)))
             continue
         d = DetectResults(success=bool(r["success"]))
@@ -210,7 +211,7 @@ def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
         if no >= 0:
             d.open_pores = np.asarray(r["open_pores"][:min(no, MAX_OPEN_PORES)], dtype=np.int64)
         d.mvs_llr_polya_end_adjust_ignored = False
-        d.mvs_llr_polya_end_to_early_stop = False
+        d.mvs_llr_polya_end_to_early_stop = bool(int(r["mvs_fail_mask"]) >> 8 & 1)  # (mvs_detect_overwrite only)
         fr = fail_reason_of(r)
         spt = START_PEAK_TYPES[int(r["start_peak_type"])]
         d.start_peak_open_pore_type = spt

@@ -1,7 +1,7 @@
 """Multi-GPU layout of ``adapted detect``: one process per GPU, reads sharded in WHOLE
 minibatches (the LLR path normalises per minibatch -- reference adapted/detect/normalize.py:
 15-22 -- so results do not depend on the GPU count), no collective on the data path, and ONE
-gather of the fixed-width result rows (528 B each) to the writer rank.  With the "nccl"
+gather of the fixed-width result rows (536 B each) to the writer rank.  With the "nccl"
 backend (= RCCL over xGMI on ROCm) the gather runs on device tensors; the same code runs on
 "gloo"/CPU tensors (used by the world_size-2 CPU tests)."""
 from __future__ import annotations

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ADP_ABI_VERSION 1
+#define ADP_ABI_VERSION 2
 
 /* error codes */
 #define ADP_OK 0
@@ -91,6 +91,7 @@ enum adp_col {
     ADP_C_MED_SHIFT, ADP_C_PRIMARY_ADAPTER_END, ADP_C_PRIMARY_POLYA_END,
     ADP_C_MVS_MEAN, ADP_C_MVS_VAR, ADP_C_MVS_POLYA_MED, ADP_C_MVS_LOCAL_RANGE, ADP_C_MVS_MED_SHIFT,
     ADP_C_REAL_MEAN_START, ADP_C_REAL_MEAN_END, ADP_C_REAL_LOCAL_RANGE,
+    ADP_C_MVS_ADAPTER_END,             /* mvs_detect_overwrite: position found by the MVS scan, 0 if none (combined.py:523) */
     ADP_NCOL
 };
 
@@ -105,14 +106,19 @@ enum adp_fail {
     ADP_F_MVS_NOT_ENOUGH = 6,   /* "MVS polya check failed: not enough signal" */
     ADP_F_MVS_CHECKS = 7,       /* "MVS polya check failed: " + names from mvs_fail_mask */
     ADP_F_MED_SHIFT = 8,        /* "Median shift check failed" */
-    /* >= 9: the reference raised inside the per-read try block; the row is all-None */
+    /* 9..14: the reference raised inside the per-read try block; the row is all-None */
     ADP_F_EXC_TOPK_NONE = 9,    /* "'NoneType' object is not iterable" (combined.py:464) */
     ADP_F_EXC_SLICE = 10,       /* "slice indices must be integers or None or have an __index__ method" */
     ADP_F_EXC_MOVE_WINDOW = 11, /* bottleneck: moving window larger than the slice */
     ADP_F_EXC_PA_RANGE = 12,    /* "pA_mean_range is not specified" (combined.py:462) */
     ADP_F_EXC_EMPTY_TRACE = 13, /* "attempt to get argmin of an empty sequence" (CNN fallback, llr.py:136) */
-    ADP_F_EXC_MAD_ZERO = 14     /* "MAD normalization failed: scale is 0" (CNN fallback, normalize.py:56-59) */
+    ADP_F_EXC_MAD_ZERO = 14,    /* "MAD normalization failed: scale is 0" (CNN fallback, normalize.py:56-59) */
+    ADP_F_NO_ADAPTER_MVS = 15   /* "No adapter detected in range (mvs_detect)" (mvs_detect_overwrite, combined.py:540) */
 };
+#define ADP_F_IS_EXCEPTION(code) ((code) >= 9 && (code) <= 14)
+/* adp_row.mvs_fail_mask bit 8: mvs_llr_polya_end_to_early_stop (mvs_detect_overwrite moved the adapter end past the
+ * poly(A) end; the reference then takes Boundaries.trace_early_stop_pos, None on every v0.2.4 path: polya_end is None) */
+#define ADP_MVS_TO_EARLY_STOP 256
 
 #define ADP_MAX_CAND 16
 #define ADP_MAX_OPEN_PORES 16
@@ -123,7 +129,7 @@ typedef struct adp_row {
     uint64_t present;          /* bit c set <=> col[c] is not None */
     int32_t success;
     int32_t fail_code;         /* enum adp_fail */
-    int32_t mvs_fail_mask;     /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift failed */
+    int32_t mvs_fail_mask;     /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift failed; bit8 ADP_MVS_TO_EARLY_STOP */
     int32_t start_peak_type;   /* 0 None, 1 "open pore in adapter", 2 "potential concatemer adapter-only read" */
     int32_t n_cand;            /* polya_candidates length; -1 <=> None */
     int32_t n_open_pores;      /* open_pores length (may exceed ADP_MAX_OPEN_PORES); -1 <=> None */

@@ -81,6 +81,7 @@ enum { /* numeric columns, DetectResults field order (adapted/container_types.py
     C_MED_SHIFT, C_PRIMARY_ADAPTER_END, C_PRIMARY_POLYA_END,
     C_MVS_MEAN, C_MVS_VAR, C_MVS_POLYA_MED, C_MVS_LOCAL_RANGE, C_MVS_MED_SHIFT,
     C_REAL_MEAN_START, C_REAL_MEAN_END, C_REAL_LOCAL_RANGE,
+    C_MVS_ADAPTER_END,
     ORC_NCOL
 };
 
@@ -97,8 +98,11 @@ enum { /* fail codes <-> the reference's fail_reason strings (combined.py:396-58
     F_EXC_TOPK_NONE = 9,     /* TypeError: 'NoneType' object is not iterable (combined.py:464) */
     F_EXC_SLICE = 10,        /* TypeError: slice indices must be integers ... (start-peak None rows) */
     F_EXC_MOVE_WINDOW = 11,  /* ValueError from bottleneck: window > n */
-    F_EXC_PA_RANGE = 12      /* ValueError("pA_mean_range is not specified") */
+    F_EXC_PA_RANGE = 12,     /* ValueError("pA_mean_range is not specified") */
+    /* 13, 14: CNN fallback exceptions (see orc_cnn_fallback); 9..14 are the exception rows */
+    F_NO_ADAPTER_MVS = 15    /* "No adapter detected in range (mvs_detect)" (combined.py:540, mvs_detect_overwrite) */
 };
+#define MVS_FLAG_TO_EARLY_STOP 256 /* mvs_fail_mask bit 8: mvs_llr_polya_end_to_early_stop (combined.py:559-561) */
 
 #define ORC_MAX_CAND 16
 #define ORC_MAX_OPEN_PORES 16
@@ -108,7 +112,7 @@ typedef struct {
     uint64_t present;      /* bit c set <=> col[c] is not None */
     int32_t success;
     int32_t fail_code;
-    int32_t mvs_fail_mask; /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift FAILED */
+    int32_t mvs_fail_mask; /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift FAILED; bit8: polya_end set to the early-stop position */
     int32_t start_peak_type; /* 0 None, 1 "open pore in adapter", 2 "potential concatemer adapter-only read" */
     int32_t n_cand;        /* -1 <=> polya_candidates is None */
     int32_t n_open_pores;  /* -1 <=> open_pores is None; may exceed ORC_MAX_OPEN_PORES (list truncated) */
@@ -809,6 +813,52 @@ static mvs_out mvs_check(const float *sig, long S, long a_e, long p_e, const orc
     return o;
 }
 
+/* mean_var_shift_polyA_detect_at_loc(signal, loc, params, return_values=True, less_signal_ok=False)
+ * (adapted/detect/mvs.py:181-338): first position in [loc - offset, loc + search_window) whose moving mean and
+ * moving variance are both in range, then the poly(A) median / local range / median shift at max(loc, position).
+ * The array comparisons of in_range (utils.py:26) are float32 array against scalar bounds: numpy 1.x casts the
+ * bounds to float32 (value-based casting; the goldens were made with numpy 1.26), the scalar checks at the end
+ * compare Python floats (float64). */
+typedef struct { int ok, exc; long idx; double mean, var, med, lrange, shift; } mvs_loc_out;
+
+static int in_range_f32(float v, double lo, double hi) { return (float)lo <= v && v <= (float)hi; }
+
+static mvs_loc_out mvs_detect_at_loc(const float *sig, long S, long loc, const orc_cfg *cfg, const double *pA_mean_range)
+{
+    mvs_loc_out o; memset(&o, 0, sizeof(o));
+    const long wm = cfg->pA_mean_window, wv = cfg->pA_var_window;
+    const long offset = wm > wv ? wm : wv;
+    const long tailw = cfg->median_shift_window > cfg->polyA_window ? cfg->median_shift_window : cfg->polyA_window;
+    if (S < loc + cfg->search_window + tailw) return o; /* not enough signal after loc (:216-231) */
+    if (loc < offset) return o;                         /* not enough signal before loc (:234-247) */
+    const long n = offset + cfg->search_window;
+    const float *x = sig + (loc - offset);
+    if (wm < 1 || wv < 1 || wm > n || wv > n) { o.exc = F_EXC_MOVE_WINDOW; return o; }
+    float *mm = (float *)malloc(sizeof(float) * n), *mv = (float *)malloc(sizeof(float) * n);
+    /* bottleneck keeps the first window-1 outputs as NaN (min_count = window): full-length series here */
+    for (long i = 0; i < n; i++) mm[i] = mv[i] = NAN;
+    bn_move_mean_f32(x, n, wm, mm + wm - 1);
+    bn_move_var_f32(x, n, wv, mv + wv - 1);
+    long idx = 0;
+    for (long i = 0; i < n; i++)
+        if (in_range_f32(mm[i], pA_mean_range[0], pA_mean_range[1]) && in_range_f32(mv[i], cfg->pA_var_range[0], cfg->pA_var_range[1])) { idx = i; break; }
+    float mean, var;
+    if (idx > 0) { mean = mm[idx]; var = mv[idx]; idx += loc - offset; }
+    else { mean = mm[2 * offset]; var = mv[2 * offset]; } /* (2*offset < n is required of the config) */
+    free(mm); free(mv);
+    o.idx = idx; o.mean = (double)mean; o.var = (double)var;
+    const long loc_ = loc > idx ? loc : idx;
+    long e1 = loc_ + cfg->polyA_window; if (e1 > S) e1 = S;
+    long e2 = loc_ + cfg->median_shift_window; if (e2 > S) e2 = S;
+    o.med = (double)orc_np_median_f32(sig + loc_, e1 - loc_);
+    o.lrange = orc_np_percentile_diff_f32(sig + loc_, e1 - loc_, 85.0, 15.0);
+    o.shift = (double)(orc_np_median_f32(sig + loc_, e2 - loc_) - orc_np_median_f32(sig, loc_));
+    o.ok = idx > 0 && in_range(o.med, cfg->polyA_med_range[0], cfg->polyA_med_range[1]) &&
+           in_range(o.lrange, cfg->polyA_local_range[0], cfg->polyA_local_range[1]) &&
+           in_range(o.shift, cfg->median_shift_range[0], cfg->median_shift_range[1]);
+    return o;
+}
+
 /* V1 validate_boundaries.  sig = row[:full_len] => S = min(full_len, m) samples.
  * cand == NULL <=> polya_end_topk is None. */
 void orc_validate(const float *sig, long m, long full_len, long adapter_end_in, long polya_end_in,
@@ -817,6 +867,7 @@ void orc_validate(const float *sig, long m, long full_len, long adapter_end_in, 
     memset(r, 0, sizeof(*r));
     long S = full_len < m ? full_len : m;
     long a_s = 0, a_e = adapter_end_in, p_best = polya_end_in;
+    int p_none = 0; /* polya_end_best became None (mvs_detect_overwrite, combined.py:559-561) */
     int success = 1, fail = F_NONE;
     float adapter_med = 0, adapter_mad = 0; int have_med = 0;
     r->n_cand = -1; r->n_open_pores = -1;
@@ -875,6 +926,25 @@ void orc_validate(const float *sig, long m, long full_len, long adapter_end_in, 
             for (int c = 0; c < n_cand; c++) {
                 long p_e = (long)cand[c];
                 if (p_e == 0) break;
+                if (cfg->mvs_detect_overwrite) {
+                    /* combined.py:517-562: look for the adapter end in [loc, loc + search_window) by the MVS method */
+                    mvs_loc_out o = mvs_detect_at_loc(sig, S, a_e, cfg, pr);
+                    if (o.exc) { memset(r, 0, sizeof(*r)); r->n_cand = -1; r->n_open_pores = -1; r->success = 0; r->fail_code = o.exc; return; }
+                    row_set(r, C_MVS_ADAPTER_END, (double)o.idx);
+                    row_set(r, C_MVS_MEAN, o.mean); row_set(r, C_MVS_VAR, o.var);
+                    row_set(r, C_MVS_POLYA_MED, o.med); row_set(r, C_MVS_LOCAL_RANGE, o.lrange);
+                    row_set(r, C_MVS_MED_SHIFT, o.shift);
+                    int p_e_none = 0;
+                    if (!o.ok) { success = 0; fail = F_NO_ADAPTER_MVS; }
+                    else if (o.idx - a_e > 0) {
+                        a_e = o.idx;
+                        /* Boundaries.polya_end_adjust, .polya_truncated and .trace_early_stop_pos are None on every
+                         * v0.2.4 call path (combined.py:146-152, :324-328, cnn :280-300): the new poly(A) end is None */
+                        if (a_e > p_e) { p_e_none = 1; r->mvs_fail_mask |= MVS_FLAG_TO_EARLY_STOP; }
+                    }
+                    if (success) { p_best = p_e; p_none = p_e_none; break; }
+                    continue;
+                }
                 mvs_out o = mvs_check(sig, S, a_e, p_e, cfg, pr);
                 if (o.exc) { memset(r, 0, sizeof(*r)); r->n_cand = -1; r->n_open_pores = -1; r->success = 0; r->fail_code = o.exc; return; }
                 row_set(r, C_MVS_MEAN, o.mean); row_set(r, C_MVS_VAR, o.var);
@@ -899,11 +969,11 @@ void orc_validate(const float *sig, long m, long full_len, long adapter_end_in, 
         if (!in_range((double)sh, cfg->med_shift_range[0], cfg->med_shift_range[1])) { success = 0; fail = F_MED_SHIFT; }
     }
     partition_stats(sig, S, 1, a_s, 1, a_e, r, C_ADAPTER_START, C_ADAPTER_LEN);
-    partition_stats(sig, S, 1, a_e, 1, p_best, r, C_POLYA_START, C_POLYA_LEN);
-    partition_stats(sig, S, 1, p_best, 1, S, r, C_RNA_START, C_RNA_LEN);
+    partition_stats(sig, S, 1, a_e, !p_none, p_best, r, C_POLYA_START, C_POLYA_LEN);
+    partition_stats(sig, S, !p_none, p_best, 1, S, r, C_RNA_START, C_RNA_LEN);
     /* DetectResults(adapter_end=..., polya_end=...) are set explicitly (combined.py:603-604) */
     row_set(r, C_ADAPTER_END, (double)a_e);
-    row_set(r, C_POLYA_END, (double)p_best);
+    if (!p_none) row_set(r, C_POLYA_END, (double)p_best);
     row_set(r, C_SIGNAL_LEN, (double)full_len);
     row_set(r, C_PRELOADED, (double)S);
     row_set(r, C_PRIMARY_ADAPTER_END, (double)adapter_end_in);

@@ -21,13 +21,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness  # noqa: E402
 
 import numpy as np  # noqa: E402
-from golden_cases import CASES, resolve_lens  # noqa: E402
+from golden_cases import CASES, apply_overrides, resolve_lens  # noqa: E402
 
 _spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "adapted_amd", "synth.py"))
 synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
+CSV_CASES = ("rna004_llr_default", "rna004_llr_mvs_overwrite_wide")  # cases whose CSV text is kept as well
 
 
 def make_spc(case):
@@ -44,6 +45,7 @@ def make_spc(case):
         spc.mvs_polya.mvs_detect_check = case["mvs_detect_check"]
     if "detect_med_shift" in case:
         spc.med_shift.detect_med_shift = case["detect_med_shift"]
+    apply_overrides(spc, case)
     spc.update_primary_method()
     spc.update_sig_preload_size()
     return spc
@@ -236,8 +238,16 @@ def export_weights():
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "llr"
+    only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None  # e.g. llr rna004_llr_mvs_overwrite: just these cases
     os.makedirs(GOLD, exist_ok=True)
     ref_harness.install(need_torch=(what == "cnn"))
+    if what == "llr" and only:
+        for name in sorted(only):
+            results, spc, sig, lens = run_case(name, CASES[name])
+            print(name, "ok", sum(r.success for r in results), "/", len(results))
+            if name in CSV_CASES:
+                gen_csv(results, lens, name)
+        return
     if what == "llr":
         gen_bottleneck()
         for name, case in CASES.items():
@@ -245,7 +255,7 @@ def main():
                 continue
             results, spc, sig, lens = run_case(name, case)
             print(name, "ok", sum(r.success for r in results), "/", len(results))
-            if name == "rna004_llr_default":
+            if name in CSV_CASES:
                 gen_csv(results, lens, name)
         gen_start_peak_table()
     elif what == "cnn":

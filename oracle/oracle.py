@@ -23,11 +23,11 @@ COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len"
         "start_peak_next_max_pa", "start_peak_open_pore_idx", "adapter_rna_median_shift",
         "PRIMARY_adapter_end", "PRIMARY_polya_end", "mvs_detect_mean_at_loc", "mvs_detect_var_at_loc",
         "mvs_detect_polya_med", "mvs_detect_polya_local_range", "mvs_detect_med_shift",
-        "real_adapter_mean_start", "real_adapter_mean_end", "real_adapter_local_range"]
+        "real_adapter_mean_start", "real_adapter_mean_end", "real_adapter_local_range", "mvs_adapter_end"]
 INT_COLS = {"signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len", "polya_start",
             "polya_end", "polya_len", "rna_preloaded_start", "rna_preloaded_len", "start_peak_idx",
             "start_peak_next_max_idx", "start_peak_open_pore_idx", "PRIMARY_adapter_end",
-            "PRIMARY_polya_end"}
+            "PRIMARY_polya_end", "mvs_adapter_end"}
 MAX_CAND, MAX_OP = 16, 16
 
 ROW_DTYPE = np.dtype([("col", "<f8", (len(COLS),)), ("present", "<u8"), ("success", "<i4"),
@@ -48,7 +48,8 @@ FAIL_STR = {0: None, 1: "No adapter detected (primary)", 2: "adapter MAD check f
             11: "Moving window (=%d) must between 1 and %d, inclusive",
             12: "pA_mean_range is not specified",
             13: "attempt to get argmin of an empty sequence",
-            14: "MAD normalization failed: scale is 0"}
+            14: "MAD normalization failed: scale is 0",
+            15: "No adapter detected in range (mvs_detect)"}
 SP_TYPES = {0: None, 1: "open pore in adapter", 2: "potential concatemer adapter-only read"}
 PRIMARY = {"llr": 0, "cnn": 1, "start_peak": 2}
 
@@ -151,7 +152,7 @@ def rows_to_dicts(rows: np.ndarray, primary: str):
     """orc_row[] -> list of dicts with the DetectResults field names."""
     out = []
     for r in rows:
-        if r["fail_code"] >= 9:  # exception rows: DetectResults(success=False, fail_reason=str(e))
+        if 9 <= r["fail_code"] <= 14:  # exception rows: DetectResults(success=False, fail_reason=str(e))
             out.append({"success": False, "fail_reason": FAIL_STR[int(r["fail_code"])], "_exception": True})
             continue
         d = {"success": bool(r["success"])}
@@ -179,7 +180,7 @@ def rows_to_dicts(rows: np.ndarray, primary: str):
             fr = fr + "+" + spt
         d["fail_reason"] = fr
         d["mvs_llr_polya_end_adjust_ignored"] = False
-        d["mvs_llr_polya_end_to_early_stop"] = False
+        d["mvs_llr_polya_end_to_early_stop"] = bool(r["mvs_fail_mask"] >> 8 & 1)
         out.append(d)
     return out
 

@@ -37,10 +37,31 @@ CASES = {
     # start-peak primary with the preset's mvs check left on: polya_end_topk is None -> TypeError
     "rna004_start_peak_mvs": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=19,
                                   first=0, n=16, lens="full", minibatch=16, dump=[]),
+    # mvs_detect_overwrite = true (custom TOML only): the adapter end is moved to the MVS-detected position
+    # (reference adapted/detect/mvs.py:181-338, adapted/detect/combined.py:517-562)
+    "rna004_llr_mvs_overwrite": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=21, first=0, n=96,
+                                     lens="mixed", minibatch=96, dump=[],
+                                     override={"mvs_polya.mvs_detect_overwrite": True}),
+    # wide variance window: the new adapter end passes the poly(A) end of short tails -> polya_end becomes None
+    "rna004_llr_mvs_overwrite_wide": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=11, first=0, n=96,
+                                          lens="mixed", minibatch=96, dump=[],
+                                          override={"mvs_polya.mvs_detect_overwrite": True, "mvs_polya.pA_var_window": 600,
+                                                    "mvs_polya.search_window": 1200, "med_shift.detect_med_shift": True}),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
 }
+
+
+def apply_overrides(spc, case):
+    """case["override"]: {"section.field": value} set on the config tree (both the reference's and the mirror)."""
+    for key, val in (case.get("override") or {}).items():
+        obj = spc
+        parts = key.split(".")
+        for q in parts[:-1]:
+            obj = getattr(obj, q)
+        assert hasattr(obj, parts[-1]), key
+        setattr(obj, parts[-1], val)
 
 
 def resolve_lens(spec, n, m):

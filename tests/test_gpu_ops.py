@@ -65,10 +65,11 @@ def test_single_read_validator_equals_batch_rows():
         assert not row_diffs(got, w, float_rel=0.0), (i, row_diffs(got, w))
 
 
-def test_cli_detect_writes_reference_csv(tmp_path):
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide"])
+def test_cli_detect_writes_reference_csv(tmp_path, name):
     from adapted_amd import main as cli
 
-    case, spc, sig, lens, want = load_case("rna004_llr_default")
+    case, spc, sig, lens, want = load_case(name)
     ids = np.array(["read_%04d" % i for i in range(case["n"])], dtype=object)
     bundle = tmp_path / "reads_0.npz"
     np.savez(bundle, signals=sig, full_lengths=lens, read_ids=ids)
@@ -81,9 +82,9 @@ def test_cli_detect_writes_reference_csv(tmp_path):
     rd = out / run[0]
     for f in ("command.json", "config.toml", "adapted.log"):
         assert (rd / f).exists()
-    with open(os.path.join(GOLD, "rna004_llr_default.pass.csv")) as fh:
+    with open(os.path.join(GOLD, name + ".pass.csv")) as fh:
         assert (rd / "boundaries" / "detected_boundaries_0.csv").read_text() == fh.read()
-    with open(os.path.join(GOLD, "rna004_llr_default.fail.csv")) as fh:
+    with open(os.path.join(GOLD, name + ".fail.csv")) as fh:
         assert (rd / "failed_reads" / "failed_reads_0.csv").read_text() == fh.read()
     # `continue` finds every read already processed and writes nothing new
     cli.main(["continue", str(rd)])
@@ -221,3 +222,68 @@ def test_int16_ingestion_equals_float32_path(tmp_path):
         rd = o / [d for d in os.listdir(o) if d.startswith("adapted_")][0]
         texts.append(((rd / "boundaries" / "detected_boundaries_0.csv").read_text(), (rd / "failed_reads" / "failed_reads_0.csv").read_text()))
     assert texts[0] == texts[1]
+
+
+@pytest.mark.parametrize("windows", [dict(), dict(pA_var_window=600, search_window=1200), dict(pA_mean_window=150, pA_var_window=40, search_window=300),
+                                     dict(pA_var_window=320, pA_mean_window=321, search_window=700, polyA_window=2500)])
+def test_mvs_detect_overwrite_vs_oracle(oracle_mod, windows):
+    """mvs_detect_overwrite = true (reference adapted/detect/mvs.py:181-338, combined.py:517-562) on more reads than the
+    goldens hold, with windows on both sides of the LDS-staged series path (MV_HIST = 320): the LLR path end to end and the
+    candidate validator with a k-column table (the CNN path's entry), every field against the oracle."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+    spc.mvs_polya.mvs_detect_overwrite = True
+    spc.med_shift.detect_med_shift = True
+    for k, v in windows.items():
+        setattr(spc.mvs_polya, k, v)
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m, n, mb = spc.sig_preload_size, 384, 128
+    rng = np.random.default_rng(5)
+    lens = np.where(rng.random(n) < 0.7, m, rng.integers(1500, 3 * m, n)).astype(np.int32)
+    sig, lens = synth.synth_batch(31, 0, n, m, lens)
+    eng = lib.Engine(spc, n, m, device=0)
+    rows, mbs = eng.detect_llr_rows(sig, lens, n, mb)
+    assert (mbs == 0).all()
+    got = lib.rows_to_results(rows, "llr")
+    want = []
+    for s in range(0, n, mb):
+        want += oracle_mod.detect_llr(sig[s:s + mb], lens[s:s + mb], spc)
+    pub = lambda w: {k: v for k, v in w.items() if not k.startswith("_")}  # noqa: E731
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in [row_diffs(g, pub(w))] if d]
+    assert not bad, bad[:5]
+    moved = sum(1 for g in got if g.success and g.mvs_adapter_end and g.adapter_end == g.mvs_adapter_end)
+    assert moved > n // 4
+    # candidate tables as the CNN path hands them over: adapter end + 3 poly(A) candidates (0-terminated lists)
+    ae = np.array([g.llr_adapter_end or 0 for g in got], dtype=np.int64)
+    pe = np.array([g.llr_polya_end or 0 for g in got], dtype=np.int64)
+    bounds = np.stack([ae, pe, np.where(pe > 0, pe + 37, 0), np.zeros(n, dtype=np.int64)], axis=1)
+    bounds[::7, 1] = np.where(ae[::7] > 0, ae[::7] + 60, 0)  # tails shorter than the MVS lag: polya_end turns None
+    spc.cnn_boundaries.cnn_detect, spc.llr_boundaries.llr_detect = True, False
+    spc.cnn_boundaries.fallback_to_llr_short_reads = False  # (the validator alone)
+    spc.update_primary_method()
+    eng2 = lib.Engine(spc, n, m, device=0)
+    got2 = lib.rows_to_results(eng2.validate_rows(sig, lens, n, bounds), "cnn")
+    want2 = oracle_mod.detect_cnn_from_preds(sig, lens, bounds, spc)
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got2, want2)) for d in [row_diffs(g, pub(w))] if d]
+    assert not bad, bad[:5]
+    if not windows:
+        assert any(g.success and g.polya_end is None and g.mvs_llr_polya_end_to_early_stop for g in got2)
+    eng.close()
+    eng2.close()
+
+
+def test_mvs_detect_overwrite_rejects_a_search_window_inside_the_lag():
+    from adapted_amd import lib
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.mvs_polya.mvs_detect_overwrite = True
+    spc.mvs_polya.search_window = 100  # == pA_var_window: the reference indexes its series out of bounds (mvs.py:264)
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    with pytest.raises(lib.HipLibraryError, match="search_window"):
+        lib.Engine(spc, 8, spc.sig_preload_size, device=0)

@@ -93,18 +93,19 @@ def _results_from_golden(name):
     return out
 
 
-def test_csv_text_equals_reference(tmp_path):
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide"])
+def test_csv_text_equals_reference(tmp_path, name):
     from adapted_amd.output import CSV_COLUMNS, save_detected_boundaries
 
-    res = _results_from_golden("rna004_llr_default")
+    res = _results_from_golden(name)
     ok = [r for r in res if r.success]
     bad = [r for r in res if not r.success]
     p, f = tmp_path / "p.csv", tmp_path / "f.csv"
     save_detected_boundaries(ok, str(p), save_fail_reasons=False)
     save_detected_boundaries(bad, str(f), save_fail_reasons=True)
-    with open(os.path.join(GOLD, "rna004_llr_default.pass.csv")) as fh:
+    with open(os.path.join(GOLD, name + ".pass.csv")) as fh:
         assert p.read_text() == fh.read()
-    with open(os.path.join(GOLD, "rna004_llr_default.fail.csv")) as fh:
+    with open(os.path.join(GOLD, name + ".fail.csv")) as fh:
         assert f.read_text() == fh.read()
     header = p.read_text().splitlines()[0].split(",")
     assert header == CSV_COLUMNS and header[17] == "polya_truncated"  # scripts/get_truncated.sh: column 18
@@ -114,8 +115,8 @@ def test_abi_library_loads_and_exports_header_symbols():
     from adapted_amd import lib
 
     L = lib.load()
-    assert L.adp_abi_version() == 1
-    assert L.adp_sizeof_row() == lib.ROW_DTYPE.itemsize == 528
+    assert L.adp_abi_version() == 2
+    assert L.adp_sizeof_row() == lib.ROW_DTYPE.itemsize == 536
     assert L.adp_sizeof_cfg() == ctypes.sizeof(lib.AdpCfg)
     with open(os.path.join(ROOT, "include", "adapted_hip.h")) as fh:
         declared = set(re.findall(r"\b(adp_[a-z0-9_]+)\s*\(", fh.read()))

@@ -7,7 +7,7 @@ import numpy as np
 
 from adapted_amd import synth
 from adapted_amd.config import get_chemistry_specific_config
-from golden_cases import CASES, resolve_lens
+from golden_cases import CASES, apply_overrides, resolve_lens
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -30,6 +30,7 @@ def make_spc(case):
         spc.mvs_polya.mvs_detect_check = case["mvs_detect_check"]
     if "detect_med_shift" in case:
         spc.med_shift.detect_med_shift = case["detect_med_shift"]
+    apply_overrides(spc, case)
     spc.update_primary_method()
     spc.update_sig_preload_size()
     return spc
