@@ -53,6 +53,7 @@ struct BlockScratch {
     int scan[8];
     int bin, before, ncollect, nmad, flag;
     uint32_t below, cntb;
+    uint32_t kmin, kmax; // smallest / largest key copied out of the median's bucket (equal: the bucket holds ONE value)
     float bcast[4];
     int nleaf, tail_cached;
     short leaf_off[132], leaf_len[132], leaf_slot[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk, and their tree slots
@@ -146,6 +147,8 @@ static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS 
         if (kb == p.key) {
             int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (slot < BS_MEDCAP) bs_collect(bs)[slot] = v;
+            __hip_atomic_fetch_min(&bs->kmin, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(&bs->kmax, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (p.do_mad) {
             float dt = fabsf(v - p.c);
@@ -181,9 +184,12 @@ static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, fl
 // the copies of SIDE_COLLECT alone (dt < P is counted elsewhere)
 static __device__ __forceinline__ void bs_copy_exact(float v, const SideParam &p, LDS BlockScratch *bs)
 {
-    if ((f2key(v) >> BS_KSH) == p.key) {
+    const uint32_t key = f2key(v);
+    if ((key >> BS_KSH) == p.key) {
         int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (slot < BS_MEDCAP) bs_collect(bs)[slot] = v;
+        __hip_atomic_fetch_min(&bs->kmin, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&bs->kmax, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     if (p.do_mad) {
         const float dt = fabsf(v - p.c);
@@ -440,6 +446,61 @@ static __device__ __noinline__ uint32_t bs_max_key_below(const float *__restrict
     return best;
 }
 
+// The median's bucket holds more samples than the copy list (BS_MEDCAP): data with few distinct values, e.g. calibrated
+// int16 ADC samples (a step of ~0.18 pA is wider than a bucket, so thousands of samples share one key).  One more pass
+// counts the bucket's samples by their exact key -- 4096 counters in the staging area -- and notes the largest key below
+// the bucket; the median follows from the counts, whatever the multiplicities.
+static __device__ __noinline__ float bs_median_dense_bucket(const float *__restrict__ x_, int n, LDS BlockScratch *bs, uint32_t key_lo, int rk)
+{
+    const GLB float *x = (const GLB float *)x_;
+    const int tid = threadIdx.x;
+    LDS uint32_t *sub = (LDS uint32_t *)bs->u.stage; // 4096 counters (16 KB of the 17 KB staging area)
+    static_assert(sizeof(((BlockScratch *)0)->u.stage) >= 4096 * 4, "staging area too small for the key counters");
+    __syncthreads();
+    for (int i = tid; i < 4096; i += BS_THREADS) sub[i] = 0;
+    if (tid == 0) bs->below = 0;
+    __syncthreads();
+    uint32_t best = 0;
+    for (int base = 0; base < n; base += BS_THREADS * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = (i < n) ? x[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = base + u * BS_THREADS + tid;
+            if (i < n) {
+                const uint32_t key = f2key(v[u]);
+                const uint32_t d = key - key_lo; // wraps below the bucket
+                if (d < 4096u) __hip_atomic_fetch_add(&sub[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (key < key_lo && key > best) best = key;
+            }
+        }
+    }
+    best = wave_max(best);
+    if ((tid & 63) == 0 && best) __hip_atomic_fetch_max(&bs->below, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    block_find_bin<4096>(bs, sub, rk, 0);
+    const int bin = bs->bin, rkk = rk - bs->before; // (the rank lies inside: pass A counted the same samples)
+    __syncthreads();
+    // x_(k-1): the same key when the rank is not the first of its key, else the nearest occupied key below
+    if (tid == 0) bs->cntb = 0; // (largest occupied counter index below `bin`, + 1)
+    __syncthreads();
+    uint32_t lowb = 0;
+    for (int i = tid; i < bin; i += BS_THREADS) if (sub[i]) lowb = (uint32_t)i + 1u;
+    lowb = wave_max(lowb);
+    if ((tid & 63) == 0 && lowb) __hip_atomic_fetch_max(&bs->cntb, lowb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const float vk = key2f(key_lo + (uint32_t)bin);
+    float res = vk;
+    if ((n & 1) == 0) {
+        float lo = vk;
+        if (rkk == 0) lo = bs->cntb ? key2f(key_lo + bs->cntb - 1u) : key2f(bs->below);
+        res = (lo + vk) / 2.0f;
+    }
+    __syncthreads();
+    return res;
+}
+
 // passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
 static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x_, int n, LDS BlockScratch *bs, float med, float sd)
 {
@@ -478,7 +539,7 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
     const bool miss = bs->flag != 0;
     const int bin = bs->bin, rk = k1 - bs->before;
     __syncthreads();
-    if (tid == 0) { bs->ncollect = 0; bs->below = 0; }
+    if (tid == 0) { bs->ncollect = 0; bs->below = 0; bs->kmin = 0xffffffffu; bs->kmax = 0u; }
     __syncthreads();
     if (!miss) {
         const uint32_t tgt = wlo + (uint32_t)bin;
@@ -494,7 +555,11 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
                     float d = fabsf(v[u] - med);
                     uint32_t key = f2key(d);
                     uint32_t k18 = key >> 14;
-                    if (k18 == tgt) { int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (slot < BS_BINS18) c18[slot] = d; }
+                    if (k18 == tgt) {
+                        int slot = __hip_atomic_fetch_add(&bs->ncollect, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); if (slot < BS_BINS18) c18[slot] = d;
+                        __hip_atomic_fetch_min(&bs->kmin, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(&bs->kmax, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     else if (k18 < tgt && key > below) below = key;
                 }
             }
@@ -504,7 +569,13 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
         __syncthreads();
     }
     float mad;
-    if (miss || bs->ncollect > BS_BINS18) {
+    if (!miss && bs->ncollect > BS_BINS18 && bs->kmin == bs->kmax) {
+        // the bucket of the rank holds one distance only (quantised data): nothing to select
+        const float vk = key2f(bs->kmin);
+        mad = vk;
+        if ((n & 1) == 0) mad = (((rk >= 1) ? vk : key2f(bs->below)) + vk) / 2.0f;
+        __syncthreads();
+    } else if (miss || bs->ncollect > BS_BINS18) {
         __syncthreads();
         if (tid < 64) { float m_ = wave_median(x_, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
         __syncthreads();
@@ -622,7 +693,7 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
         }
         if (!fallback_med && !(g_ablate & 2)) predicted = bs_predict_mad(bs, wlo, k1, c, w0, P, Q);
         __syncthreads();
-        if (tid == 0) { bs->ncollect = 0; bs->nmad = 0; }
+        if (tid == 0) { bs->ncollect = 0; bs->nmad = 0; bs->kmin = 0xffffffffu; bs->kmax = 0u; }
         __syncthreads();
     }
     phase(1);
@@ -635,12 +706,26 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     o.sd = sqrtf(p2.sum / (float)n);
     phase(2);
     if (have_medmad || (g_ablate & (2048 | 8192))) { o.med = med_in; o.mad = mad_in; return o; }
-    if (fallback_med || bs->ncollect > BS_MEDCAP) {
+    if (fallback_med) {
         __syncthreads();
         if (tid < 64) { float m_ = wave_median(x, n, 0, 0.f, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
         __syncthreads();
         o.med = bs->bcast[1];
         __syncthreads();
+    } else if (bs->ncollect > BS_MEDCAP) {
+        // more samples in the bucket than the list holds: many equal values (quantised data)
+        const uint32_t kmin = bs->kmin, kmax = bs->kmax;
+        __syncthreads();
+        if (kmin == kmax) { // ... all of them the same value: nothing to select
+            const float vk = key2f(kmin);
+            o.med = vk;
+            if ((n & 1) == 0) {
+                float lo = vk;
+                if (rk == 0) lo = key2f(bs_max_key_below(x, n, (wlo + (uint32_t)bin) << BS_KSH, bs)); // (rare)
+                o.med = (lo + vk) / 2.0f;
+            }
+        } else o.med = bs_median_dense_bucket(x, n, bs, (wlo + (uint32_t)bin) << BS_KSH, rk);
+        if (tid == 0 && n >= 8192) atomicAdd(&g_dbg[kmin == kmax ? 20 : 21], 1ull);
     } else {
         uint32_t below_key = 0;
         if ((n & 1) == 0 && rk == 0) below_key = bs_max_key_below(x, n, (wlo + (uint32_t)bin) << BS_KSH, bs); // (rare)

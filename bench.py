@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=1000)
     ap.add_argument("--max_obs_trace", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--adc-step", type=float, default=0.0,
+                    help="(robustness probe, not the headline workload) round the synthetic samples to multiples of this many pA, "
+                         "like calibrated int16 ADC data (~0.18 pA): exercises the tie handling of the exact selections")
     ap.add_argument("--no-start-peak", action="store_true")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--primary", choices=["llr", "cnn"], default="llr",
@@ -230,6 +233,10 @@ def main():
     for k, e in enumerate(engines):
         e.synth_fill(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, seed=args.seed,
                      first_read=rank * R + k * Rs, decorate=True)
+    if args.adc_step > 0:
+        for s0 in range(0, R, 1000):
+            sig_t[s0:s0 + 1000].div_(args.adc_step).round_().mul_(args.adc_step)
+        torch.cuda.synchronize()
     gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
@@ -323,6 +330,12 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "kernel_ms_sum": ksum,
         }
+        if args.adc_step > 0:
+            c = eng.debug_counters(8)  # k_partition_stats tallies over the large segments (cumulative over all steps)
+            out["config"]["adc_step_pa"] = args.adc_step
+            out["partition_paths"] = {"large_segments": int(c[0]), "mad_proven_in_bracket": int(c[1]), "median_generic_select": int(c[2]),
+                                      "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
+                                      "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7])}
         if world == 1 and args.cpu_sample > 0 and args.primary == "llr":
             n_s = min(args.cpu_sample, R)
             out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows)

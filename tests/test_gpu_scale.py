@@ -138,3 +138,33 @@ def test_full_size_permutation_and_composition_properties():
     eng.dev_free(dsig)
     eng.dev_free(dlen)
     eng.close()
+
+
+@pytest.mark.parametrize("kind", ["adc_0.18", "narrow_0.005", "narrow_0.02"])
+def test_quantised_signals_vs_oracle(oracle_mod, kind):
+    """Calibrated int16 ADC data lie on a grid (~0.18 pA): thousands of samples share a value, the buckets and brackets of
+    the exact selections overflow their lists and the tie paths take over (k_partition_stats: one-value bucket, key
+    counters; N1: the multi-pass selection).  Every field identical to the oracle at the full window size."""
+    from adapted_amd import lib, synth
+
+    spc = _spc200k()
+    m, n = spc.sig_preload_size, 24
+    lens = np.full(n, m, dtype=np.int32)
+    lens[5], lens[11] = 120000, m + 900
+    sig, lens = synth.synth_batch(41, 0, n, m, lens)
+    f32 = np.float32
+    if kind == "adc_0.18":
+        q = f32(0.18)
+        sig = (np.round(sig / q) * q).astype(np.float32)
+    else:  # a narrow RNA distribution on a fine grid: several occupied keys per bucket, hundreds of samples each
+        q = f32(float(kind.split("_")[1]))
+        sig = (f32(95.0) + (sig - f32(95.0)) * f32(0.05)).astype(np.float32)
+        sig = (np.round(sig / q) * q).astype(np.float32)
+        sig[:, :6000] += f32(0.0)  # (adapter / poly(A) compressed alike: most reads fail validation, the statistics are still exact)
+    eng = lib.Engine(spc, n, m, device=0)
+    rows, mbs = eng.detect_llr_rows(sig, lens, n, n, with_start_peak=True)
+    assert mbs[0] == 0
+    got = lib.rows_to_results(rows, "llr")
+    want = oracle_mod.detect_llr(sig, lens, spc, with_start_peak=True)
+    assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
+    eng.close()
