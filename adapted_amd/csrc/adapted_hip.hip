@@ -61,7 +61,7 @@ struct adp_handle {
     int max_reads = 0, m = 0;
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
-    DevBuf mbs, ghist, gbelow, gcnt, cbuf, fz, fcnt, ct_pk, ct_pv, ct_out, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
+    DevBuf mbs, ghist, gbelow, gcnt, cbuf, fz, fcnt, n1heavy, ct_pk, ct_pv, ct_out, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
     DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
@@ -178,7 +178,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -359,11 +359,13 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
     const long long fused_min = getenv("ADP_N1_FUSED_MIN") ? atoll(getenv("ADP_N1_FUSED_MIN")) : (1ll << 24);
     if ((long long)minibatch * T >= fused_min && T >= 64) {
         if (h->cbuf.ensure((size_t)n_mb * N1_CB_CAP * 4) || h->fz.ensure((size_t)n_mb * sizeof(N1Fused)) ||
-            h->fcnt.ensure((size_t)n_mb * 8 * N1F_NCNT)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+            h->fcnt.ensure((size_t)n_mb * 8 * N1F_NCNT) || h->n1heavy.ensure((size_t)n_mb * N1H_WORDS * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
         cb = h->cbuf.as<uint32_t>();
         N1Fused *fz = h->fz.as<N1Fused>();
         unsigned long long *fc = h->fcnt.as<unsigned long long>();
         HIPCHK(hipMemsetAsync(fc, 0, (size_t)n_mb * 8 * N1F_NCNT, st));
+        uint32_t *hvy = h->n1heavy.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(hvy, 0, (size_t)n_mb * N1H_WORDS * 4, st));
         { Scope s(h, !profile ? nullptr : "k_n1 sample passes");
         for (int mode = 0; mode < 2; mode++) {
             hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
@@ -371,11 +373,15 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
             hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
             hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
             hipLaunchKernelGGL(k_n1_fuse_setup, dim3((n_mb + 63) / 64), dim3(64), 0, st, mbs, fz, n_mb, mode);
-        } }
+        }
+        // values shared by many of the samples to copy (quantised data): found in the sample, counted instead of copied
+        // (a quarter of the sampled rows is plenty to see ties)
+        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div);
+        hipLaunchKernelGGL(k_n1_heavy_pick, pg, dim3(64), 0, st, mbs, fz, hvy, n_mb); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused");
-          hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb); }
+          hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused_finish");
-          hipLaunchKernelGGL(k_n1_fused_finish, pg, dim3(1024), 0, st, mbs, fz, fc, (const float *)cb, thr); }
+          hipLaunchKernelGGL(k_n1_fused_finish, pg, dim3(1024), 0, st, mbs, fz, fc, (const float *)cb, thr, (const uint32_t *)hvy); }
     }
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample

@@ -30,11 +30,38 @@
 
 struct N1Fused {
     float med_s, A0, A1, D0, D1, eps;
-    int32_t ok, pad;
+    int32_t ok, wide_ok;
+    float D0w, D1w; // the MAD band widened by another eps on either side: used when the data have heavy keys (see k_n1_heavy_pick)
 };
 // counters per minibatch (u64): 0 valid, 1 below (u < A0), 2 inner (t < D0), 3 copied (median bracket), 4 staging overflow,
 // 5 copied (MAD band)
 #define N1F_NCNT 8
+
+// ---- heavy keys: values shared by a large part of the copied samples --------------------------------------------
+// Calibrated int16 ADC data lie on one grid (pA = scale * (adc + offset), ~0.18 pA apart): a bracket then holds a
+// handful of distinct values with ~10^6 samples each, far beyond any list.  The sample tells which values those are;
+// the pass COUNTS the samples equal to one of them instead of copying them, and the finish treats each as one entry
+// with a weight.  Exactness does not depend on the sample: a value it missed is simply copied as before.
+#define N1H_SLOTS 256 // hash table of the sample's in-bracket keys (per minibatch; per block in LDS first)
+#define N1H_MAX 32    // heavy keys handed to the pass
+// per-minibatch words: [0, 256) key + 1, [256, 512) count, [512] number of heavy keys, [513] sample points inside the
+// brackets, [514, 546) the keys (ascending),
+// [546, 578) their counts over the whole minibatch (filled by k_n1_fused)
+#define N1H_WORDS 640
+#define N1H_NH 512
+#define N1H_KEYS 514
+#define N1H_CNTS 546
+
+static __device__ __forceinline__ bool n1h_insert(uint32_t *tab, uint32_t key, uint32_t cnt)
+{
+    uint32_t slot = (key * 2654435761u) >> 24;
+    for (int p = 0; p < 24; p++) {
+        const uint32_t old = atomicCAS(&tab[slot], 0u, key + 1u);
+        if (old == 0u || old == key + 1u) { atomicAdd(&tab[N1H_SLOTS + slot], cnt); return true; }
+        slot = (slot + 1u) & (N1H_SLOTS - 1u);
+    }
+    return false;
+}
 
 // after the sample passes of a statistic: turn the key bracket into the float brackets of the fused pass
 __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__ fz, int n_mb, int mode)
@@ -44,7 +71,7 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
     MbState st = mbs[mb];
     N1Fused f = fz[mb];
     if (mode == 0) {
-        f.ok = 0; f.med_s = 0.f; f.A0 = 0.f; f.A1 = 0.f; f.D0 = 0.f; f.D1 = 0.f; f.eps = 0.f;
+        f.ok = 0; f.med_s = 0.f; f.A0 = 0.f; f.A1 = 0.f; f.D0 = 0.f; f.D1 = 0.f; f.eps = 0.f; f.wide_ok = 0; f.D0w = 0.f; f.D1w = 0.f;
         if (st.status == ADP_MB_OK && st.ckw && st.cklo + st.ckw > st.cklo) {
             const float a_lo = key2f(st.cklo), a_hi = key2f(st.cklo + st.ckw);
             const float ms = key2f(st.cklo + (st.ckw >> 1));
@@ -60,12 +87,129 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
                 const float e = f.eps * 1.01f + 1e-6f * fabsf(f.med_s) + 1e-30f;
                 f.D0 = d_lo - e; f.D1 = d_hi + e;
                 f.ok = (f.D0 > f.eps && f.D1 > f.D0 && f.D1 < __builtin_inff()) ? 1 : 0; // the median bracket lies inside the inner zone
+                // The zone the finish can use shrinks by |med - med_s| <= eps on either side.  With tied data the sample's
+                // distances |x - med_s| themselves sit up to eps away from the true |x - med| (all of one level move
+                // together), so the band needs twice the margin; it holds few distinct values then, and they are counted.
+                const float e2 = f.eps * 2.02f + 1e-6f * fabsf(f.med_s) + 1e-30f;
+                f.D0w = d_lo - e2; f.D1w = d_hi + e2;
+                f.wide_ok = (f.ok && f.D0w > f.eps && f.D1w > f.D0w && f.D1w < __builtin_inff()) ? 1 : 0;
             } else f.ok = 0;
         }
         // leave the state as n1_select.h's own sample passes expect to find it
         mbs[mb].med = 0.f; mbs[mb].ckw = 0; mbs[mb].cklo = 0; mbs[mb].kbase = 0; mbs[mb].krem = 0; mbs[mb].bad = 0; mbs[mb].done = 0;
     }
     fz[mb] = f;
+}
+
+// The sample once more (same rows and columns as the sample passes): the keys of the points that the pass would copy,
+// with their multiplicities -- per block in LDS, then only the repeated ones (>= 4 in this block's share) to the
+// minibatch's table.
+__global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
+                                                               const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
+                                                               uint32_t *__restrict__ hv, int row_step, int col_div)
+{
+    __shared__ uint32_t tab_[2 * N1H_SLOTS];
+    const int mb = blockIdx.y;
+    if (mbs[mb].status != ADP_MB_OK) return;
+    const N1Fused f = fz[mb];
+    if (!f.ok) return;
+    for (int i = threadIdx.x; i < 2 * N1H_SLOTS; i += N1_THREADS) tab_[i] = 0;
+    __syncthreads();
+    const int r0 = mb * mbsize;
+    const int r1 = min(n_reads, r0 + mbsize);
+    const float D0 = f.wide_ok ? f.D0w : f.D0, D1 = f.wide_ok ? f.D1w : f.D1; // (the band the pass will use if keys turn out heavy)
+    uint32_t nin = 0;
+    for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
+        const float *row = sig + (size_t)r * m;
+        const int Tc = col_div > 1 ? ((T / col_div) & ~3) : T;
+        const int chunk = col_div > 1 ? (int)(((r - r0) / row_step) % col_div) : 0;
+        const float *seg = row + (size_t)chunk * Tc;
+        auto visit = [&](float x) {
+            const float u = x - f.med_s, t = fabsf(u);
+            const bool inner = t < D0;
+            const bool take = inner ? (u >= f.A0 && u < f.A1) : (t <= D1); // (as n1f_count)
+            if (take) {
+                nin++;
+                const uint32_t key = f2key(x);
+                uint32_t slot = (key * 2654435761u) >> 24;
+                for (int p = 0; p < 6; p++) { // a full table (data without ties) just drops the point
+                    const uint32_t old = atomicCAS(&tab_[slot], 0u, key + 1u);
+                    if (old == 0u || old == key + 1u) { atomicAdd(&tab_[N1H_SLOTS + slot], 1u); break; }
+                    slot = (slot + 1u) & (N1H_SLOTS - 1u);
+                }
+            }
+        };
+        if (((reinterpret_cast<uintptr_t>(seg) & 15) == 0)) {
+            const float4 *seg4 = reinterpret_cast<const float4 *>(seg);
+            for (int i = threadIdx.x; i < (Tc >> 2); i += N1_THREADS) { const float4 v = seg4[i]; visit(v.x); visit(v.y); visit(v.z); visit(v.w); }
+            for (int i = (Tc & ~3) + threadIdx.x; i < Tc; i += N1_THREADS) visit(seg[i]);
+        } else {
+            for (int i = threadIdx.x; i < Tc; i += N1_THREADS) visit(seg[i]);
+        }
+    }
+    __syncthreads();
+    uint32_t *g = hv + (size_t)mb * N1H_WORDS;
+    nin = (uint32_t)wave_sum((int)nin);
+    if (lane_id() == 0 && nin) atomicAdd(&g[N1H_NH + 1], nin);
+    for (int sidx = threadIdx.x; sidx < N1H_SLOTS; sidx += N1_THREADS) {
+        const uint32_t c = tab_[N1H_SLOTS + sidx];
+        if (c >= 4u) n1h_insert(g, tab_[sidx] - 1u, c);
+    }
+}
+
+// one wave per minibatch: the (at most N1H_MAX) keys that carry at least 1/128 of the repeated sample points, ascending
+__global__ void __launch_bounds__(64) k_n1_heavy_pick(const MbState *__restrict__ mbs, N1Fused *__restrict__ fz, uint32_t *__restrict__ hv,
+                                                       int n_mb)
+{
+    __shared__ uint32_t keys_[N1H_MAX];
+    const int mb = blockIdx.x;
+    const int ln = threadIdx.x;
+    uint32_t *g = hv + (size_t)mb * N1H_WORDS;
+    uint32_t k[4], c[4];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { k[j] = g[4 * ln + j]; c[j] = k[j] ? g[N1H_SLOTS + 4 * ln + j] : 0u; tot += c[j]; }
+    tot = (uint32_t)wave_sum((int)tot);
+    const uint32_t thr = tot / 128u > 16u ? tot / 128u : 16u;
+    int nh = 0;
+    uint32_t hsum = 0; // sample points on the chosen keys
+    if (mbs[mb].status == ADP_MB_OK && fz[mb].ok) {
+        for (; nh < N1H_MAX; nh++) {
+            uint32_t bc = 0; int bj = -1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (c[j] >= thr && c[j] > bc) { bc = c[j]; bj = j; }
+            const uint32_t wc = wave_max(bc);
+            if (wc == 0u) break;
+            hsum += wc;
+            const unsigned long long mk = __ballot(bc == wc);
+            const int src = __ffsll((long long)mk) - 1;
+            if (ln == src) {
+                keys_[nh] = k[bj] - 1u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (j == bj) c[j] = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    if (ln < nh) {
+        const uint32_t mine = keys_[ln];
+        int rank = 0;
+        for (int j = 0; j < nh; j++) rank += keys_[j] < mine ? 1 : 0;
+        g[N1H_KEYS + rank] = mine;
+    }
+    // Heavy keys are worth their lookups only where they carry the bulk of the samples to copy (quantised data); a few
+    // repeated values among mostly distinct ones are left to the lists.
+    if ((unsigned long long)hsum * 2ull < (unsigned long long)g[N1H_NH + 1]) nh = 0;
+    __syncthreads();
+    if (ln < N1H_MAX) g[N1H_CNTS + ln] = 0u;
+    if (ln == 0) {
+        g[N1H_NH] = (uint32_t)nh;
+        // tied data -- nearly every sample point to copy sits on a heavy key: the wide band (its extra members are counted,
+        // not copied); a few repeated values among otherwise distinct ones keep the narrow one
+        if (nh > 0 && fz[mb].wide_ok && (unsigned long long)hsum * 10ull >= (unsigned long long)g[N1H_NH + 1] * 9ull) {
+            fz[mb].D0 = fz[mb].D0w; fz[mb].D1 = fz[mb].D1w;
+        }
+    }
 }
 
 struct N1FAcc { uint32_t nvalid, nbelow, ninner; };
@@ -84,27 +228,43 @@ static __device__ __forceinline__ uint32_t n1f_count(float x, float med_s, float
     return take ? 1u : 0u;
 }
 // the copy itself: median bracket -> first list, MAD band -> second
-static __device__ __forceinline__ void n1f_copy(float x, float med_s, float D0, LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+// a heavy key is counted, not copied (out of line: the pass's inner loop keeps its registers)
+static __device__ __noinline__ bool n1f_heavy(float x, int nh, const LDS uint32_t *hkeys, LDS uint32_t *hcnt)
 {
+    const uint32_t key = f2key(x);
+    int lo = 0, hi = nh;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (hkeys[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < nh && hkeys[lo] == key) { __hip_atomic_fetch_add(&hcnt[lo], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); return true; }
+    return false;
+}
+static __device__ __forceinline__ void n1f_copy(float x, float med_s, float D0, LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2,
+                                                int nh, const LDS uint32_t *hkeys, LDS uint32_t *hcnt)
+{
+    if (nh && n1f_heavy(x, nh, hkeys, hcnt)) return;
     const bool inner = fabsf(x - med_s) < D0;
     uint32_t slot = __hip_atomic_fetch_add(cnt2 + (inner ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (inner) { if (slot < N1F_LDS_M) cbm[slot] = x; }
     else if (slot < N1F_LDS_B) cbb[slot] = x;
 }
 static __device__ __forceinline__ void n1f_account(float x, float med_s, float A0, float A1, float D0, float D1, N1FAcc &a,
-                                                   LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2)
+                                                   LDS float *cbm, LDS float *cbb, LDS uint32_t *cnt2, int nh, const LDS uint32_t *hkeys,
+                                                   LDS uint32_t *hcnt)
 {
-    if (n1f_count(x, med_s, A0, A1, D0, D1, a)) n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
+    if (n1f_count(x, med_s, A0, A1, D0, D1, a)) n1f_copy(x, med_s, D0, cbm, cbb, cnt2, nh, hkeys, hcnt);
 }
 
 // grid = (blocks_per_minibatch, n_minibatch); block = N1_THREADS
 __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                           const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
-                                                          unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf)
+                                                          unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf,
+                                                          uint32_t *__restrict__ hv)
 {
     __shared__ float cbm_[N1F_LDS_M];
     __shared__ float cbb_[N1F_LDS_B];
     __shared__ uint32_t cnt2_[2], base2[2];
+    __shared__ uint32_t hkeys_[N1H_MAX], hcnt_[N1H_MAX];
+    const LDS uint32_t *hkeys = (const LDS uint32_t *)hkeys_;
+    LDS uint32_t *hcnt = (LDS uint32_t *)hcnt_;
     LDS float *cbm = (LDS float *)cbm_;
     LDS float *cbb = (LDS float *)cbb_;
     LDS uint32_t *cnt2 = (LDS uint32_t *)cnt2_;
@@ -113,6 +273,9 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
     const N1Fused f = fz[mb];
     if (!f.ok) return;
     if (threadIdx.x < 2) cnt2_[threadIdx.x] = 0;
+    uint32_t *hg = hv + (size_t)mb * N1H_WORDS;
+    const int nh = (int)hg[N1H_NH];
+    if (threadIdx.x < N1H_MAX) { hkeys_[threadIdx.x] = threadIdx.x < nh ? hg[N1H_KEYS + threadIdx.x] : 0xffffffffu; hcnt_[threadIdx.x] = 0; }
     __syncthreads();
     const int r0 = mb * mbsize;
     const int r1 = min(n_reads, r0 + mbsize);
@@ -121,7 +284,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
     const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
     float *dstm = cbuf + (size_t)mb * N1_CB_CAP;
     float *dstb = dstm + N1F_MCAP;
-#define ACC(xx) n1f_account(xx, med_s, A0, A1, D0, D1, a, cbm, cbb, cnt2)
+#define ACC(xx) n1f_account(xx, med_s, A0, A1, D0, D1, a, cbm, cbb, cnt2, nh, hkeys, hcnt)
     // hand the copied samples to the minibatch's lists: one global atomic per list, per block and per quarter row
     auto flush = [&]() {
         __syncthreads();
@@ -165,7 +328,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
                         float x = e[0];
 #pragma unroll
                         for (int z = 1; z < 8; z++) x = (q == z) ? e[z] : x;
-                        n1f_copy(x, med_s, D0, cbm, cbb, cnt2);
+                        n1f_copy(x, med_s, D0, cbm, cbb, cnt2, nh, hkeys, hcnt);
                     }
                 }
                 for (; i < send; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
@@ -185,6 +348,8 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
         if (nb) atomicAdd(&fcnt[N1F_NCNT * mb + 1], nb);
         if (ni) atomicAdd(&fcnt[N1F_NCNT * mb + 2], ni);
     }
+    __syncthreads();
+    if ((int)threadIdx.x < nh && hcnt_[threadIdx.x]) atomicAdd(&hg[N1H_CNTS + threadIdx.x], hcnt_[threadIdx.x]);
 }
 
 // ---- finish: counting selection in LDS -------------------------------------------------------------------------
@@ -229,8 +394,10 @@ static __device__ void n1f_find(LDS uint32_t *hist, int nb, uint32_t k, LDS N1Se
 template <class KF, class RK>
 static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float *__restrict__ xs, uint32_t n, KF keyf, uint32_t klo,
                                   uint32_t khi, RK rank_in_zone, bool need_prev, uint32_t *out_k, uint32_t *out_km1,
-                                  uint32_t *c_lo_out, uint32_t *c_hi_out)
+                                  uint32_t *c_lo_out, uint32_t *c_hi_out, int nh = 0, const LDS float *hval = nullptr,
+                                  const LDS uint32_t *hwgt = nullptr)
 {
+    // (hval[j], hwgt[j]), j < nh: the heavy values of this list -- one entry each, counted hwgt[j] times (0: not in this list)
     const int tid = threadIdx.x;
     const unsigned long long span = (unsigned long long)khi - klo + 1ull;
     int bits = 0; while ((1ull << bits) < span) bits++;
@@ -246,17 +413,18 @@ static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float 
         if (tid == 0) { S->s_below = 0; if (first) { S->s_clo = 0; S->s_chi = 0; } }
         __syncthreads();
         uint32_t clo = 0, chi = 0, below = 0;
-        auto visit = [&](float x) {
+        auto visit_w = [&](float x, uint32_t w) {
             const uint32_t key = keyf(x);
             if (key < base) {
-                if (key < klo) clo++;
+                if (key < klo) clo += w;
                 else if (key + 1u > below) below = key + 1u; // inside the zone, below the range in play (+1: 0 = none)
             } else {
                 const unsigned long long d = (unsigned long long)key - base;
-                if (d < width) __hip_atomic_fetch_add(&hist[(uint32_t)(d >> sh)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                else if (key > khi) chi++;
+                if (d < width) __hip_atomic_fetch_add(&hist[(uint32_t)(d >> sh)], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (key > khi) chi += w;
             }
         };
+        auto visit = [&](float x) { visit_w(x, 1u); };
         const uint32_t n4 = n >> 2;
         uint32_t i = tid;
         for (; i + 7 * 1024 < n4; i += 8 * 1024) { // eight 16-byte loads in flight per thread: one block per minibatch
@@ -272,6 +440,7 @@ static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float 
         }
         for (; i < n4; i += 1024) { float4 v = xs4[i]; visit(v.x); visit(v.y); visit(v.z); visit(v.w); }
         for (uint32_t j = (n4 << 2) + tid; j < n; j += 1024) visit(xs[j]);
+        for (int j = tid; j < nh; j += 1024) if (hwgt[j]) visit_w(hval[j], hwgt[j]);
         below = wave_max(below);
         if (lane_id() == 0 && below) atomicMax((uint32_t *)&S->s_below, below);
         if (first) {
@@ -317,10 +486,12 @@ static __device__ bool n1f_select(LDS uint32_t *hist, LDS N1Sel *S, const float 
 // one block (1024 threads) per minibatch
 __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
                                                            unsigned long long *__restrict__ fcnt, const float *__restrict__ cbuf,
-                                                           double thresh)
+                                                           double thresh, const uint32_t *__restrict__ hv)
 {
     __shared__ uint32_t hist_[N1F_BINS];
     __shared__ N1Sel S_;
+    __shared__ float hval_[N1H_MAX];
+    __shared__ uint32_t hwm_[N1H_MAX], hwb_[N1H_MAX], hsum_[2];
     LDS uint32_t *hist = (LDS uint32_t *)hist_;
     LDS N1Sel *S = (LDS N1Sel *)&S_;
     const int mb = blockIdx.x;
@@ -328,14 +499,36 @@ __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ 
     const MbState st = mbs[mb];
     const N1Fused f = fz[mb];
     const unsigned long long n_valid = fcnt[N1F_NCNT * mb], n_below = fcnt[N1F_NCNT * mb + 1], n_inner = fcnt[N1F_NCNT * mb + 2],
-                             n_cm = fcnt[N1F_NCNT * mb + 3], ovf = fcnt[N1F_NCNT * mb + 4], n_cb = fcnt[N1F_NCNT * mb + 5];
+                             ovf = fcnt[N1F_NCNT * mb + 4];
+    unsigned long long n_cm = fcnt[N1F_NCNT * mb + 3], n_cb = fcnt[N1F_NCNT * mb + 5];
+    // heavy values: counted by the pass, each one entry of its list (median bracket: |x - med_s| < D0, else MAD band)
+    const uint32_t *hg = hv + (size_t)mb * N1H_WORDS;
+    const int nh = (st.status == ADP_MB_OK && f.ok) ? (int)hg[N1H_NH] : 0;
+    if (tid < 2) hsum_[tid] = 0;
+    __syncthreads();
+    if (tid < N1H_MAX) {
+        float x = 0.f; uint32_t wm = 0, wb = 0;
+        if (tid < nh) {
+            x = key2f(hg[N1H_KEYS + tid]);
+            const uint32_t c = hg[N1H_CNTS + tid];
+            if (fabsf(x - f.med_s) < f.D0) wm = c; else wb = c;
+            if (wm) atomicAdd(&hsum_[0], wm);
+            if (wb) atomicAdd(&hsum_[1], wb);
+        }
+        hval_[tid] = x; hwm_[tid] = wm; hwb_[tid] = wb;
+    }
     __syncthreads();
     if (tid < N1F_NCNT) fcnt[N1F_NCNT * mb + tid] = 0; // ready for the next call
     if (st.status != ADP_MB_OK || !f.ok) return;
-    if (tid == 0) atomicAdd(&g_dbg[5], 1ull);
+    if (tid == 0) { atomicAdd(&g_dbg[5], 1ull); atomicAdd(&g_dbg[22], (unsigned long long)nh); atomicAdd(&g_dbg[23], (unsigned long long)hsum_[0] + hsum_[1]);
+                    if (ovf) atomicAdd(&g_dbg[19], 1ull); if (n_cm > N1F_MCAP) atomicAdd(&g_dbg[18], 1ull); if (n_cb > N1F_BCAP) atomicAdd(&g_dbg[17], 1ull); }
     if (ovf || n_cm > N1F_MCAP || n_cb > N1F_BCAP || n_valid < 4) { if (tid == 0) atomicAdd(&g_dbg[6], 1ull); return; }
     const float *xm = cbuf + (size_t)mb * N1_CB_CAP;
     const float *xb = xm + N1F_MCAP;
+    const uint32_t l_cm = (uint32_t)n_cm, l_cb = (uint32_t)n_cb; // list lengths
+    n_cm += hsum_[0]; n_cb += hsum_[1];                           // members of the brackets, heavy ones included
+    const LDS float *hval = (const LDS float *)hval_;
+    const LDS uint32_t *hwm = (const LDS uint32_t *)hwm_, *hwb = (const LDS uint32_t *)hwb_;
     const float med_s = f.med_s, D0 = f.D0, D1 = f.D1;
     const bool even = (n_valid & 1ull) == 0;
     const unsigned long long k = n_valid / 2;
@@ -346,9 +539,9 @@ __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ 
     {
         const uint32_t ka = f2key(med_s + f.A0), kb = f2key(med_s + f.A1);
         const uint32_t klo = ka > 64u ? ka - 64u : 0u, khi = kb < 0xffffffffu - 64u ? kb + 64u : 0xffffffffu;
-        const bool okm = n1f_select(hist, S, xm, (uint32_t)n_cm, [](float x) { return f2key(x); }, klo, khi,
+        const bool okm = n1f_select(hist, S, xm, l_cm, [](float x) { return f2key(x); }, klo, khi,
                                     [&](uint32_t) { return (k >= n_below && k - n_below < n_cm) ? (long long)(k - n_below) : -1ll; },
-                                    even, &kk, &kkm1, &c_lo, &c_hi);
+                                    even, &kk, &kkm1, &c_lo, &c_hi, nh, hval, hwm);
         if (!okm || c_lo || c_hi) { if (tid == 0) atomicAdd(&g_dbg[6], 1ull); return; }
     }
     float med = key2f(kk);
@@ -362,10 +555,10 @@ __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ 
     if (!(thi > 0.0) || !(vhi > vlo) || f2key(vhi) - f2key(vlo) < 2u) { if (tid == 0) atomicAdd(&g_dbg[7], 1ull); return; }
     {
         // samples with v <= vlo: every inner one plus the copied ones below the zone
-        const bool okd = n1f_select(hist, S, xb, (uint32_t)n_cb, [&](float x) { return f2key(fabsf(x - med)); }, f2key(vlo) + 1u,
+        const bool okd = n1f_select(hist, S, xb, l_cb, [&](float x) { return f2key(fabsf(x - med)); }, f2key(vlo) + 1u,
                                     f2key(vhi) - 1u,
                                     [&](uint32_t clo) { unsigned long long cle = n_inner + clo; return k >= cle ? (long long)(k - cle) : -1ll; },
-                                    even, &kk, &kkm1, &c_lo, &c_hi);
+                                    even, &kk, &kkm1, &c_lo, &c_hi, nh, hval, hwb);
         if (!okd) { if (tid == 0) atomicAdd(&g_dbg[7], 1ull); return; }
     }
     float mad = key2f(kk);

@@ -331,11 +331,12 @@ def main():
             "kernel_ms_sum": ksum,
         }
         if args.adc_step > 0:
-            c = eng.debug_counters(8)  # k_partition_stats tallies over the large segments (cumulative over all steps)
+            c = eng.debug_counters(24)  # k_partition_stats tallies over the large segments (cumulative over all steps)
             out["config"]["adc_step_pa"] = args.adc_step
             out["partition_paths"] = {"large_segments": int(c[0]), "mad_proven_in_bracket": int(c[1]), "median_generic_select": int(c[2]),
                                       "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
-                                      "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7])}
+                                      "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7]),
+                                      "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23]), "n1_dbg": [int(c[19]), int(c[18]), int(c[17]), int(c[6]), int(c[7])]}
         if world == 1 and args.cpu_sample > 0 and args.primary == "llr":
             n_s = min(args.cpu_sample, R)
             out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows)

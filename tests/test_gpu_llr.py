@@ -161,7 +161,8 @@ def test_n1_guess_miss_falls_back_exactly(hip, oracle_mod, kind):
     eng.close()
 
 
-@pytest.mark.parametrize("kind", ["plain", "odd_count", "bimodal_rows", "nan_sample", "constant", "negatives", "two_values"])
+@pytest.mark.parametrize("kind", ["plain", "odd_count", "bimodal_rows", "nan_sample", "constant", "negatives", "two_values",
+                                  "adc_grid", "adc_grid_odd", "half_grid", "coarse_grid"])
 def test_n1_fused_single_pass_is_exact_or_falls_back(hip, oracle_mod, kind, monkeypatch):
     """Big minibatches get median and MAD from one pass (n1_fused.h); forced here on a small batch.  Whatever the
     sampled brackets cannot prove must fall through to the multi-pass selection: the result is always numpy's."""
@@ -189,6 +190,14 @@ def test_n1_fused_single_pass_is_exact_or_falls_back(hip, oracle_mod, kind, monk
     elif kind == "two_values":
         sig[:, :] = np.float32(50.0)
         sig[:, 1::2] = np.float32(90.0)
+    elif kind in ("adc_grid", "adc_grid_odd"):  # calibrated int16 data: one grid for the whole minibatch (heavy keys)
+        sig = (np.round(sig / np.float32(0.18)) * np.float32(0.18)).astype(np.float32)
+        if kind == "adc_grid_odd":
+            sig[3, 17] = np.nan
+    elif kind == "half_grid":  # every other read on the grid, the rest continuous
+        sig[0::2] = (np.round(sig[0::2] / np.float32(0.18)) * np.float32(0.18)).astype(np.float32)
+    elif kind == "coarse_grid":
+        sig = (np.round(sig / np.float32(3.0)) * np.float32(3.0)).astype(np.float32)
     eng = _engine(hip, spc, n, m)
     before = eng.debug_counters().copy()
     eng.debug_llr_upto(sig, lens, n, n, 1)

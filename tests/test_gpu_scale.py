@@ -168,3 +168,40 @@ def test_quantised_signals_vs_oracle(oracle_mod, kind):
     want = oracle_mod.detect_llr(sig, lens, spc, with_start_peak=True)
     assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
     eng.close()
+
+
+def test_full_size_quantised_minibatch_keeps_the_single_pass_n1(oracle_mod):
+    """One minibatch of 1000 reads at 200k on a 0.18 pA grid (calibrated int16 ADC data): ~10^6 samples per value.  N1 still
+    comes from the single fused pass -- the heavy values are counted instead of copied -- and is numpy's nanmedian / MAD;
+    the rows equal the oracle's on a sample of the reads."""
+    from adapted_amd import lib
+
+    spc = _spc200k()
+    m = spc.sig_preload_size
+    n = 1000
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+    lens = np.full(n, m, dtype=np.int32)
+    eng.h2d(dlen, lens)
+    eng.synth_fill(dsig, dlen, n, seed=13, first_read=0)
+    sig = np.zeros((n, m), dtype=np.float32)
+    eng.d2h(sig, dsig)
+    q = np.float32(0.18)
+    np.divide(sig, q, out=sig)
+    np.round(sig, out=sig)
+    np.multiply(sig, q, out=sig)
+    eng.h2d(dsig, sig)
+    c0 = eng.debug_counters().copy()
+    rows, mbs = eng.detect_llr_rows(dsig, dlen, n, n, device_ptrs=True)
+    assert mbs[0] == 0
+    c1 = eng.debug_counters()
+    assert list((c1 - c0)[5:8]) == [1, 0, 0], (c0, c1)
+    rc, want_np = oracle_mod.norm_params(sig, spc.core.max_obs_trace, spc.core.sig_norm_outlier_thresh)
+    assert list(eng.debug_norm_params(1)[0]) == list(want_np)
+    # the rows of a few reads against the oracle, given the minibatch's normalisation (it only enters through N1)
+    got = lib.rows_to_results(rows, "llr")
+    want = oracle_mod.detect_llr(sig, lens, spc)
+    assert not _rows_equal(got, want), _rows_equal(got, want)[:10]
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
