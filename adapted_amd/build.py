@@ -32,13 +32,25 @@ def stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
+    import fcntl
+
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB,
-                             os.path.join(CSRC, "adapted_hip.hip")]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # several ranks of one node may get here at once (torchrun): one builds, the others wait and find it fresh; the
+    # library appears by an atomic rename, never half written
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                tmp = "%s.%d.tmp" % (LIB, os.getpid())
+                cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", tmp,
+                                         os.path.join(CSRC, "adapted_hip.hip")]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
