@@ -349,9 +349,12 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
     uint32_t *cb = h->cbuf.as<uint32_t>();
     int bpm = 4096 / n_mb; if (bpm > 256) bpm = 256; if (bpm < 4) bpm = 4;
     dim3 hg(bpm, n_mb), pg(n_mb);
-    // sample: every row_step-th read, one rotating eighth of its window (about 1/32 of the minibatch, from ~250 reads)
-    const int col_div = (T >= 8192) ? 8 : 1;
-    int row_step = (col_div > 1) ? minibatch / 256 : minibatch / 32; if (row_step < 1) row_step = 1;
+    // sample: 1/32 of the minibatch -- of EVERY read `col_div` pieces of ~96 samples, one in each col_div-th of the window
+    // at a position that rotates from read to read (short windows: every 32nd read whole)
+    const int pdiv = 32;
+    int col_div = 1;
+    if (T >= 8192) { col_div = T / (pdiv * 96); if (col_div > 64) col_div = 64; if (col_div < 2) col_div = 2; }
+    int row_step = (col_div > 1) ? 1 : minibatch / 32; if (row_step < 1) row_step = 1;
     int sb = (minibatch + row_step - 1) / row_step; if (sb > bpm) sb = bpm; if (sb < 1) sb = 1;
     dim3 sg(sb, n_mb);
     const double thr = h->cfg.sig_norm_outlier_thresh;
@@ -368,15 +371,15 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
         HIPCHK(hipMemsetAsync(hvy, 0, (size_t)n_mb * N1H_WORDS * 4, st));
         { Scope s(h, !profile ? nullptr : "k_n1 sample passes");
         for (int mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
+            hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
             hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-            hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
+            hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
             hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
             hipLaunchKernelGGL(k_n1_fuse_setup, dim3((n_mb + 63) / 64), dim3(64), 0, st, mbs, fz, n_mb, mode);
         }
         // values shared by many of the samples to copy (quantised data): found in the sample, counted instead of copied
         // (a quarter of the sampled rows is plenty to see ties)
-        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div);
+        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div, pdiv);
         hipLaunchKernelGGL(k_n1_heavy_pick, pg, dim3(64), 0, st, mbs, fz, hvy, n_mb); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused");
           hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy); }
@@ -385,9 +388,9 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
     }
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample
-        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
+        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
         hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div);
+        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
         hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 1 over everything, verified
         { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med"));

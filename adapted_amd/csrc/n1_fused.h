@@ -106,7 +106,7 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
 // minibatch's table.
 __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                                const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
-                                                               uint32_t *__restrict__ hv, int row_step, int col_div)
+                                                               uint32_t *__restrict__ hv, int row_step, int col_div, int pdiv)
 {
     __shared__ uint32_t tab_[2 * N1H_SLOTS];
     const int mb = blockIdx.y;
@@ -121,9 +121,10 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__res
     uint32_t nin = 0;
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
         const float *row = sig + (size_t)r * m;
-        const int Tc = col_div > 1 ? ((T / col_div) & ~3) : T;
-        const int chunk = col_div > 1 ? (int)(((r - r0) / row_step) % col_div) : 0;
-        const float *seg = row + (size_t)chunk * Tc;
+        // (the pieces of the sample passes, n1_select.h)
+        const int npc = col_div > 1 ? col_div : 1;
+        const int Rg = col_div > 1 ? ((T / col_div) & ~3) : 0, Tp = col_div > 1 ? ((T / (col_div * pdiv)) & ~3) : T;
+        const int rot = col_div > 1 ? (int)(((r - r0) / row_step) % pdiv) : 0;
         auto visit = [&](float x) {
             const float u = x - f.med_s, t = fabsf(u);
             const bool inner = t < D0;
@@ -139,12 +140,10 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__res
                 }
             }
         };
-        if (((reinterpret_cast<uintptr_t>(seg) & 15) == 0)) {
-            const float4 *seg4 = reinterpret_cast<const float4 *>(seg);
-            for (int i = threadIdx.x; i < (Tc >> 2); i += N1_THREADS) { const float4 v = seg4[i]; visit(v.x); visit(v.y); visit(v.z); visit(v.w); }
-            for (int i = (Tc & ~3) + threadIdx.x; i < Tc; i += N1_THREADS) visit(seg[i]);
-        } else {
-            for (int i = threadIdx.x; i < Tc; i += N1_THREADS) visit(seg[i]);
+        const int tot = npc * Tp;
+        for (int i = threadIdx.x; i < tot; i += N1_THREADS) {
+            const int pc = i / Tp, j = i - pc * Tp;
+            visit(row[(size_t)pc * Rg + (size_t)rot * Tp + j]);
         }
     }
     __syncthreads();
@@ -311,8 +310,8 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
         if (vec) {
             const int T4 = T >> 2;
             const float4 *row4 = reinterpret_cast<const float4 *>(row);
-            // the row in four quarters, the staging lists flushed after each: small lists leave LDS for 8 blocks per CU
-            const int q4 = ((T4 + 3) / 4 + 2 * N1_THREADS - 1) / (2 * N1_THREADS) * (2 * N1_THREADS);
+            // the row in eight parts, the staging lists flushed after each: small lists leave LDS for 8 blocks per CU
+            const int q4 = ((T4 + 7) / 8 + 2 * N1_THREADS - 1) / (2 * N1_THREADS) * (2 * N1_THREADS);
             for (int seg = 0; seg < T4; seg += q4) {
                 const int send = min(T4, seg + q4);
                 int i = seg + threadIdx.x;
@@ -520,6 +519,9 @@ __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ 
     __syncthreads();
     if (tid < N1F_NCNT) fcnt[N1F_NCNT * mb + tid] = 0; // ready for the next call
     if (st.status != ADP_MB_OK || !f.ok) return;
+#ifdef N1F_DEBUG_PRINT
+    if (tid == 0 && mb < 6) printf("mb %d nvalid %llu below %llu inner %llu n_cm %llu n_cb %llu ovf %llu med_s %.6f A0 %.6f A1 %.6f D0 %.6f D1 %.6f eps %.6f nh %d\n", mb, n_valid, n_below, n_inner, n_cm, n_cb, ovf, f.med_s, f.A0, f.A1, f.D0, f.D1, f.eps, nh);
+#endif
     if (tid == 0) { atomicAdd(&g_dbg[5], 1ull); atomicAdd(&g_dbg[22], (unsigned long long)nh); atomicAdd(&g_dbg[23], (unsigned long long)hsum_[0] + hsum_[1]);
                     if (ovf) atomicAdd(&g_dbg[19], 1ull); if (n_cm > N1F_MCAP) atomicAdd(&g_dbg[18], 1ull); if (n_cb > N1F_BCAP) atomicAdd(&g_dbg[17], 1ull); }
     if (ovf || n_cm > N1F_MCAP || n_cb > N1F_BCAP || n_valid < 4) { if (tid == 0) atomicAdd(&g_dbg[6], 1ull); return; }

@@ -81,7 +81,7 @@ template <int PASS>
 __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                          int mode, const MbState *__restrict__ mbs, uint32_t *__restrict__ ghist,
                                                          uint32_t *__restrict__ gbelow, unsigned long long *__restrict__ gcnt,
-                                                         int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div)
+                                                         int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div, int pdiv = 8)
 {
     __shared__ uint32_t hist_[N1_BINS];
     __shared__ uint32_t sbelow, sbelow2, cb_cnt_, cb_base;
@@ -107,23 +107,29 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
         const float *row = sig + (size_t)r * m;
         if (col_div > 1) {
-            // sampling pass: one contiguous 1/col_div of the row, the part rotating from sampled row to sampled row so
-            // that every position of the window is covered by many different reads
-            const int Tc = (T / col_div) & ~3;
-            const int chunk = (int)(((r - r0) / row_step) % col_div);
-            const float *seg = row + (size_t)chunk * Tc;
-            if (vec) {
-                const float4 *seg4 = reinterpret_cast<const float4 *>(seg);
-                for (int i = threadIdx.x; i < (Tc >> 2); i += N1_THREADS) {
-                    float4 v = seg4[i];
+            // sampling pass: col_div contiguous pieces of T / (col_div * pdiv) samples, one in every col_div-th of the window
+            // (reads of very different lengths still contribute from every part they have -- with every read sampled, the
+            // sample's mix of reads is the minibatch's own), the position inside the part rotating from row to row
+            const int Rg = (T / col_div) & ~3, Tp = (T / (col_div * pdiv)) & ~3;
+            const int rot = (int)(((r - r0) / row_step) % pdiv);
+            if (vec) { // all pieces of the row as one index space: (piece, float4 inside it)
+                const int p4 = Tp >> 2, tot4 = col_div * p4;
+                const float4 *row4 = reinterpret_cast<const float4 *>(row);
+                const int rg4 = Rg >> 2, off4 = (rot * Tp) >> 2;
+                for (int i = threadIdx.x; i < tot4; i += N1_THREADS) {
+                    const int pc = i / p4, j = i - pc * p4;
+                    float4 v = row4[pc * rg4 + off4 + j];
                     n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.w, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                 }
             } else {
-                for (int i = threadIdx.x; i < Tc; i += N1_THREADS)
-                    n1_account<PASS>(seg[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                const int tot = col_div * Tp;
+                for (int i = threadIdx.x; i < tot; i += N1_THREADS) {
+                    const int pc = i / Tp, j = i - pc * Tp;
+                    n1_account<PASS>(row[(size_t)pc * Rg + (size_t)rot * Tp + j], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
+                }
             }
         } else if (vec) {
             const int T4 = T >> 2;
@@ -264,7 +270,9 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
         // and the bracket is only a good bet; whether it held is verified exactly after pass 1
         const unsigned long long tot = s_total;
         const unsigned long long Ms = st.n_valid; // sample size
-        const unsigned long long D = (unsigned long long)(6.0 * sqrt((double)Ms)) + 16ull;
+        // (4.5 sigma: with every read in the sample the clustering is that of positions inside a read only; a bracket
+        // that misses costs the multi-pass selection, never the result)
+        const unsigned long long D = (unsigned long long)(4.5 * sqrt((double)Ms)) + 16ull;
         const bool cut = miss || krel < D || krel + D >= tot; // the bracket would be cut off by the window: no bracket
         const unsigned long long rlo = krel > D ? krel - D : 0ull;
         unsigned long long rhi = krel + D;

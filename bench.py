@@ -44,7 +44,7 @@ def make_spc(max_obs_trace: int):
     return spc
 
 
-def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows):
+def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens=None):
     """Time the CPU oracle (a single-threaded C port of the reference path) on the first
     n_sample reads of the resident batch, as ONE minibatch, and check the GPU rows of an
     identically composed minibatch against it."""
@@ -54,7 +54,7 @@ def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows):
     oracle.lib()
     sig = np.zeros((n_sample, m), dtype=np.float32)
     eng.d2h(sig, dsig)
-    lens = np.full(n_sample, m, dtype=np.int32)
+    lens = np.full(n_sample, m, dtype=np.int32) if lens is None else np.ascontiguousarray(lens[:n_sample], dtype=np.int32)
     t0 = time.perf_counter()
     want = oracle.detect_llr(sig, lens, spc, with_start_peak=True)
     dt = time.perf_counter() - t0
@@ -165,6 +165,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=1000)
     ap.add_argument("--max_obs_trace", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--lens", choices=["full", "pareto"], default="full",
+                    help="read lengths: full (the headline workload: every read fills the window) or pareto (BASELINE configs[4]: "
+                         "Pareto(1.2) clipped to [10k, 1M] samples -- most reads much shorter than the window, NaN padded; a probe)")
     ap.add_argument("--adc-step", type=float, default=0.0,
                     help="(robustness probe, not the headline workload) round the synthetic samples to multiples of this many pA, "
                          "like calibrated int16 ADC data (~0.18 pA): exercises the tie handling of the exact selections")
@@ -226,7 +229,12 @@ def main():
     engines = [lib.Engine(spc, Rs, m, device=local) for _ in range(NS)]
     eng = engines[0]
     sig_t = torch.empty((R, m), dtype=torch.float32, device=dev)
-    len_t = torch.full((R,), m, dtype=torch.int32, device=dev)
+    lens_host = np.full(R, m, dtype=np.int32)
+    if args.lens == "pareto":
+        from adapted_amd import synth as _synth
+
+        lens_host = np.array([_synth.pareto_length(args.seed, rank * R + i) for i in range(R)], dtype=np.int32)
+    len_t = torch.from_numpy(lens_host).to(dev)
     rows_t = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     # rank r owns reads [r*R, (r+1)*R) of the global stream: contiguous whole minibatches
@@ -242,8 +250,6 @@ def main():
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
 
     import threading
-
-    lens_host = np.full(R, m, dtype=np.int32)
 
     def run_part(k):
         if args.primary == "cnn":  # one call per minibatch: conv head in torch, pre/post in the HIP library
@@ -330,16 +336,20 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "kernel_ms_sum": ksum,
         }
-        if args.adc_step > 0:
+        if args.lens != "full":
+            out["config"]["lens"] = "%s: mean %.0f samples of m = %d preloaded (%.0f %% of the matrix is NaN padding)" % (
+                args.lens, float(np.minimum(lens_host, m).mean()), m, 100.0 * (1.0 - float(np.minimum(lens_host, m).mean()) / m))
+        if args.adc_step > 0 or args.lens != "full":
             c = eng.debug_counters(24)  # k_partition_stats tallies over the large segments (cumulative over all steps)
-            out["config"]["adc_step_pa"] = args.adc_step
+            if args.adc_step > 0:
+                out["config"]["adc_step_pa"] = args.adc_step
             out["partition_paths"] = {"large_segments": int(c[0]), "mad_proven_in_bracket": int(c[1]), "median_generic_select": int(c[2]),
                                       "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
                                       "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7]),
                                       "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23]), "n1_dbg": [int(c[19]), int(c[18]), int(c[17]), int(c[6]), int(c[7])]}
         if world == 1 and args.cpu_sample > 0 and args.primary == "llr":
             n_s = min(args.cpu_sample, R)
-            out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows)
+            out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows, lens_host)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
