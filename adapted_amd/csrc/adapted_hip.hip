@@ -338,7 +338,8 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
 
 // N1 for all minibatches (n1_select.h): sampled guess, then ONE verified full pass per statistic when the copied
 // bracket holds the rank (k_n1_finish), else the second pass; a missed window falls back to the aligned path.
-static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile)
+static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile,
+                     const int32_t *tails = nullptr) // tails: full_len when ADP_TAILS_NAN holds
 {
     hipStream_t st = h->stream;
     MbState *mbs = h->mbs.as<MbState>();
@@ -371,40 +372,40 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
         HIPCHK(hipMemsetAsync(hvy, 0, (size_t)n_mb * N1H_WORDS * 4, st));
         { Scope s(h, !profile ? nullptr : "k_n1 sample passes");
         for (int mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
+            hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-            hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
+            hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
             hipLaunchKernelGGL(k_n1_fuse_setup, dim3((n_mb + 63) / 64), dim3(64), 0, st, mbs, fz, n_mb, mode);
         }
         // values shared by many of the samples to copy (quantised data): found in the sample, counted instead of copied
         // (a quarter of the sampled rows is plenty to see ties)
-        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div, pdiv);
+        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div, pdiv, tails);
         hipLaunchKernelGGL(k_n1_heavy_pick, pg, dim3(64), 0, st, mbs, fz, hvy, n_mb); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused");
-          hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy); }
+          hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy, tails); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused_finish");
           hipLaunchKernelGGL(k_n1_fused_finish, pg, dim3(1024), 0, st, mbs, fz, fc, (const float *)cb, thr, (const uint32_t *)hvy); }
     }
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample
-        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
+        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
         hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv);
+        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
         hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 1 over everything, verified
         { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med"));
-          hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS, cb, collect, 1); }
+          hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS, cb, collect, 1, 8, tails); }
         hipLaunchKernelGGL((k_n1_pick<1, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         hipLaunchKernelGGL(k_n1_finish, pg, dim3(1024), 0, st, mbs, cb, gc, gb, mode, thr);
         // fallback (runs only for minibatches whose guess missed)
-        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1);
+        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
         hipLaunchKernelGGL((k_n1_pick<0, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1);
+        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
         hipLaunchKernelGGL((k_n1_pick<1, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 2 (only where the bracket did not settle it)
         { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med"));
-          hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_NOT_DONE, cb, 0, 1); }
+          hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_NOT_DONE, cb, 0, 1, 8, tails); }
         hipLaunchKernelGGL((k_n1_pick<2, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
     }
     return 0;
@@ -438,13 +439,14 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
-        rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true);
+        const int32_t *tails = (flags & ADP_TAILS_NAN) ? dlen : nullptr;
+        rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true, tails);
         if (rc) return rc;
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
             hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
-                               (const int32_t *)nullptr);
+                               dlen, (flags & ADP_TAILS_NAN) ? 1 : 0);
         }
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);

@@ -28,10 +28,13 @@ __device__ const double g_logcr_table[3 * LOGCR_N] = LOGCR_TABLE;
 #define NP_TILE 512
 // grid = n_reads blocks of 256 threads; dynamic LDS = NP_TILE * ds floats
 // ranges != nullptr (CNN fallback C4): per-read pooled region [ranges[2r], min(ranges[2r+1], T, full_len))
+// tails_nan (ADP_TAILS_NAN): the row is NaN padding from full_len[r] on -- pooled blocks that reach into it are NaN without
+// being read
 __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
                                                    float *__restrict__ down, int32_t *__restrict__ nvalid,
-                                                   const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len)
+                                                   const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len,
+                                                   int tails_nan = 0)
 {
     extern __shared__ float tile[];
     __shared__ int s_nan;
@@ -52,6 +55,12 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
     const float *row = sig + (size_t)r * m + off;
     if (threadIdx.x == 0) s_nan = 0;
     int my_nan = 0;
+    // pooled blocks worth computing: all of them, or only those that end before the padding starts
+    int L_ok = L;
+    if (tails_nan && !ranges) {
+        long long lv = (long long)full_len[r] - off; // valid samples of the segment
+        if (lv < Lseg) { if (lv < 0) lv = 0; L_ok = (int)(lv / ds); }
+    }
     const int tile_n = NP_TILE * ds; // samples per tile (NP_TILE pooled outputs, 2 per thread)
     const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) && ((tile_n & 3) == 0);
     // every sample of the minibatch is divided by the same MAD: one IEEE division for its reciprocal, then three
@@ -65,6 +74,10 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
     };
     for (int tb = 0; tb < L; tb += NP_TILE) {
         const int base = tb * ds;
+        if (tb >= L_ok) { // the padding: NaN blocks
+            for (int jj = threadIdx.x; jj < NP_TILE; jj += 256) if (tb + jj < L) { down[(size_t)r * Lp + tb + jj] = __builtin_nanf(""); my_nan++; }
+            continue;
+        }
         __syncthreads();
         if (vec) {
             const float4 *row4 = reinterpret_cast<const float4 *>(row + base);

@@ -106,7 +106,8 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
 // minibatch's table.
 __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                                const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
-                                                               uint32_t *__restrict__ hv, int row_step, int col_div, int pdiv)
+                                                               uint32_t *__restrict__ hv, int row_step, int col_div, int pdiv,
+                                                               const int32_t *__restrict__ full_len)
 {
     __shared__ uint32_t tab_[2 * N1H_SLOTS];
     const int mb = blockIdx.y;
@@ -141,8 +142,11 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__res
             }
         };
         const int tot = npc * Tp;
+        int Te = T;
+        if (full_len) { const int fl = full_len[r]; Te = fl < T ? (fl > 0 ? fl : 0) : T; }
         for (int i = threadIdx.x; i < tot; i += N1_THREADS) {
             const int pc = i / Tp, j = i - pc * Tp;
+            if (pc * Rg + rot * Tp + j >= Te) continue;
             visit(row[(size_t)pc * Rg + (size_t)rot * Tp + j]);
         }
     }
@@ -256,7 +260,7 @@ static __device__ __forceinline__ void n1f_account(float x, float med_s, float A
 __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                           const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
                                                           unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf,
-                                                          uint32_t *__restrict__ hv)
+                                                          uint32_t *__restrict__ hv, const int32_t *__restrict__ full_len)
 {
     __shared__ float cbm_[N1F_LDS_M];
     __shared__ float cbb_[N1F_LDS_B];
@@ -307,8 +311,10 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
     };
     for (int r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
         const float *row = sig + (size_t)r * m;
+        int Te = T; // ADP_TAILS_NAN: the NaN padding behind the read's end counts for nothing and is not read
+        if (full_len) { const int fl = full_len[r]; Te = fl < T ? (fl > 0 ? fl : 0) : T; }
         if (vec) {
-            const int T4 = T >> 2;
+            const int T4 = Te >> 2;
             const float4 *row4 = reinterpret_cast<const float4 *>(row);
             // the row in eight parts, the staging lists flushed after each: small lists leave LDS for 8 blocks per CU
             const int q4 = ((T4 + 7) / 8 + 2 * N1_THREADS - 1) / (2 * N1_THREADS) * (2 * N1_THREADS);
@@ -331,11 +337,12 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
                     }
                 }
                 for (; i < send; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
-                if (send == T4) for (int j = (T4 << 2) + threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+                if (send == T4) for (int j = (T4 << 2) + threadIdx.x; j < Te; j += N1_THREADS) ACC(row[j]);
                 flush();
             }
+            if (T4 == 0 && Te > 0) { for (int j = threadIdx.x; j < Te; j += N1_THREADS) ACC(row[j]); flush(); }
         } else {
-            for (int j = threadIdx.x; j < T; j += N1_THREADS) ACC(row[j]);
+            for (int j = threadIdx.x; j < Te; j += N1_THREADS) ACC(row[j]);
             flush();
         }
     }

@@ -81,7 +81,8 @@ template <int PASS>
 __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
                                                          int mode, const MbState *__restrict__ mbs, uint32_t *__restrict__ ghist,
                                                          uint32_t *__restrict__ gbelow, unsigned long long *__restrict__ gcnt,
-                                                         int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div, int pdiv = 8)
+                                                         int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div, int pdiv = 8,
+                                                         const int32_t *__restrict__ full_len = nullptr)
 {
     __shared__ uint32_t hist_[N1_BINS];
     __shared__ uint32_t sbelow, sbelow2, cb_cnt_, cb_base;
@@ -106,6 +107,9 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
     const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
         const float *row = sig + (size_t)r * m;
+        // ADP_TAILS_NAN: everything from the read's end on is NaN padding, which counts for nothing here
+        int Te = T;
+        if (full_len) { const int fl = full_len[r]; Te = fl < T ? (fl > 0 ? fl : 0) : T; }
         if (col_div > 1) {
             // sampling pass: col_div contiguous pieces of T / (col_div * pdiv) samples, one in every col_div-th of the window
             // (reads of very different lengths still contribute from every part they have -- with every read sampled, the
@@ -118,6 +122,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
                 const int rg4 = Rg >> 2, off4 = (rot * Tp) >> 2;
                 for (int i = threadIdx.x; i < tot4; i += N1_THREADS) {
                     const int pc = i / p4, j = i - pc * p4;
+                    if (4 * (pc * rg4 + off4 + j) >= Te) continue;
                     float4 v = row4[pc * rg4 + off4 + j];
                     n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
@@ -128,11 +133,12 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
                 const int tot = col_div * Tp;
                 for (int i = threadIdx.x; i < tot; i += N1_THREADS) {
                     const int pc = i / Tp, j = i - pc * Tp;
+                    if (pc * Rg + rot * Tp + j >= Te) continue;
                     n1_account<PASS>(row[(size_t)pc * Rg + (size_t)rot * Tp + j], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                 }
             }
         } else if (vec) {
-            const int T4 = T >> 2;
+            const int T4 = Te >> 2;
             const float4 *row4 = reinterpret_cast<const float4 *>(row);
             for (int i = threadIdx.x; i < T4; i += N1_THREADS) {
                 float4 v = row4[i];
@@ -141,10 +147,10 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
                 n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                 n1_account<PASS>(v.w, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
             }
-            for (int i = (T4 << 2) + threadIdx.x; i < T; i += N1_THREADS)
+            for (int i = (T4 << 2) + threadIdx.x; i < Te; i += N1_THREADS)
                 n1_account<PASS>(row[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
         } else {
-            for (int i = threadIdx.x; i < T; i += N1_THREADS)
+            for (int i = threadIdx.x; i < Te; i += N1_THREADS)
                 n1_account<PASS>(row[i], mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
         }
         if (PASS == 1 && ckw) { // hand the row's bracket keys to the minibatch buffer: one global atomic per row and block

@@ -22,7 +22,7 @@ NCOL = 39
 MAX_CAND = 16
 MAX_OPEN_PORES = 16
 
-ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK, ADP_TOPK_NONE, ADP_BOUNDS_HOST = 1, 2, 4, 8, 16
+ADP_IN_DEVICE, ADP_OUT_DEVICE, ADP_WITH_START_PEAK, ADP_TOPK_NONE, ADP_BOUNDS_HOST, ADP_TAILS_NAN = 1, 2, 4, 8, 16, 32
 MB_OK, MB_MAD_ZERO, MB_EMPTY_TRACE = 0, 1, 2
 
 COLS = ["signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_len", "adapter_mean",
@@ -338,11 +338,15 @@ class Engine:
         return sig.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), 0, (sig, lens)
 
     def detect_llr_rows(self, signals, full_lens, n: int, minibatch: int, with_start_peak: bool = False,
-                        device_ptrs: bool = False, rows_dev: Optional[int] = None):
-        """-> (rows ndarray[ROW_DTYPE] or None when rows_dev is given, mb_status int32[n_mb])"""
+                        device_ptrs: bool = False, rows_dev: Optional[int] = None, tails_nan: bool = False):
+        """-> (rows ndarray[ROW_DTYPE] or None when rows_dev is given, mb_status int32[n_mb]).
+        tails_nan: the caller guarantees that every row is NaN from min(full_len, m) on (the reference's own padding,
+        adapted/file_proc.py:170-174); the streaming passes then skip the padding (ADP_TAILS_NAN)."""
         sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
         if with_start_peak:
             flags |= ADP_WITH_START_PEAK
+        if tails_nan:
+            flags |= ADP_TAILS_NAN
         n_mb = (n + minibatch - 1) // minibatch
         mbs = np.zeros(n_mb, dtype=np.int32)
         if rows_dev is not None:

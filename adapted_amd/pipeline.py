@@ -87,7 +87,9 @@ class HostPipeline:
             self.eng.calibrate_i16(dsig, dlen, s["dcal"], s["dcal"] + self.N * 4, n, self.dsig16)
             dsig = self.dsig16
         if self.primary == "llr":
-            rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, self.mb, with_start_peak=self.with_start_peak, device_ptrs=True)
+            # (the staging slots are NaN padded by the reader / the on-device calibration: the passes may stop at each read's end)
+            rows, mbs = self.eng.detect_llr_rows(dsig, dlen, n, self.mb, with_start_peak=self.with_start_peak, device_ptrs=True,
+                                                 tails_nan=True)
             return rows, mbs
         if self.primary == "start_peak":
             return self.eng.detect_start_peak_rows(dsig, dlen, n, self.mb, device_ptrs=True), None

@@ -260,7 +260,8 @@ def main():
             return
         engines[k].detect_llr_rows(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, mb,
                                    with_start_peak=not args.no_start_peak, device_ptrs=True,
-                                   rows_dev=rows_t.data_ptr() + k * Rs * lib.ROW_DTYPE.itemsize)
+                                   rows_dev=rows_t.data_ptr() + k * Rs * lib.ROW_DTYPE.itemsize,
+                                   tails_nan=True)  # (the generator pads with NaN; no padding at all in the headline workload)
 
     def step():
         if NS == 1:

@@ -58,6 +58,9 @@ extern "C" {
 #define ADP_WITH_START_PEAK 4      /* LLR path: also fill the start_peak_* columns (extension) */
 #define ADP_TOPK_NONE 8            /* adp_validate_candidates: polya_end_topk is None (k must be 1) */
 #define ADP_BOUNDS_HOST 16         /* adp_validate_candidates: `bounds` is host memory even though ADP_IN_DEVICE is set */
+#define ADP_TAILS_NAN 32           /* adp_detect_llr: the caller guarantees that row r is NaN from min(full_len[r], m) on (the
+                                      padding of adapted/file_proc.py:170-174): the streaming passes then stop at the read's
+                                      end instead of reading the padding.  Without the flag the rows are taken as they are. */
 
 /* SigProcConfig, flattened.  Ranges are [lo, hi] with -inf/+inf for "None". */
 typedef struct adp_cfg {
