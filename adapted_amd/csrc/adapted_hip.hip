@@ -138,6 +138,30 @@ static int alloc_all(adp_handle *h)
     return 0;
 }
 
+// grid = (ceil(m / 1024), n); block = 256.  Read r's samples lie at packed[offs[r] .. offs[r] + min(full_len, m)).
+template <class SRC>
+__global__ void __launch_bounds__(256) k_expand_ragged(const SRC *__restrict__ packed, const int64_t *__restrict__ offs,
+                                                        const int32_t *__restrict__ full_len, const float *__restrict__ scale,
+                                                        const float *__restrict__ offset, int m, float *__restrict__ out)
+{
+    const int r = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= m) return;
+    const int len = full_len[r] < m ? (full_len[r] > 0 ? full_len[r] : 0) : m;
+    const SRC *src = packed + offs[r] + i0;
+    float *dst = out + (size_t)r * m + i0;
+    const float nanv = __builtin_nanf("");
+    float sc = 1.f, of = 0.f;
+    if (scale) { sc = scale[r]; of = offset[r]; }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (i0 + j >= m) break;
+        float v = nanv;
+        if (i0 + j < len) v = scale ? sc * ((float)src[j] + of) : (float)src[j];
+        dst[j] = v;
+    }
+}
+
 extern "C" {
 
 int adp_abi_version(void) { return ADP_ABI_VERSION; }
@@ -821,6 +845,23 @@ int adp_calibrate_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len
     if (!h || !raw || !full_len || !scale || !offset || !signals_out || n_reads < 1 || m < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     hipLaunchKernelGGL(k_calibrate_i16, dim3((m + 1023) / 1024, n_reads), dim3(256), 0, h->stream, raw, full_len, scale, offset, m, signals_out);
+    HIPCHK(hipGetLastError());
+    return ADP_OK;
+}
+
+int adp_expand_ragged(adp_handle *h, const void *packed, int is_int16, const int64_t *offsets, const int32_t *full_len,
+                      const float *scale, const float *offset, int n_reads, int m, float *signals_out)
+{
+    if (!h || !packed || !offsets || !full_len || !signals_out || n_reads < 1 || m < 1 || (is_int16 && (!scale || !offset))) {
+        g_err = "bad argument"; return ADP_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    const dim3 grid((m + 1023) / 1024, n_reads);
+    if (is_int16)
+        hipLaunchKernelGGL(k_expand_ragged<int16_t>, grid, dim3(256), 0, h->stream, (const int16_t *)packed, offsets, full_len, scale, offset, m, signals_out);
+    else
+        hipLaunchKernelGGL(k_expand_ragged<float>, grid, dim3(256), 0, h->stream, (const float *)packed, offsets, full_len,
+                           (const float *)nullptr, (const float *)nullptr, m, signals_out);
     HIPCHK(hipGetLastError());
     return ADP_OK;
 }

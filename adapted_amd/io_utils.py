@@ -222,3 +222,66 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+
+
+def yield_minibatches_packed(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
+                             preload_size: int, buffers, int16: bool = False, workers: Optional[int] = None):
+    """The reads of a minibatch packed back to back, for the ragged ingestion of adapted_amd.pipeline (ragged=True): fills
+    the buffers handed out by `buffers()` -- (flat, lengths int32 [N], offsets int64 [N + 1]) plus (scale, offset) float32
+    [N] when int16 -- with each read's first min(length, preload_size) samples at flat[offsets[k] : offsets[k + 1]] and
+    yields (k, ids).  The padded [N, preload_size] matrix of adapted/file_proc.py:143-190 is laid out on the device."""
+    if read_ids_incl and read_ids_excl:
+        read_ids_incl = read_ids_incl.difference(read_ids_excl)
+        read_ids_excl = set()
+    selection = list(read_ids_incl) if read_ids_incl else None
+    N, m = batch_size, preload_size
+    dt = np.int16 if int16 else np.float32
+    pool = _copy_pool(workers)
+    pending = []
+
+    def put(dst, signal, take, rid):
+        s = np.asarray(signal[:take], dtype=dt)
+        if s.size < take:
+            raise ValueError("read %s: %d samples stored, %d announced" % (rid, s.size, take))
+        dst[:] = s
+
+    def finish():
+        for f in pending:
+            f.result()
+        pending.clear()
+
+    cur = None
+    k = 0
+    it = _iter_reads_i16 if int16 else (lambda fn, sel: ((r, n, s, None, None) for r, n, s in _iter_reads(fn, sel)))
+    try:
+        for fn in files:
+            for rid, n_samples, signal, scale, offset in it(fn, selection):
+                if rid in read_ids_excl:
+                    continue
+                if cur is None:
+                    cur = buffers()
+                    ids = np.empty(N, dtype=object)
+                    cur[2][0] = 0
+                flat, lens, offs = cur[0], cur[1], cur[2]
+                take = max(0, min(m, int(n_samples)))
+                a = int(offs[k])
+                if pool is not None:
+                    pending.append(pool.submit(put, flat[a:a + take], signal, take, rid))
+                else:
+                    put(flat[a:a + take], signal, take, rid)
+                offs[k + 1] = a + take
+                lens[k], ids[k] = n_samples, rid
+                if int16:
+                    cur[3][k], cur[4][k] = scale, offset
+                k += 1
+                if k == N:
+                    finish()
+                    yield k, ids
+                    cur = None
+                    k = 0
+        if k:
+            finish()
+            yield k, ids[:k]
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)

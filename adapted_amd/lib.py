@@ -124,7 +124,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
-           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16"]
+           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -287,6 +287,14 @@ class Engine:
         on the handle's stream: the detect call that follows is ordered behind it)"""
         self._check(self.lib.adp_calibrate_i16(self._h, C.c_void_p(raw_dev), C.c_void_p(len_dev), C.c_void_p(scale_dev),
                                                C.c_void_p(offset_dev), int(n), self.m, C.c_void_p(out_dev)))
+
+    def expand_ragged(self, packed_dev: int, is_int16: bool, offs_dev: int, len_dev: int, n: int, out_dev: int,
+                      scale_dev: int = 0, offset_dev: int = 0):
+        """reads packed back to back (float32 pA, or int16 ADC + per-read calibration) -> float32 [n, m] NaN-padded, on the
+        device (asynchronous on the handle's stream)"""
+        self._check(self.lib.adp_expand_ragged(self._h, C.c_void_p(packed_dev), int(bool(is_int16)), C.c_void_p(offs_dev),
+                                               C.c_void_p(len_dev), C.c_void_p(scale_dev or None), C.c_void_p(offset_dev or None),
+                                               int(n), self.m, C.c_void_p(out_dev)))
 
     def host_alloc(self, shape, dtype) -> np.ndarray:
         """page-locked host array (staging for h2d_async); release with host_free(arr)"""

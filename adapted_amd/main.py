@@ -130,8 +130,11 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
     # pinned staging slots filled in place by a producer thread, H2D overlapped with the detect call, CSV writing in
     # a third thread (adapted_amd/pipeline.py); ranks take whole minibatches round-robin
     GROUP = 4  # minibatches per staging slot and detect call (normalisation stays per minibatch)
+    # one rank: the reads travel packed back to back and the padded matrix is laid out on the device (only the samples that
+    # exist cross PCIe); several ranks keep the dense slots (each takes every ws-th group out of the common stream)
+    ragged = ws == 1
     pipe = HostPipeline(spc, minibatch, m, device=device, primary=primary, with_start_peak=start_peak,
-                        model=model if primary == "cnn" else None, int16_input=int16_ingest, group=GROUP)
+                        model=model if primary == "cnn" else None, int16_input=int16_ingest, group=GROUP, ragged=ragged)
 
     def fill_i16(get_buffers):
         # raw ADC samples + calibration travel to the device, pA values are made there (extension, see pipeline.py)
@@ -147,7 +150,17 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
                 braw[:k], bl[:k], bsc[:k], bof[:k] = raw, lens, sc, of
             yield raw.shape[0], ids.copy()
 
+    def fill_packed(get_buffers):
+        from .io_utils import yield_minibatches_packed
+
+        for k, ids in yield_minibatches_packed(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, get_buffers,
+                                               int16=int16_ingest):
+            yield k, ids.copy()
+
     def fill(get_buffers):
+        if ragged:
+            yield from fill_packed(get_buffers)
+            return
         if int16_ingest:
             yield from fill_i16(get_buffers)
             return

@@ -29,23 +29,32 @@ from . import lib
 
 class HostPipeline:
     def __init__(self, spc, minibatch: int, m: int, device: int = 0, n_slots: int = 3, primary: str = "llr",
-                 with_start_peak: bool = False, model=None, int16_input: bool = False, group: int = 1):
+                 with_start_peak: bool = False, model=None, int16_input: bool = False, group: int = 1, ragged: bool = False):
         """int16_input: the staging slots hold raw ADC samples (int16) plus per-read (scale, offset); they are calibrated
         to float32 pA on the device (adp_calibrate_i16), so only 2 bytes per sample cross PCIe.  get_buffers() then hands
         out (raw, lengths, scale, offset) instead of (signals, lengths)."""
         """group: minibatches per staging slot and per detect call (a call over several minibatches fills the GPU better
         than one over 1000 reads; normalisation stays per minibatch)."""
+        """ragged: the staging slots hold the reads packed back to back (flat array + offsets int64 [N + 1]); only the samples
+        that exist cross PCIe and the NaN-padded [N, m] minibatch is laid out on the device (adp_expand_ragged).  With
+        heavy-tailed read lengths most of the padded matrix is padding.  get_buffers() hands out (flat, lengths, offsets)
+        -- plus (scale, offset) with int16_input."""
         self.spc, self.mb, self.m, self.device = spc, int(minibatch), int(m), int(device)
         self.N = self.mb * max(1, int(group))  # reads per slot
         self.primary, self.with_start_peak, self.model, self.i16 = primary, with_start_peak, model, bool(int16_input)
+        self.ragged = bool(ragged)
         self.eng = lib.Engine(spc, self.N, self.m, device=self.device)
         self.slots = []
-        self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4) if self.i16 else None  # calibrated minibatch (one: detect is serial)
+        # the float32 minibatch made on the device (calibrated and / or laid out from packed reads); one: detect is serial
+        self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4) if (self.i16 or self.ragged) else None
         for _ in range(min(16, max(2, n_slots))):
-            sig = self.eng.host_alloc((self.N, self.m), np.int16 if self.i16 else np.float32)
+            sig = self.eng.host_alloc((self.N * self.m,) if self.ragged else (self.N, self.m), np.int16 if self.i16 else np.float32)
             lens = self.eng.host_alloc((self.N,), np.int32)
             slot = {"sig": sig, "lens": lens, "ds": self.eng.dev_alloc(self.N * self.m * (2 if self.i16 else 4)),
                     "dl": self.eng.dev_alloc(self.N * 4)}
+            if self.ragged:
+                slot["offs"] = self.eng.host_alloc((self.N + 1,), np.int64)
+                slot["do"] = self.eng.dev_alloc((self.N + 1) * 8)
             if self.i16:
                 slot["cal"] = self.eng.host_alloc((2, self.N), np.float32)  # scale, offset
                 slot["dcal"] = self.eng.dev_alloc(2 * self.N * 4)
@@ -63,6 +72,9 @@ class HostPipeline:
             if "cal" in s:
                 self.eng.host_free(s["cal"])
                 self.eng.dev_free(s["dcal"])
+            if "offs" in s:
+                self.eng.host_free(s["offs"])
+                self.eng.dev_free(s["do"])
         if self.dsig16:
             self.eng.dev_free(self.dsig16)
             self.dsig16 = None
@@ -72,7 +84,11 @@ class HostPipeline:
     # -- stages -------------------------------------------------------------------------------
     def _start_h2d(self, j: int, n: int):
         s = self.slots[j]
-        self.eng.h2d_async(s["ds"], s["sig"], n * self.m * (2 if self.i16 else 4))
+        if self.ragged:  # only the samples that exist
+            self.eng.h2d_async(s["ds"], s["sig"], int(s["offs"][n]) * (2 if self.i16 else 4))
+            self.eng.h2d_async(s["do"], s["offs"], (n + 1) * 8)
+        else:
+            self.eng.h2d_async(s["ds"], s["sig"], n * self.m * (2 if self.i16 else 4))
         self.eng.h2d_async(s["dl"], s["lens"], n * 4)
         if self.i16:
             self.eng.h2d_async(s["dcal"], s["cal"])
@@ -83,7 +99,13 @@ class HostPipeline:
         s = self.slots[j]
         self.eng.copy_wait(j)  # this slot's copies only: the next slot's may still be in flight
         dsig, dlen = s["ds"], s["dl"]
-        if self.i16:  # raw ADC -> float32 pA, NaN beyond the read, on the engine's stream ahead of the detect kernels
+        if self.ragged:  # packed reads (-> calibrated) -> float32 [n, m], NaN beyond each read
+            if self.i16:
+                self.eng.expand_ragged(dsig, True, s["do"], dlen, n, self.dsig16, s["dcal"], s["dcal"] + self.N * 4)
+            else:
+                self.eng.expand_ragged(dsig, False, s["do"], dlen, n, self.dsig16)
+            dsig = self.dsig16
+        elif self.i16:  # raw ADC -> float32 pA, NaN beyond the read, on the engine's stream ahead of the detect kernels
             self.eng.calibrate_i16(dsig, dlen, s["dcal"], s["dcal"] + self.N * 4, n, self.dsig16)
             dsig = self.dsig16
         if self.primary == "llr":
@@ -111,9 +133,11 @@ class HostPipeline:
         def get_buffers():
             j = self.free.get()
             cur["j"] = j
+            sl = self.slots[j]
+            head = (sl["sig"], sl["lens"], sl["offs"]) if self.ragged else (sl["sig"], sl["lens"])
             if self.i16:
-                return self.slots[j]["sig"], self.slots[j]["lens"], self.slots[j]["cal"][0], self.slots[j]["cal"][1]
-            return self.slots[j]["sig"], self.slots[j]["lens"]
+                return head + (sl["cal"][0], sl["cal"][1])
+            return head
 
         def producer():
             try:

@@ -91,12 +91,22 @@ def host_pipeline_bench(args, spc, device):
     m, mb = spc.sig_preload_size, args.minibatch
     i16 = bool(args.int16)
     G = max(1, args.group)
-    pipe = HostPipeline(spc, mb, m, device=device, primary="llr", with_start_peak=not args.no_start_peak, int16_input=i16, group=G)
+    ragged = bool(args.ragged)
+    pipe = HostPipeline(spc, mb, m, device=device, primary="llr", with_start_peak=not args.no_start_peak, int16_input=i16, group=G,
+                        ragged=ragged)
     mb = mb * G  # reads per slot from here on
     pool = []
     dev = torch.device("cuda", device)
     d = torch.empty((mb, m), dtype=torch.float32, device=dev)
-    dl = torch.full((mb,), m, dtype=torch.int32, device=dev)
+    lens = np.full(mb, m, dtype=np.int32)
+    if args.lens == "pareto":
+        from adapted_amd import synth as _synth
+
+        lens = np.array([_synth.pareto_length(args.seed, i) for i in range(mb)], dtype=np.int32)
+    dl = torch.from_numpy(lens).to(dev)
+    take = np.minimum(lens, m).astype(np.int64)
+    offs = np.zeros(mb + 1, dtype=np.int64)
+    np.cumsum(take, out=offs[1:])
     sc, of = np.float32(0.17), np.float32(-12.0)  # a typical pod5 calibration
     for k in range(3):
         pipe.eng.synth_fill(d.data_ptr(), dl.data_ptr(), mb, seed=args.seed, first_read=k * mb, decorate=True)
@@ -105,7 +115,12 @@ def host_pipeline_bench(args, spc, device):
             pool.append(torch.clamp(torch.round(d / float(sc) - float(of)), -32768, 32767).to(torch.int16).cpu().numpy().copy())
         else:
             pool.append(d.cpu().numpy().copy())
-    lens = np.full(mb, m, dtype=np.int32)
+        if ragged:  # the same reads packed back to back
+            dense = pool[-1]
+            flat = np.empty(int(offs[-1]), dtype=dense.dtype)
+            for r in range(mb):
+                flat[offs[r]:offs[r + 1]] = dense[r, :take[r]]
+            pool[-1] = flat
     ids = np.arange(mb).astype(object)
     n_ok = [0]
     lock = threading.Lock()
@@ -120,9 +135,18 @@ def host_pipeline_bench(args, spc, device):
             bufs = get_buffers()
             sig, ln = bufs[0], bufs[1]
             if i16:
-                bufs[2][:] = sc
-                bufs[3][:] = of
-            if assemble:  # (host memcpy: the stand-in for a reader writing the minibatch)
+                bufs[-2][:] = sc
+                bufs[-1][:] = of
+            if ragged:
+                bufs[2][:] = offs
+                if assemble:
+                    src = pool[i % len(pool)]
+                    if ex is None:
+                        np.copyto(sig[:src.size], src)
+                    else:
+                        step = (src.size + K - 1) // K
+                        list(ex.map(lambda a: np.copyto(sig[a:a + step], src[a:a + step]), range(0, src.size, step)))
+            elif assemble:  # (host memcpy: the stand-in for a reader writing the minibatch)
                 src = pool[i % len(pool)]
                 if ex is None:
                     np.copyto(sig, src)
@@ -146,12 +170,14 @@ def host_pipeline_bench(args, spc, device):
     dt2 = time.perf_counter() - t1
     pipe.close()
     bps = 2 if i16 else 4
-    gb = total * m * bps / 1e9
+    per_read = (float(offs[-1]) / mb) if ragged else float(m)  # samples that cross PCIe per read
+    gb = total * per_read * bps / 1e9
     print(json.dumps({"metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads, HOST buffers (PCIe-inclusive; not the headline)",
                       "value": total / dt, "unit": "reads/s", "n_gpus": 1, "minibatches": args.host_pipeline,
                       "h2d_GB_per_s": gb / dt, "pass_rate": n_ok[0] / max(total + total2, 1),
-                      "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * m * bps / 1e9 / dt2},
-                      "input": "int16 ADC + device calibration" if i16 else "float32 pA", "fill_threads": K,
+                      "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * per_read * bps / 1e9 / dt2},
+                      "input": ("int16 ADC + device calibration" if i16 else "float32 pA") + (", reads packed back to back (ragged)" if ragged else ", padded [N, m] matrix"),
+                      "lens": "%s (mean %.0f of m = %d samples preloaded)" % (args.lens, float(take.mean()), m), "fill_threads": K,
                       "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}}))
 
 
@@ -168,6 +194,8 @@ def main():
     ap.add_argument("--lens", choices=["full", "pareto"], default="full",
                     help="read lengths: full (the headline workload: every read fills the window) or pareto (BASELINE configs[4]: "
                          "Pareto(1.2) clipped to [10k, 1M] samples -- most reads much shorter than the window, NaN padded; a probe)")
+    ap.add_argument("--ragged", action="store_true", help="with --host-pipeline: reads packed back to back in the staging slots, "
+                                                          "the padded matrix laid out on the device (adp_expand_ragged)")
     ap.add_argument("--adc-step", type=float, default=0.0,
                     help="(robustness probe, not the headline workload) round the synthetic samples to multiples of this many pA, "
                          "like calibrated int16 ADC data (~0.18 pA): exercises the tie handling of the exact selections")

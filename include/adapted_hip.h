@@ -209,6 +209,14 @@ int adp_memcpy_d2h(adp_handle *h, void *dst, const void *src, uint64_t bytes);
 int adp_calibrate_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len, const float *scale, const float *offset,
                       int n_reads, int m, float *signals_out);
 
+/* Ragged ingestion (extension, next to adp_calibrate_i16): the reads of a minibatch packed back to back -- read r's first
+ * min(full_len[r], m) samples at packed[offsets[r] ...], float32 pA or (is_int16) raw ADC samples with per-read
+ * calibration -- are laid out as the float32 [n, m] NaN-padded minibatch on the device.  Only the samples that exist
+ * cross PCIe: with heavy-tailed read lengths most of the padded matrix is NaN (84 % for BASELINE configs[4]).
+ * All pointers are DEVICE pointers; scale / offset may be NULL for float32 input. */
+int adp_expand_ragged(adp_handle *h, const void *packed, int is_int16, const int64_t *offsets, const int32_t *full_len,
+                      const float *scale, const float *offset, int n_reads, int m, float *signals_out);
+
 /* Streaming input (adapted_amd/pipeline.py): page-locked host staging memory, and a host-to-device copy on the handle's
  * COPY stream (neither the compute stream nor its side stream), so that the copy of the next minibatch overlaps the
  * detect call of the current one.  adp_copy_mark(slot) marks the copies issued so far (slot in [0, 16));

@@ -287,3 +287,56 @@ def test_mvs_detect_overwrite_rejects_a_search_window_inside_the_lag():
     spc.update_sig_preload_size()
     with pytest.raises(lib.HipLibraryError, match="search_window"):
         lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+
+
+@pytest.mark.parametrize("int16", [False, True])
+def test_ragged_pipeline_equals_padded_minibatches(tmp_path, int16):
+    """Ragged ingestion (HostPipeline ragged=True, adp_expand_ragged): reads packed back to back cross PCIe, the NaN-padded
+    [N, m] minibatch is laid out on the device -- rows identical to engine calls on the padded matrix the reference builds
+    (adapted/file_proc.py:143-190), for float32 pA and for raw int16 with on-device calibration; through the file reader
+    (yield_minibatches_packed) including a last, partial minibatch."""
+    from adapted_amd import lib, synth
+    from adapted_amd.io_utils import yield_minibatches_packed
+    from adapted_amd.pipeline import HostPipeline
+
+    case, spc, _, _, _ = load_case("rna004_llr_default")
+    m = spc.sig_preload_size
+    n, N = 40, 16
+    rng = np.random.default_rng(3)
+    lens = np.where(rng.random(n) < 0.4, m + 700, rng.integers(1100, m, n)).astype(np.int32)
+    sig, lens = synth.synth_batch(23, 0, n, m + 800, lens)  # (reads longer than the window keep their extra samples in the file)
+    ids = np.array(["r%03d" % i for i in range(n)], dtype=object)
+    sc, of = np.float32(0.17), np.float32(-12.0)
+    if int16:
+        raw = np.clip(np.round(np.nan_to_num(sig) / sc - of), -32768, 32767).astype(np.int16)
+        pa = (sc * (raw.astype(np.float32) + of)).astype(np.float32)
+        np.savez(tmp_path / "reads_0.npz", raw=raw, scale=np.full(n, sc), offset=np.full(n, of), full_lengths=lens, read_ids=ids)
+    else:
+        pa = sig
+        np.savez(tmp_path / "reads_0.npz", signals=sig, full_lengths=lens, read_ids=ids)
+    # the padded minibatches of the reference layout, straight into the engine
+    dense = np.full((n, m), np.nan, dtype=np.float32)
+    for r in range(n):
+        t = min(m, int(lens[r]))
+        dense[r, :t] = pa[r, :t]
+    eng = lib.Engine(spc, N, m, device=0)
+    want = {}
+    for s0 in range(0, n, N):
+        k = min(N, n - s0)
+        rows, mbs = eng.detect_llr_rows(dense[s0:s0 + k], lens[s0:s0 + k], k, k, with_start_peak=True)
+        assert mbs[0] == 0
+        want[s0 // N] = rows
+    eng.close()
+    pipe = HostPipeline(spc, N, m, device=0, primary="llr", with_start_peak=True, n_slots=2, int16_input=int16, ragged=True)
+    got = []
+
+    def fill(get_buffers):
+        for k, idv in yield_minibatches_packed([str(tmp_path / "reads_0.npz")], set(), set(), N, m, get_buffers, int16=int16):
+            yield k, idv.copy()
+
+    total = pipe.run(fill, lambda idv, rows: got.append((list(idv), rows.copy())))
+    pipe.close()
+    assert total == n and len(got) == 3
+    for q, (idv, rows) in enumerate(got):
+        assert idv == list(ids[q * N:(q + 1) * N])
+        assert rows.tobytes() == want[q].tobytes()
