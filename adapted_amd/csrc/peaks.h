@@ -53,72 +53,11 @@ static __device__ __forceinline__ int tv_peak_at(const TraceView &t, int i)
     return -1;
 }
 
-// prominence of the peak at p (scipy _peak_prominences, wlen = None)
-static __device__ double tv_prominence(const TraceView &t, int p)
-{
-    const double xp = tv_get(t, p);
-    double left_min = xp, right_min = xp;
-    int i = p;
-    while (i >= t.lo) {
-        if (t.bmax && (i & (SUMBLK - 1)) == SUMBLK - 1 && i - (SUMBLK - 1) >= t.lo) {
-            int b = i / SUMBLK;
-            if (t.bmax[b] <= xp) { double m = t.bmin[b]; if (m < left_min) left_min = m; i -= SUMBLK; continue; }
-        }
-        double v = tv_get(t, i);
-        if (!(v <= xp)) break;
-        if (v < left_min) left_min = v;
-        i--;
-    }
-    i = p;
-    while (i <= t.hi) {
-        if (t.bmax && (i & (SUMBLK - 1)) == 0 && i + (SUMBLK - 1) <= t.hi) {
-            int b = i / SUMBLK;
-            if (t.bmax[b] <= xp) { double m = t.bmin[b]; if (m < right_min) right_min = m; i += SUMBLK; continue; }
-        }
-        double v = tv_get(t, i);
-        if (!(v <= xp)) break;
-        if (v < right_min) right_min = v;
-        i++;
-    }
-    return xp - (left_min > right_min ? left_min : right_min);
-}
-
-// width of the peak at p at relative height rel (<= 1) (scipy _peak_widths).  For rel <= 1 the
-// walk stops by value at or before the prominence base, so the bases need not be carried.
-static __device__ double tv_width(const TraceView &t, int p, double prom, double rel)
-{
-    const double xp = tv_get(t, p);
-    const double height = xp - prom * rel;
-    int i = p;
-    while (i > t.lo) {
-        if (t.bmin && (i & (SUMBLK - 1)) == SUMBLK - 1 && i - (SUMBLK - 1) > t.lo) {
-            int b = i / SUMBLK;
-            if (t.bmin[b] > height && t.bmax[b] <= xp) { i -= SUMBLK; continue; }
-        }
-        if (!(height < tv_get(t, i))) break;
-        i--;
-    }
-    double left_ip = (double)i;
-    {
-        double xi = tv_get(t, i);
-        if (xi < height) left_ip += (height - xi) / (tv_get(t, i + 1) - xi);
-    }
-    i = p;
-    while (i < t.hi) {
-        if (t.bmin && (i & (SUMBLK - 1)) == 0 && i + (SUMBLK - 1) < t.hi) {
-            int b = i / SUMBLK;
-            if (t.bmin[b] > height && t.bmax[b] <= xp) { i += SUMBLK; continue; }
-        }
-        if (!(height < tv_get(t, i))) break;
-        i++;
-    }
-    double right_ip = (double)i;
-    {
-        double xi = tv_get(t, i);
-        if (xi < height) right_ip -= (height - xi) / (tv_get(t, i - 1) - xi);
-    }
-    return right_ip - left_ip;
-}
+// scipy's _peak_widths walks from the peak towards each side's prominence BASE -- the first sample, going away from the
+// peak, that attains the side's minimum -- and stops there at the latest.  At rel_height = 1 the evaluation height
+// x[p] - prominence is that minimum up to rounding, so whether the walk ends by value or at the base is decided by the last
+// bit: the walks below carry the two side minima and stop on a sample EQUAL to its side's minimum as well as on one at or
+// below the height (equivalent to carrying the base indices).
 
 // ---- long walks, cooperatively ------------------------------------------------------------------------
 // The dominant peak of a trace has nothing higher on either side: its prominence walk runs to the ends of the
@@ -128,20 +67,20 @@ static __device__ double tv_width(const TraceView &t, int p, double prom, double
 enum { WALK_PROM = 0, WALK_WIDTH = 1 };
 
 template <int KIND>
-static __device__ __forceinline__ bool walk_block_clean(double bmx, double bmn, double xp, double height)
+static __device__ __forceinline__ bool walk_block_clean(double bmx, double bmn, double xp, double height, double smin)
 {
-    return KIND == WALK_PROM ? (bmx <= xp) : (bmn > height && bmx <= xp);
+    return KIND == WALK_PROM ? (bmx <= xp) : (bmn > height && bmn > smin && bmx <= xp);
 }
 template <int KIND>
-static __device__ __forceinline__ bool walk_hit(double v, double xp, double height)
+static __device__ __forceinline__ bool walk_hit(double v, double xp, double height, double smin)
 {
-    return KIND == WALK_PROM ? !(v <= xp) : !(height < v);
+    return KIND == WALK_PROM ? !(v <= xp) : (!(height < v) || v == smin);
 }
 
 // nearest j in [limit, start], searching downwards, with walk_hit(x[j]); limit - 1 if none.  mn (WALK_PROM):
 // minimum of the samples passed, i.e. those above j.  Uniform call (all lanes, same arguments).
 template <int KIND>
-static __device__ int coop_find_down(const TraceView &t, int start, int limit, double xp, double height, double &mn)
+static __device__ int coop_find_down(const TraceView &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
 {
     const int ln = lane_id();
     double lmn = xp;
@@ -153,7 +92,7 @@ static __device__ int coop_find_down(const TraceView &t, int start, int limit, d
             const int bb = b - ln;
             const bool whole = bb >= 0 && bb * SUMBLK >= limit;
             const double bmx = whole ? t.bmax[bb] : 0.0, bmn = whole ? t.bmin[bb] : 0.0;
-            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height);
+            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height, smin);
             const unsigned long long m = __ballot(dirty);
             const int first = m ? __ffsll((long long)m) - 1 : 64;
             if (KIND == WALK_PROM && ln < first && bmn < lmn) lmn = bmn;
@@ -165,7 +104,7 @@ static __device__ int coop_find_down(const TraceView &t, int start, int limit, d
         const int e = bstart + ln;
         const bool in = e >= limit && e <= i;
         const double v = in ? tv_get(t, e) : 0.0;
-        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height));
+        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height, smin));
         if (m) {
             found = bstart + 63 - __clzll((long long)m);
             if (KIND == WALK_PROM && in && e > found && v < lmn) lmn = v;
@@ -180,7 +119,7 @@ static __device__ int coop_find_down(const TraceView &t, int start, int limit, d
 
 // nearest j in [start, limit], searching upwards; limit + 1 if none
 template <int KIND>
-static __device__ int coop_find_up(const TraceView &t, int start, int limit, double xp, double height, double &mn)
+static __device__ int coop_find_up(const TraceView &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
 {
     const int ln = lane_id();
     double lmn = xp;
@@ -191,7 +130,7 @@ static __device__ int coop_find_up(const TraceView &t, int start, int limit, dou
             const int bb = b + ln;
             const bool whole = bb * SUMBLK + SUMBLK - 1 <= limit;
             const double bmx = whole ? t.bmax[bb] : 0.0, bmn = whole ? t.bmin[bb] : 0.0;
-            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height);
+            const bool dirty = !whole || !walk_block_clean<KIND>(bmx, bmn, xp, height, smin);
             const unsigned long long m = __ballot(dirty);
             const int first = m ? __ffsll((long long)m) - 1 : 64;
             if (KIND == WALK_PROM && ln < first && bmn < lmn) lmn = bmn;
@@ -202,7 +141,7 @@ static __device__ int coop_find_up(const TraceView &t, int start, int limit, dou
         const int e = bstart + ln;
         const bool in = e >= i && e <= limit;
         const double v = in ? tv_get(t, e) : 0.0;
-        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height));
+        const unsigned long long m = __ballot(in && walk_hit<KIND>(v, xp, height, smin));
         if (m) {
             found = bstart + __ffsll((long long)m) - 1;
             if (KIND == WALK_PROM && in && e < found && v < lmn) lmn = v;
@@ -218,7 +157,7 @@ static __device__ int coop_find_up(const TraceView &t, int start, int limit, dou
 // the walks of tv_prominence / tv_width with a step budget: false if a walk was cut short.  Eight samples are
 // loaded per round trip to memory (the loads do not depend on the comparisons), then examined in walk order.
 #define WALK_CHUNK 8
-static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budget, double &prom)
+static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budget, double &prom, double &lmin_out, double &rmin_out)
 {
     const double xp = tv_get(t, p);
     double left_min = xp, right_min = xp;
@@ -251,9 +190,10 @@ static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budge
         }
     }
     prom = xp - (left_min > right_min ? left_min : right_min);
+    lmin_out = left_min; rmin_out = right_min;
     return true;
 }
-static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, double rel, int budget, double &width)
+static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, double rel, int budget, double &width, double lmin, double rmin)
 {
     const double xp = tv_get(t, p);
     const double height = xp - prom * rel;
@@ -270,7 +210,7 @@ static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, d
             for (int u = 0; u < WALK_CHUNK; u++) {
                 if (!stopped) {
                     if (i0 - u <= t.lo) { stopped = true; il = t.lo; }
-                    else if (!(height < v[u])) { stopped = true; il = i0 - u; }
+                    else if (!(height < v[u]) || v[u] == lmin) { stopped = true; il = i0 - u; }
                 }
             }
         }
@@ -287,7 +227,7 @@ static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, d
             for (int u = 0; u < WALK_CHUNK; u++) {
                 if (!stopped) {
                     if (i0 + u >= t.hi) { stopped = true; ir = t.hi; }
-                    else if (!(height < v[u])) { stopped = true; ir = i0 + u; }
+                    else if (!(height < v[u]) || v[u] == rmin) { stopped = true; ir = i0 + u; }
                 }
             }
         }
@@ -305,9 +245,9 @@ static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, d
 static __device__ bool wave_peak_ok(const TraceView &t, int p, double pmin, double wmin, double rel)
 {
     const int ln = lane_id();
-    double prom = 0.0;
+    double prom = 0.0, lmn = 0.0, rmn = 0.0; // prominence and the minima of the two sides (the values at the bases)
     bool have = p >= 0, done = true;
-    if (have) done = tv_prominence_budget(t, p, WALK_BUDGET, prom);
+    if (have) done = tv_prominence_budget(t, p, WALK_BUDGET, prom, lmn, rmn);
     unsigned long long todo = __ballot(have && !done);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
@@ -317,24 +257,25 @@ static __device__ bool wave_peak_ok(const TraceView &t, int p, double pmin, doub
         double lmin, rmin;
         coop_find_down<WALK_PROM>(t, pp, t.lo, xp, 0.0, lmin);
         coop_find_up<WALK_PROM>(t, pp, t.hi, xp, 0.0, rmin);
-        if (ln == src) prom = xp - (lmin > rmin ? lmin : rmin);
+        if (ln == src) { prom = xp - (lmin > rmin ? lmin : rmin); lmn = lmin; rmn = rmin; }
     }
     bool cand = have && (pmin <= prom);
     double width = 0.0;
     done = true;
-    if (cand) done = tv_width_budget(t, p, prom, rel, WALK_BUDGET, width);
+    if (cand) done = tv_width_budget(t, p, prom, rel, WALK_BUDGET, width, lmn, rmn);
     todo = __ballot(cand && !done);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const int pp = __shfl(p, src);
         const double pr = __shfl(prom, src);
+        const double sl = __shfl(lmn, src), sr = __shfl(rmn, src);
         const double xp = tv_get(t, pp);
         const double height = xp - pr * rel;
         double dummy;
-        int il = coop_find_down<WALK_WIDTH>(t, pp, t.lo + 1, xp, height, dummy);
+        int il = coop_find_down<WALK_WIDTH>(t, pp, t.lo + 1, xp, height, dummy, sl);
         if (il < t.lo + 1) il = t.lo;
-        int ir = coop_find_up<WALK_WIDTH>(t, pp, t.hi - 1, xp, height, dummy);
+        int ir = coop_find_up<WALK_WIDTH>(t, pp, t.hi - 1, xp, height, dummy, sr);
         if (ir > t.hi - 1) ir = t.hi;
         double left_ip = (double)il, right_ip = (double)ir;
         { double xi = tv_get(t, il); if (xi < height) left_ip += (height - xi) / (tv_get(t, il + 1) - xi); }

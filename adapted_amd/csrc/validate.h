@@ -757,7 +757,7 @@ __global__ void k_sp_decorate(const SpOut *__restrict__ sp, adp_row *__restrict_
         memset(o, 0, sizeof(*o)); o->n_cand = -1; o->n_open_pores = -1; o->success = 0; o->fail_code = ADP_F_EXC_SLICE;
         return;
     }
-    if (o->fail_code >= ADP_F_EXC_TOPK_NONE) return;
+    if (ADP_F_IS_EXCEPTION(o->fail_code)) return; // (the reference raised: a bare DetectResults)
     SpOut s = sp[r];
     if (!s.valid) return;
     if (mode == 0 && o->present == 0) return; // dropped minibatch

@@ -1213,7 +1213,7 @@ void orc_detect_cnn_from_preds(const float *batch, const int32_t *full_len, long
         const float *row = batch + r * m;
         const int64_t *p = preds + r * (1 + k);
         orc_validate(row, m, full_len[r], (long)p[0], (long)p[1], p + 1, k, cfg, &rows[r]);
-        if (!rows[r].success && rows[r].fail_code < F_EXC_TOPK_NONE && p[0] > 0 && p[1] > 0 && p[1] - p[0] > 1000 &&
+        if (!rows[r].success && !(rows[r].fail_code >= 9 && rows[r].fail_code <= 14) && p[0] > 0 && p[1] > 0 && p[1] - p[0] > 1000 &&
             full_len[r] < 2 * (long)cfg->max_obs_adapter && cfg->fallback_to_llr_short_reads) {
             int st;
             long pe = orc_cnn_fallback(row, m, full_len[r], (long)p[0], (long)p[1], cfg, &st);

@@ -208,3 +208,33 @@ def test_n1_fused_single_pass_is_exact_or_falls_back(hip, oracle_mod, kind, monk
     print(kind, "fused attempts/median misses/MAD misses:", (after - before)[5:8])
     # (small batches are clustered samples: the brackets may well miss, or not be set up at all)
     eng.close()
+
+
+def test_width_walk_stops_at_the_prominence_base(hip, oracle_mod):
+    """scipy's peak_widths walks no further than the prominence base of each side.  With rel_height = 1 the evaluation
+    height equals the base's value up to rounding, so a walk that stops by value alone may run past the base to the end of
+    the clipped trace: here the adapter peak is 74.69 pooled points wide against a threshold of 75 (RNA002, a 100-point
+    trace) -- one more point flips "No adapter detected" into a detection.  (Found by tools/soak_vs_oracle.py.)"""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA002")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+    spc.core.max_obs_trace = 4000
+    spc.med_shift.detect_med_shift = True
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m, n, it = spc.sig_preload_size, 160, 15
+    lo = spc.core.min_obs_adapter + 2 * spc.core.downscale_factor + 8
+    lens = np.array([max(lo, synth.pareto_length(it, i, lo=3000, hi=4 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(100 + it, 0, n, m, lens)
+    sig, lens = sig[80:], lens[80:]
+    eng = _engine(hip, spc, 80, m)
+    rows, mbs = eng.detect_llr_rows(sig, lens, 80, 80, with_start_peak=True)
+    got = lib.rows_to_results(rows, "llr")
+    want = oracle_mod.detect_llr(sig, lens, spc, with_start_peak=True)
+    assert want[3]["llr_adapter_end"] == 0 and want[3]["fail_reason"] == "No adapter detected (primary)"
+    from util import row_diffs
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got, want)) for d in [row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")})] if d]
+    assert not bad, bad[:3]
+    eng.close()

@@ -1,0 +1,66 @@
+"""Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
+several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
+    python tools/soak_vs_oracle.py [n_rounds]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from adapted_amd import lib, synth  # noqa: E402
+from adapted_amd.config import get_chemistry_specific_config  # noqa: E402
+from oracle import oracle  # noqa: E402
+from util import row_diffs  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    rng = np.random.default_rng(2024)
+    bad_total = 0
+    for it in range(rounds):
+        chem = ["RNA004", "RNA002"][it % 2]
+        spc = get_chemistry_specific_config(chem)
+        spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+        spc.core.max_obs_trace = int(rng.choice([4000, 16000, 25000, 60000]))
+        spc.mvs_polya.mvs_detect_overwrite = bool(it % 3 == 2)
+        spc.med_shift.detect_med_shift = bool(it % 2)
+        spc.update_primary_method()
+        spc.update_sig_preload_size()
+        m = spc.sig_preload_size
+        n = 160
+        lo = spc.core.min_obs_adapter + 2 * spc.core.downscale_factor + 8
+        lens = np.array([max(lo, synth.pareto_length(it, i, lo=3000, hi=4 * m)) for i in range(n)], dtype=np.int32)
+        sig, lens = synth.synth_batch(100 + it, 0, n, m, lens)
+        step = [0.0, 0.18, 0.05][it % 3]
+        if step:
+            q = np.float32(step)
+            sig = (np.round(sig / q) * q).astype(np.float32)
+        eng = lib.Engine(spc, n, m, device=0)
+        rows, mbs = eng.detect_llr_rows(sig, lens, n, 80, with_start_peak=True, tails_nan=bool(it % 2))
+        got = lib.rows_to_results(rows, "llr")
+        want = []
+        for s0 in range(0, n, 80):
+            want += oracle.detect_llr(sig[s0:s0 + 80], lens[s0:s0 + 80], spc, with_start_peak=True)
+        bad = 0
+        shown = 0
+        for i, (g, w) in enumerate(zip(got, want)):
+            d = row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")})
+            bad += len(d)
+            if d and shown < 3:
+                shown += 1
+                print("   read %d (len %d): %s" % (i, lens[i], d[:6]), flush=True)
+        ok = sum(1 for g in got if g.success)
+        print("round %d %s T=%d m=%d step=%.2f overwrite=%d mbs=%s pass=%d/%d differing fields: %d" % (
+            it, chem, spc.core.max_obs_trace, m, step, spc.mvs_polya.mvs_detect_overwrite, list(mbs), ok, n, bad), flush=True)
+        bad_total += bad
+        eng.close()
+    print("TOTAL differing fields:", bad_total)
+    return 1 if bad_total else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
