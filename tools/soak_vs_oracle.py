@@ -1,6 +1,6 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tools/soak_vs_oracle.py [n_rounds]
+    python tools/soak_vs_oracle.py [n_rounds] [start_peak]
 """
 import os
 import sys
@@ -28,6 +28,16 @@ def main():
         spc.core.max_obs_trace = int(rng.choice([4000, 16000, 25000, 60000]))
         spc.mvs_polya.mvs_detect_overwrite = bool(it % 3 == 2)
         spc.med_shift.detect_med_shift = bool(it % 2)
+        if it >= 12:  # perturbed thresholds: decisions land near their limits more often
+            spc.llr_boundaries.adapter_peak_width = int(rng.integers(200, 2500))
+            spc.llr_boundaries.adapter_peak_prominence = float(rng.choice([0.5, 1.0, 2.0]))
+            spc.mvs_polya.pA_var_window = int(rng.choice([50, 100, 200]))
+            spc.mvs_polya.pA_mean_window = int(rng.choice([10, 20, 60]))
+            spc.mvs_polya.median_shift_window = int(rng.choice([500, 1000, 2000]))
+            spc.mvs_polya.search_window = int(rng.choice([300, 500, 900]))
+            spc.real_range.mean_window = int(rng.choice([100, 300]))
+            spc.real_range.max_obs_local_range = int(rng.choice([1000, 5000]))
+            spc.med_shift.med_shift_window = int(rng.choice([500, 2000]))
         spc.update_primary_method()
         spc.update_sig_preload_size()
         m = spc.sig_preload_size
@@ -39,12 +49,23 @@ def main():
         if step:
             q = np.float32(step)
             sig = (np.round(sig / q) * q).astype(np.float32)
+        sp_primary = len(sys.argv) > 2 and sys.argv[2] == "start_peak"
+        if sp_primary:  # the start-peak primary (API only in the reference): validation without the MVS candidates
+            spc.llr_boundaries.llr_detect, spc.rna_start_peak.detect_rna_start_peak = False, True
+            spc.mvs_polya.mvs_detect_check = bool(it % 4 == 0)  # (on: the reference raises for every read, topk is None)
+            spc.update_primary_method()
         eng = lib.Engine(spc, n, m, device=0)
-        rows, mbs = eng.detect_llr_rows(sig, lens, n, 80, with_start_peak=True, tails_nan=bool(it % 2))
-        got = lib.rows_to_results(rows, "llr")
-        want = []
-        for s0 in range(0, n, 80):
-            want += oracle.detect_llr(sig[s0:s0 + 80], lens[s0:s0 + 80], spc, with_start_peak=True)
+        if sp_primary:
+            rows = eng.detect_start_peak_rows(sig, lens, n, 80)
+            mbs = np.zeros(2, dtype=np.int32)
+            got = lib.rows_to_results(rows, "start_peak")
+            want = oracle.detect_start_peak(sig, lens, spc)
+        else:
+            rows, mbs = eng.detect_llr_rows(sig, lens, n, 80, with_start_peak=True, tails_nan=bool(it % 2))
+            got = lib.rows_to_results(rows, "llr")
+            want = []
+            for s0 in range(0, n, 80):
+                want += oracle.detect_llr(sig[s0:s0 + 80], lens[s0:s0 + 80], spc, with_start_peak=True)
         bad = 0
         shown = 0
         for i, (g, w) in enumerate(zip(got, want)):
