@@ -1,6 +1,6 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tools/soak_vs_oracle.py [n_rounds] [start_peak]
+    python tools/soak_vs_oracle.py [n_rounds] [start_peak | big]
 """
 import os
 import sys
@@ -26,6 +26,9 @@ def main():
         spc = get_chemistry_specific_config(chem)
         spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
         spc.core.max_obs_trace = int(rng.choice([4000, 16000, 25000, 60000]))
+        big = len(sys.argv) > 2 and sys.argv[2] == "big"  # the headline window; minibatches of 100 reads reach the fused N1 pass
+        if big:
+            spc.core.max_obs_trace = 200000
         spc.mvs_polya.mvs_detect_overwrite = bool(it % 3 == 2)
         spc.med_shift.detect_med_shift = bool(it % 2)
         if it >= 12:  # perturbed thresholds: decisions land near their limits more often
@@ -41,9 +44,12 @@ def main():
         spc.update_primary_method()
         spc.update_sig_preload_size()
         m = spc.sig_preload_size
-        n = 160
+        n = 200 if big else 160
+        mbn = 100 if big else 80
         lo = spc.core.min_obs_adapter + 2 * spc.core.downscale_factor + 8
         lens = np.array([max(lo, synth.pareto_length(it, i, lo=3000, hi=4 * m)) for i in range(n)], dtype=np.int32)
+        if big and it % 2 == 0:
+            lens[:] = np.where(rng.random(n) < 0.6, m, lens)  # mostly full-length reads
         sig, lens = synth.synth_batch(100 + it, 0, n, m, lens)
         step = [0.0, 0.18, 0.05][it % 3]
         if step:
@@ -56,16 +62,16 @@ def main():
             spc.update_primary_method()
         eng = lib.Engine(spc, n, m, device=0)
         if sp_primary:
-            rows = eng.detect_start_peak_rows(sig, lens, n, 80)
+            rows = eng.detect_start_peak_rows(sig, lens, n, mbn)
             mbs = np.zeros(2, dtype=np.int32)
             got = lib.rows_to_results(rows, "start_peak")
             want = oracle.detect_start_peak(sig, lens, spc)
         else:
-            rows, mbs = eng.detect_llr_rows(sig, lens, n, 80, with_start_peak=True, tails_nan=bool(it % 2))
+            rows, mbs = eng.detect_llr_rows(sig, lens, n, mbn, with_start_peak=True, tails_nan=bool(it % 2))
             got = lib.rows_to_results(rows, "llr")
             want = []
-            for s0 in range(0, n, 80):
-                want += oracle.detect_llr(sig[s0:s0 + 80], lens[s0:s0 + 80], spc, with_start_peak=True)
+            for s0 in range(0, n, mbn):
+                want += oracle.detect_llr(sig[s0:s0 + mbn], lens[s0:s0 + mbn], spc, with_start_peak=True)
         bad = 0
         shown = 0
         for i, (g, w) in enumerate(zip(got, want)):
@@ -75,8 +81,9 @@ def main():
                 shown += 1
                 print("   read %d (len %d): %s" % (i, lens[i], d[:6]), flush=True)
         ok = sum(1 for g in got if g.success)
-        print("round %d %s T=%d m=%d step=%.2f overwrite=%d mbs=%s pass=%d/%d differing fields: %d" % (
-            it, chem, spc.core.max_obs_trace, m, step, spc.mvs_polya.mvs_detect_overwrite, list(mbs), ok, n, bad), flush=True)
+        cnt = eng.debug_counters(8)
+        print("round %d %s T=%d m=%d step=%.2f overwrite=%d mbs=%s pass=%d/%d differing fields: %d  (N1 single pass tried/median missed/MAD missed: %s)" % (
+            it, chem, spc.core.max_obs_trace, m, step, spc.mvs_polya.mvs_detect_overwrite, list(mbs), ok, n, bad, list(cnt[5:8])), flush=True)
         bad_total += bad
         eng.close()
     print("TOTAL differing fields:", bad_total)
