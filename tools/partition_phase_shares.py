@@ -2,7 +2,7 @@
 tallies of a -DADP_PHASE_TIMING build of the library:
 
     hipcc <flags of adapted_amd/build.py> -DADP_PHASE_TIMING -o /tmp/phase.so adapted_amd/csrc/adapted_hip.hip
-    ADAPTED_HIP_LIB=/tmp/phase.so python tools/partition_phase_shares.py
+    ADAPTED_HIP_LIB=/tmp/phase.so python tools/partition_phase_shares.py [pareto]
 """
 import sys, numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -15,6 +15,9 @@ R, mb = 8000, 500
 eng = lib.Engine(spc, R, m, device=0)
 sig = torch.empty((R, m), dtype=torch.float32, device="cuda")
 ln = torch.full((R,), m, dtype=torch.int32, device="cuda")
+if len(sys.argv) > 1 and sys.argv[1] == "pareto":  # heavy-tailed lengths (BASELINE configs[4])
+    from adapted_amd import synth
+    ln = torch.tensor([synth.pareto_length(1, i) for i in range(R)], dtype=torch.int32, device="cuda")
 rows = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device="cuda")
 eng.synth_fill(sig.data_ptr(), ln.data_ptr(), R, seed=1, first_read=0, decorate=True)
 eng.detect_llr_rows(sig.data_ptr(), ln.data_ptr(), R, mb, with_start_peak=True, device_ptrs=True, rows_dev=rows.data_ptr())
