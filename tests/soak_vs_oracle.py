@@ -1,6 +1,6 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tools/soak_vs_oracle.py [n_rounds] [start_peak | big]
+    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big]
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))  # (the oracle is test infrastructure: this script lives with the tests)
 
 from adapted_amd import lib, synth  # noqa: E402
 from adapted_amd.config import get_chemistry_specific_config  # noqa: E402

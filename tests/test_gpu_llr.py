@@ -214,7 +214,7 @@ def test_width_walk_stops_at_the_prominence_base(hip, oracle_mod):
     """scipy's peak_widths walks no further than the prominence base of each side.  With rel_height = 1 the evaluation
     height equals the base's value up to rounding, so a walk that stops by value alone may run past the base to the end of
     the clipped trace: here the adapter peak is 74.69 pooled points wide against a threshold of 75 (RNA002, a 100-point
-    trace) -- one more point flips "No adapter detected" into a detection.  (Found by tools/soak_vs_oracle.py.)"""
+    trace) -- one more point flips "No adapter detected" into a detection.  (Found by tests/soak_vs_oracle.py.)"""
     from adapted_amd import lib, synth
     from adapted_amd.config import get_chemistry_specific_config
 
