@@ -1,6 +1,6 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big]
+    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big | candidates]
 """
 import os
 import sys
@@ -60,8 +60,29 @@ def main():
             spc.llr_boundaries.llr_detect, spc.rna_start_peak.detect_rna_start_peak = False, True
             spc.mvs_polya.mvs_detect_check = bool(it % 4 == 0)  # (on: the reference raises for every read, topk is None)
             spc.update_primary_method()
+        cand_mode = len(sys.argv) > 2 and sys.argv[2] == "candidates"
         eng = lib.Engine(spc, n, m, device=0)
-        if sp_primary:
+        if cand_mode:  # the CNN path's validator: adapter end + k candidate poly(A) ends per read (0 ends the list)
+            r0, _ = eng.detect_llr_rows(sig, lens, n, mbn)
+            g0 = lib.rows_to_results(r0, "llr")
+            ae = np.array([g.llr_adapter_end or 0 for g in g0], dtype=np.int64)
+            pe = np.array([g.llr_polya_end or 0 for g in g0], dtype=np.int64)
+            k = int(rng.integers(1, 6))
+            bounds = np.zeros((n, 1 + k), dtype=np.int64)
+            bounds[:, 0] = np.where(rng.random(n) < 0.9, ae, 0)
+            for c in range(k):
+                jit = rng.integers(-400, 1500, n)
+                col = np.where(pe > 0, np.maximum(pe + jit * (c > 0), 0), 0)
+                bounds[:, 1 + c] = np.where(rng.random(n) < (0.9 if c == 0 else 0.6), col, 0)
+            spc.cnn_boundaries.cnn_detect, spc.llr_boundaries.llr_detect = True, False
+            spc.cnn_boundaries.fallback_to_llr_short_reads = False
+            spc.update_primary_method()
+            eng.close()
+            eng = lib.Engine(spc, n, m, device=0)
+            got = lib.rows_to_results(eng.validate_rows(sig, lens, n, bounds), "cnn")
+            want = oracle.detect_cnn_from_preds(sig, lens, bounds, spc)
+            mbs = np.zeros(2, dtype=np.int32)
+        elif sp_primary:
             rows = eng.detect_start_peak_rows(sig, lens, n, mbn)
             mbs = np.zeros(2, dtype=np.int32)
             got = lib.rows_to_results(rows, "start_peak")
