@@ -670,6 +670,20 @@ static __device__ SegStats block_segment_stats(const float *__restrict__ x, int 
     sp.key = wlo;
     SumAux p1 = (have_medmad || (g_ablate & 2048)) ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, sp);
     o.mean = p1.sum / (float)n;
+    if (o.mean != o.mean) {
+        // a NaN mean: a NaN sample (np.std, np.median and the MAD are NaN as well then) or infinities of both signs (they are
+        // not).  Never the case for the reads of a run; one look at the segment decides.
+        __syncthreads();
+        if (tid == 0) bs->flag = 0;
+        __syncthreads();
+        bool nanhere = false;
+        for (int i = tid; i < n; i += BS_THREADS) { const float v = x[i]; nanhere |= v != v; }
+        if (__any(nanhere) && (tid & 63) == 0) bs->flag = 1;
+        __syncthreads();
+        const bool any_nan = bs->flag != 0;
+        __syncthreads();
+        if (any_nan) { o.sd = o.med = o.mad = __builtin_nanf(""); return o; }
+    }
     phase(0);
     bool fallback_med = false, predicted = false;
     int bin = 0, rk = 0;

@@ -63,13 +63,21 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
 {
     const int ln = lane_id();
     uint32_t mn = 0xffffffffu, mx = 0u;
+    bool has_nan = false;
     for (int base = 0; base < n; base += 512) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : x[0]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { uint32_t key = f2key(ws_xform(v[u], mode, c)); mn = key < mn ? key : mn; mx = key > mx ? key : mx; }
+        for (int u = 0; u < 8; u++) {
+            const float xf = ws_xform(v[u], mode, c);
+            has_nan |= xf != xf;
+            uint32_t key = f2key(xf); mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+        }
     }
+    // np.partition sorts NaN behind everything and np.median / np.percentile return NaN when one is present
+    // (numpy/lib/_function_base_impl.py _median, _quantile): so do the order statistics here
+    if (__any(has_nan)) { vk = __builtin_nanf(""); vkm1 = vk; return; }
     mn = wave_min(mn); mx = wave_max(mx);
     const uint32_t span = mx - mn;
     int rb = span ? 32 - __clz(span) : 0; // bits of d still unresolved

@@ -340,3 +340,12 @@ def test_ragged_pipeline_equals_padded_minibatches(tmp_path, int16):
     for q, (idv, rows) in enumerate(got):
         assert idv == list(ids[q * N:(q + 1) * N])
         assert rows.tobytes() == want[q].tobytes()
+
+
+def test_hostile_inputs_equal_the_oracle(oracle_mod):
+    """Infinities, magnitudes of 1e30 and 1e-30, negative signals, constant stretches, NaN holes inside reads (np.median and
+    np.percentile return NaN then), duplicated and integer-valued samples: every field as the oracle has it
+    (tests/abuse_vs_oracle.py holds the cases)."""
+    import abuse_vs_oracle
+
+    assert abuse_vs_oracle.main() == 0
