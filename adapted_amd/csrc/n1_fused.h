@@ -321,6 +321,22 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
             for (int seg = 0; seg < T4; seg += q4) {
                 const int send = min(T4, seg + q4);
                 int i = seg + threadIdx.x;
+                for (; i + 3 * N1_THREADS < send; i += 4 * N1_THREADS) { // four loads in flight per lane (-3 % against two)
+                    float4 v0 = ld_stream4(&row4[i]), v1 = ld_stream4(&row4[i + N1_THREADS]), v2 = ld_stream4(&row4[i + 2 * N1_THREADS]),
+                           v3 = ld_stream4(&row4[i + 3 * N1_THREADS]);
+                    const float e[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+                    uint32_t fl = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) fl |= n1f_count(e[q], med_s, A0, A1, D0, D1, a) << q;
+                    while (fl) {
+                        const int q = __ffs(fl) - 1;
+                        fl &= fl - 1;
+                        float x = e[0];
+#pragma unroll
+                        for (int z = 1; z < 16; z++) x = (q == z) ? e[z] : x;
+                        n1f_copy(x, med_s, D0, cbm, cbb, cnt2, nh, hkeys, hcnt);
+                    }
+                }
                 for (; i + N1_THREADS < send; i += 2 * N1_THREADS) { // two loads in flight per lane
                     float4 v = ld_stream4(&row4[i]), w = ld_stream4(&row4[i + N1_THREADS]);
                     const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
