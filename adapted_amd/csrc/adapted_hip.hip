@@ -69,6 +69,10 @@ struct adp_handle {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     int last_n = 0, last_nmb = 0;
+    int layout = 0;   // ADP_LAYOUT_*: 1 = the single-read API (pooled from sample 0)
+    int oh1 = 5;      // head offset of the first gains pass
+    int pos_off = 0;  // added to pooled indices * ds for sample positions
+    DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
 };
 
 static int geom(adp_handle *h)
@@ -88,6 +92,12 @@ static int geom(adp_handle *h)
     h->T = c.max_obs_trace < h->m ? c.max_obs_trace : h->m;
     h->off = c.min_obs_adapter;
     h->ds = c.downscale_factor;
+    h->oh1 = 5; h->pos_off = h->off;
+    if (h->layout == ADP_LAYOUT_SINGLE_READ) { // combined_detect_llr: no min_obs_adapter slice, a longer head offset instead,
+        h->off = 0;                             // and min_obs_adapter still added to the positions (combined.py:66-68, 93-95)
+        h->oh1 = 5 + c.min_obs_adapter / c.downscale_factor;
+        h->pos_off = c.min_obs_adapter;
+    }
     int Lseg = h->T - h->off;
     h->L = Lseg > 0 ? (Lseg + h->ds - 1) / h->ds : 0;
     h->Lp = ((h->L + 63) / 64) * 64;
@@ -202,7 +212,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -440,6 +450,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
 {
     if (!h || !signals || !full_len || n < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    if (h->layout == ADP_LAYOUT_SINGLE_READ && minibatch != 1) { g_err = "the single-read layout normalises every read on its own: minibatch must be 1"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear();
     h->ev_used = 0;
@@ -468,8 +479,19 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (rc) return rc;
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
+            const int64_t *rng = nullptr;
+            if (h->layout == ADP_LAYOUT_SINGLE_READ) {
+                // the reference pools the unpadded read: its last, ragged block is filled up with zeros at the READ's end
+                // (downscale.py:22-29), which is what the per-read range [0, min(T, full_len)) does here
+                if (h->rng0.ensure((size_t)n * 16)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+                std::vector<int64_t> hr((size_t)2 * n);
+                for (int i = 0; i < n; i++) { hr[2 * i] = 0; hr[2 * i + 1] = T; }
+                HIPCHK(hipMemcpyAsync(h->rng0.p, hr.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+                HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope)
+                rng = h->rng0.as<int64_t>();
+            }
             hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
-                               minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
+                               minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), rng,
                                dlen, (flags & ADP_TAILS_NAN) ? 1 : 0);
         }
         if (upto >= 2)
@@ -493,7 +515,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<1>");
             hipLaunchKernelGGL(k_gains<1>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n, h->oh1);
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
@@ -506,7 +528,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n, 5);
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
@@ -519,7 +541,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     if (upto >= 8) {
         if (h->L > 0)
             hipLaunchKernelGGL(k_llr_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->adapter_idx.as<int32_t>(),
-                               h->polya_idx.as<int32_t>(), n, h->ds, h->off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>());
+                               h->polya_idx.as<int32_t>(), n, h->ds, h->pos_off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>(), h->layout == ADP_LAYOUT_SINGLE_READ ? 1 : 0);
         rc = launch_validate(h, dsig, dlen, n, m, 1, minibatch, true);
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
@@ -545,6 +567,18 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
 }
 
 extern "C" {
+
+int adp_set_layout(adp_handle *h, int layout)
+{
+    if (!h || (layout != ADP_LAYOUT_MINIBATCH && layout != ADP_LAYOUT_SINGLE_READ)) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const int old = h->layout;
+    h->layout = layout;
+    int rc = geom(h);
+    if (!rc && alloc_all(h)) { g_err = "device allocation failed"; rc = ADP_ERR_HIP; }
+    if (rc) { h->layout = old; (void)geom(h); }
+    return rc;
+}
 
 int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch, int flags,
                    adp_row *rows_out, int32_t *mb_status)
@@ -769,7 +803,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
                        h->ck.as<double2>(), h->tail.as<double2>());
     hipLaunchKernelGGL(k_gains<1>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), 1, mbs, h->trace.as<double>(),
-                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr, n);
+                       h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 1, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, (double *)nullptr, n, 5);
     int grid = n < h->pslots ? n : h->pslots;
     hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)(((h->Lp / 2 + 1) + 8) / 16 + 2) * 4, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                        h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, 1, mbs,

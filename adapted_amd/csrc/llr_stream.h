@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
                                               int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
-                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat, int n_reads)
+                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat, int n_reads, int oh1)
 {
     // GAINS_WPB waves (reads) per block share log_cr's table; everything else is private to a wave, so the only
     // block-wide barrier is the one after the table copy
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
     if (mbs[r / mbsize].status != ADP_MB_OK) return;
     const int n = nvalid[r];
     if (n <= 0) return;
-    int start = 0, oh = 5, ot = 5;
+    int start = 0, oh = oh1, ot = 5; // (oh1: 5 for combined_detect_llr2; 5 + min_obs_adapter // ds for the single-read API)
     if (PASS == 2) {
         start = adapter_idx[r];
         if (start < 0) return;

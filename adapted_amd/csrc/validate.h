@@ -787,14 +787,15 @@ __global__ void k_sp_bounds(const SpOut *__restrict__ sp, int n_reads, int64_t *
 }
 
 // bounds for the LLR primary from pooled-unit indices
+// single: combined_detect_llr (combined.py:91-117) stops at an adapter candidate at index 0 -- no poly(A) search
 __global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int32_t *__restrict__ polya_idx, int n_reads, int ds,
-                             int off, int64_t *__restrict__ bounds, int8_t *__restrict__ topk_none)
+                             int off, int64_t *__restrict__ bounds, int8_t *__restrict__ topk_none, int single)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int a = adapter_idx[r], p = polya_idx[r];
     int64_t ae = (a > 0) ? (int64_t)a * ds + off : 0;
-    int64_t pe = (a >= 0 && p > 0) ? (int64_t)p * ds + off : 0;
+    int64_t pe = ((single ? a > 0 : a >= 0) && p > 0) ? (int64_t)p * ds + off : 0;
     bounds[2 * r] = ae;
     bounds[2 * r + 1] = pe;
     topk_none[r] = (pe > 0) ? 0 : 1; // polya_end_topk is only assigned when a poly(A) end was found

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's detect operators, backed by libadapted_hip.so.
 
 Same names, argument meaning, return types and error behaviour as the reference's
-adapted/detect/combined.py: ``combined_detect_llr2`` (:122-227), ``combined_detect_cnn``
+adapted/detect/combined.py: ``combined_detect_llr2`` (:122-227), ``combined_detect_llr`` (:39-119), ``combined_detect_cnn``
 (:230-309), ``combined_detect_start_peak`` (:312-355) and ``validate_boundaries`` (:358-631).
 Each call treats its batch as ONE minibatch (the reference's batch-global normalisation,
 adapted/detect/normalize.py:15-22).  Everything numeric runs on the GPU through the C ABI
@@ -68,6 +68,40 @@ def combined_detect_llr2(batch_of_signals: np.ndarray, full_signal_lens: np.ndar
         # the reference dies in np.argmin on a read whose pooled trace is empty (llr.py:136)
         raise ValueError("attempt to get argmin of an empty sequence")
     return lib.rows_to_results(rows, "llr")
+
+
+_EXC_TYPES = {9: TypeError, 10: TypeError, 11: ValueError, 12: ValueError, 13: ValueError, 14: ValueError}
+
+
+def combined_detect_llr(calibrated_signal: np.ndarray, full_signal_len: int, spc, device: int = 0) -> DetectResults:
+    """The single-read operator (reference adapted/detect/combined.py:39-119; no call site in the reference's CLI): the read
+    is normalised by its own median / MAD, pooled from sample 0 (offset_head = 5 + min_obs_adapter // ds), and validated;
+    errors propagate as in the reference (it has no try / except on this path).  At most sig_preload_size samples are
+    looked at -- the reference's validation reads the whole array, so the signal has to be the preloaded part of the read."""
+    sig = np.ascontiguousarray(calibrated_signal, dtype=np.float32).reshape(-1)
+    m = int(spc.sig_preload_size)
+    if sig.size > m:
+        raise ValueError("combined_detect_llr: at most sig_preload_size = %d samples (the preloaded part of the read)" % m)
+    if sig.size < min(int(full_signal_len), m):
+        raise ValueError("combined_detect_llr: the signal is shorter than min(full_signal_len, sig_preload_size)")
+    key = (_cfg_key(spc), m, int(device), "single")
+    eng = _ENGINES.get(key)
+    if eng is None:
+        eng = lib.Engine(spc, 1, m, device=device, single_read_layout=True)
+        _ENGINES[key] = eng
+    row = np.full((1, m), np.nan, dtype=np.float32)
+    row[0, : sig.size] = sig
+    rows, mbs = eng.detect_llr_rows(row, np.array([full_signal_len], dtype=np.int32), 1, 1)
+    if mbs[0] == lib.MB_MAD_ZERO:
+        msg = "MAD normalization failed: scale is 0"
+        logging.error(msg)
+        raise ValueError(msg)
+    if mbs[0] == lib.MB_EMPTY_TRACE:
+        raise ValueError("attempt to get argmin of an empty sequence")
+    fc = int(rows[0]["fail_code"])
+    if 9 <= fc <= 14:  # raised inside validate_boundaries: not caught on this path
+        raise _EXC_TYPES[fc](lib.fail_reason_of(rows[0]))
+    return lib.rows_to_results(rows, "llr")[0]
 
 
 def combined_detect_start_peak(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, spc,

@@ -124,7 +124,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
-           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged"]
+           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -228,7 +228,9 @@ def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
 class Engine:
     """One GPU's detect engine: a handle of libadapted_hip.so sized for (max_reads, m)."""
 
-    def __init__(self, spc, max_reads: int, m: int, device: int = 0):
+    def __init__(self, spc, max_reads: int, m: int, device: int = 0, single_read_layout: bool = False):
+        """single_read_layout: the engine of combined_detect_llr (adapted/detect/combined.py:39-119): pooled from sample 0, every
+        read its own minibatch (detect_llr_rows with minibatch = 1)"""
         self.lib = load()
         self.spc = spc
         self.cfg = make_cfg(spc)
@@ -236,6 +238,8 @@ class Engine:
         self._h = C.c_void_p()
         self._pinned = {}
         self._check(self.lib.adp_create(self.device, C.byref(self.cfg), self.max_reads, self.m, C.byref(self._h)))
+        if single_read_layout:
+            self._check(self.lib.adp_set_layout(self._h, 1))
 
     # -- plumbing ---------------------------------------------------------------------
     def _check(self, rc):

@@ -154,6 +154,14 @@ int adp_device_count(void);
 int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle **out);
 int adp_destroy(adp_handle *h);
 int adp_set_config(adp_handle *h, const adp_cfg *cfg);
+/* Layout of the LLR path.  ADP_LAYOUT_MINIBATCH (default): combined_detect_llr2, adapted/detect/combined.py:122-227.
+ * ADP_LAYOUT_SINGLE_READ: combined_detect_llr, adapted/detect/combined.py:39-119 (API only in v0.2.4) -- every read
+ * normalised on its own (adp_detect_llr with minibatch = 1), pooled from sample 0 with offset_head = 5 +
+ * min_obs_adapter // ds, min_obs_adapter still added to the positions, no poly(A) search behind a candidate at index 0,
+ * the ragged last pooled block filled up with zeros at the READ's end. */
+#define ADP_LAYOUT_MINIBATCH 0
+#define ADP_LAYOUT_SINGLE_READ 1
+int adp_set_layout(adp_handle *h, int layout);
 /* The handle's HIP stream (hipStream_t as void*); all work of a call is ordered on it. */
 void *adp_stream(adp_handle *h);
 int adp_synchronize(adp_handle *h);

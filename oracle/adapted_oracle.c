@@ -1088,6 +1088,47 @@ int orc_llr_primary(const float *row, long m, const orc_cfg *cfg, const double *
     return 0;
 }
 
+/* combined_detect_llr (adapted/detect/combined.py:39-119; API only, no call site in v0.2.4): ONE read, normalised by its own
+ * median / MAD over signal[:T]; the pooled signal starts at sample 0 (no min_obs_adapter slice) with offset_head =
+ * 5 + min_obs_adapter // ds, yet min_obs_adapter is still added to the positions; an adapter candidate at index 0 ends the
+ * search (no poly(A) trace); validate_boundaries sees the whole signal.  `row` holds the read's first min(len, m) samples,
+ * NaN behind them (the reference is handed the unpadded array: its pooling pads the read's end with zeros).
+ * returns 0, -1 (MAD == 0), -2 (no pooled block): the reference raises in both cases. */
+int orc_detect_llr_single(const float *row, long m, long full_len, const orc_cfg *cfg, orc_row *out)
+{
+    double np4[4];
+    int rc = orc_norm_params(row, 1, m, cfg->max_obs_trace, cfg->sig_norm_outlier_thresh, np4);
+    if (rc) return rc;
+    long T = cfg->max_obs_trace < m ? cfg->max_obs_trace : m;
+    long have = full_len < m ? full_len : m;
+    long Lseg = T < have ? T : have; if (Lseg < 0) Lseg = 0;
+    int ds = cfg->downscale_factor;
+    long L = (Lseg + ds - 1) / ds;
+    float *down = (float *)malloc(sizeof(float) * (L > 0 ? L : 1));
+    orc_pool_row(row, Lseg, ds, 1, (float)np4[0], (float)np4[1], (float)np4[2], (float)np4[3], down);
+    long n_nan = 0;
+    for (long j = 0; j < L; j++) if (down[j] != down[j]) n_nan++;
+    long n = L - n_nan;
+    if (n == 0) { free(down); return -2; }
+    double *c = (double *)malloc(sizeof(double) * n), *c2 = (double *)malloc(sizeof(double) * n);
+    double *g = (double *)malloc(sizeof(double) * n);
+    orc_cumsum(down, n, c, c2);
+    orc_gains(0, n - 1, c, c2, n, 5 + cfg->min_obs_adapter / ds, 5, g);
+    long raw_first, npk, ae = 0, pe = 0;
+    long cand = orc_adapter_candidate(g, n, cfg->adapter_peak_prominence, cfg->adapter_peak_rel_height,
+                                      cfg->adapter_peak_width / ds, &raw_first, &npk);
+    if (cand > 0) {
+        ae = cand * ds + cfg->min_obs_adapter;
+        orc_gains(cand, n - 1, c, c2, n, 1, 1, g);
+        long p = orc_polya_peak(g, n);
+        if (p > 0) pe = p * ds + cfg->min_obs_adapter;
+    }
+    free(down); free(c); free(c2); free(g);
+    int64_t cd = pe;
+    orc_validate(row, m, full_len, ae, pe, pe > 0 ? &cd : NULL, 1, cfg, out);
+    return 0;
+}
+
 /* combined_detect_llr2 over one minibatch [N, m].  with_start_peak != 0 additionally fills
  * the start_peak_* columns from K1 (a build extension; default off).
  * returns 0, -1 (MAD == 0: the reference raises and drops the minibatch), -2 (empty trace). */

@@ -36,6 +36,8 @@ def make_spc(case):
 
     spc = get_chemistry_specific_config(case["chem"])
     p = case["primary"]
+    if p == "llr_single":
+        p = "llr"
     spc.llr_boundaries.llr_detect = p == "llr"
     spc.cnn_boundaries.cnn_detect = p == "cnn"
     spc.rna_start_peak.detect_rna_start_peak = p == "start_peak"
@@ -110,6 +112,33 @@ def run_case(name, case):
         json.dump(out, fh, indent=0, allow_nan=True)
     dump_intermediates(name, case, spc, sig, lens, model)
     return results, spc, sig, lens
+
+
+def run_single_case(name, case):
+    """combined_detect_llr, read by read, each handed over without padding; exceptions are recorded as the reference raises them"""
+    from adapted.detect import combined
+
+    spc = make_spc(case)
+    m = spc.sig_preload_size
+    n = case["n"]
+    lens = np.asarray(resolve_lens(case["lens"], n, m), dtype=np.int32)
+    sig, lens = synth.synth_batch(case["seed"], case["first"], n, m, lens)
+    rows = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in range(n):
+            have = min(int(lens[i]), m)
+            try:
+                r = combined.combined_detect_llr(sig[i, :have].copy(), int(lens[i]), spc)
+                d = dict(r.__dict__)
+                d.pop("llr_trace", None)
+                rows.append({k: jsonable(v) for k, v in d.items()})
+            except Exception as e:  # noqa: BLE001 -- recorded: the API lets them through
+                rows.append({"_raise": type(e).__name__ + ": " + str(e)})
+    out = dict(case=name, m=int(m), lens=[int(x) for x in lens], primary_method=spc.primary_method, rows=rows)
+    with open(os.path.join(GOLD, name + ".rows.json"), "w") as fh:
+        json.dump(out, fh, indent=0, allow_nan=True)
+    return rows
 
 
 def dump_intermediates(name, case, spc, sig, lens, model):
@@ -243,6 +272,10 @@ def main():
     ref_harness.install(need_torch=(what == "cnn"))
     if what == "llr" and only:
         for name in sorted(only):
+            if CASES[name]["primary"] == "llr_single":
+                rows = run_single_case(name, CASES[name])
+                print(name, "ok", sum(1 for r in rows if r.get("success")), "/", len(rows), "raised", sum(1 for r in rows if "_raise" in r))
+                continue
             results, spc, sig, lens = run_case(name, CASES[name])
             print(name, "ok", sum(r.success for r in results), "/", len(results))
             if name in CSV_CASES:
@@ -252,6 +285,9 @@ def main():
         gen_bottleneck()
         for name, case in CASES.items():
             if case["primary"] == "cnn":
+                continue
+            if case["primary"] == "llr_single":
+                run_single_case(name, case)
                 continue
             results, spc, sig, lens = run_case(name, case)
             print(name, "ok", sum(r.success for r in results), "/", len(results))

@@ -211,6 +211,25 @@ def detect_llr(batch, full_lens, spc, with_start_peak=False, return_params=False
     return (d, np4) if return_params else d
 
 
+def detect_llr_single(signal, full_len, spc, m=None):
+    """combined_detect_llr on ONE read -> dict row.  signal: the read's samples (1-D, at most m of them are used); raises
+    ValueError like the reference for MAD == 0 / an empty trace."""
+    L = lib()
+    cfg = make_cfg(spc)
+    m = int(m or spc.sig_preload_size)
+    row = np.full(m, np.nan, dtype=np.float32)
+    s = np.asarray(signal, dtype=np.float32)[:m]
+    row[: s.size] = s
+    out = np.zeros(1, dtype=ROW_DTYPE)
+    rc = L.orc_detect_llr_single(row.ctypes.data_as(C.POINTER(C.c_float)), C.c_long(m), C.c_long(int(full_len)), C.byref(cfg),
+                                 out.ctypes.data_as(C.c_void_p))
+    if rc == -1:
+        raise ValueError("MAD normalization failed: scale is 0")
+    if rc == -2:
+        raise ValueError("attempt to get argmin of an empty sequence")
+    return rows_to_dicts(out, "llr")[0]
+
+
 def detect_start_peak(batch, full_lens, spc):
     L = lib()
     b, bp = _f32c(batch)

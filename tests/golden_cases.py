@@ -47,6 +47,12 @@ CASES = {
                                           lens="mixed", minibatch=96, dump=[],
                                           override={"mvs_polya.mvs_detect_overwrite": True, "mvs_polya.pA_var_window": 600,
                                                     "mvs_polya.search_window": 1200, "med_shift.detect_med_shift": True}),
+    # combined_detect_llr (adapted/detect/combined.py:39-119), the single-read API: per-read normalisation, pooled from
+    # sample 0; every read on its own, handed over without padding
+    "rna004_llr_single": dict(chem="RNA004", primary="llr_single", max_obs_trace=None, seed=11, first=0, n=96,
+                              lens="mixed", minibatch=1, dump=[]),
+    "rna002_llr_single_4k": dict(chem="RNA002", primary="llr_single", max_obs_trace=4000, seed=13, first=0, n=48,
+                                 lens="mixed002", minibatch=1, dump=[]),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),

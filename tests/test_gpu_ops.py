@@ -349,3 +349,44 @@ def test_hostile_inputs_equal_the_oracle(oracle_mod):
     import abuse_vs_oracle
 
     assert abuse_vs_oracle.main() == 0
+
+
+@pytest.mark.parametrize("name", [k for k, c in CASES.items() if c["primary"] == "llr_single"])
+def test_single_read_api_vs_golden_and_oracle(oracle_mod, name):
+    """combined_detect_llr (adapted/detect/combined.py:39-119, API only): per-read normalisation, pooling from sample 0 with
+    the longer head offset, min_obs_adapter added to the positions all the same, zeros behind the READ's end in its last
+    pooled block -- every field as the reference run read by read (goldens) and as the oracle."""
+    import json
+
+    from adapted_amd import synth
+    from adapted_amd.detect.combined import combined_detect_llr
+    from golden_cases import resolve_lens
+    from util import make_spc
+
+    case = CASES[name]
+    spc = make_spc(case)
+    with open(os.path.join(GOLD, name + ".rows.json")) as fh:
+        g = json.load(fh)
+    m = g["m"]
+    lens = np.asarray(g["lens"], dtype=np.int32)
+    sig, _ = synth.synth_batch(case["seed"], case["first"], case["n"], m, lens)
+    bad = []
+    for i, w in enumerate(g["rows"]):
+        have = min(int(lens[i]), m)
+        if "_raise" in w:
+            with pytest.raises((ValueError, TypeError)):
+                combined_detect_llr(sig[i, :have], int(lens[i]), spc)
+            continue
+        got = combined_detect_llr(sig[i, :have], int(lens[i]), spc)
+        d = row_diffs(got, w)
+        if not d:
+            d = row_diffs(got, {k: v for k, v in oracle_mod.detect_llr_single(sig[i, :have], int(lens[i]), spc, m).items() if not k.startswith("_")})
+        if d:
+            bad.append((i, d[:4]))
+    assert not bad, bad[:5]
+    # a read whose length is not a multiple of the pooling factor and a constant one (MAD == 0)
+    odd = sig[0, : min(m, 9000) - 13].copy()
+    assert not row_diffs(combined_detect_llr(odd, odd.size, spc),
+                         {k: v for k, v in oracle_mod.detect_llr_single(odd, odd.size, spc, m).items() if not k.startswith("_")})
+    with pytest.raises(ValueError, match="scale is 0"):
+        combined_detect_llr(np.full(min(m, 9000), 80.0, dtype=np.float32), min(m, 9000), spc)

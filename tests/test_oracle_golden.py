@@ -108,3 +108,38 @@ def test_cnn_oracle_vs_golden(oracle_mod):
     got = oracle_mod.detect_cnn_from_preds(sig, lens, st["preds"], spc)
     bad = [(i, d) for i, (g, w_) in enumerate(zip(got, want)) for d in row_diffs(g, w_)]
     assert not bad, bad[:10]
+
+
+SINGLE_CASES = [k for k, c in CASES.items() if c["primary"] == "llr_single"]
+
+
+@pytest.mark.parametrize("name", SINGLE_CASES)
+def test_single_read_api_vs_golden(oracle_mod, name):
+    """combined_detect_llr (adapted/detect/combined.py:39-119): the oracle's restatement against the reference run read by read"""
+    import json
+    import os
+
+    from util import GOLD, make_spc, row_diffs
+    from golden_cases import resolve_lens
+    from adapted_amd import synth
+
+    case = CASES[name]
+    spc = make_spc(case)
+    with open(os.path.join(GOLD, name + ".rows.json")) as fh:
+        g = json.load(fh)
+    m = g["m"]
+    lens = np.asarray(g["lens"], dtype=np.int32)
+    assert list(lens) == resolve_lens(case["lens"], case["n"], m)
+    sig, _ = synth.synth_batch(case["seed"], case["first"], case["n"], m, lens)
+    bad = []
+    for i, w in enumerate(g["rows"]):
+        have = min(int(lens[i]), m)
+        if "_raise" in w:
+            with pytest.raises(ValueError):
+                oracle_mod.detect_llr_single(sig[i, :have], int(lens[i]), spc, m)
+            continue
+        got = oracle_mod.detect_llr_single(sig[i, :have], int(lens[i]), spc, m)
+        d = row_diffs(got, w)
+        if d:
+            bad.append((i, d[:4]))
+    assert not bad, bad[:5]

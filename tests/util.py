@@ -21,6 +21,8 @@ SKIP_FIELDS = {"llr_detect_log", "polya_truncated", "llr_trace"}
 def make_spc(case):
     spc = get_chemistry_specific_config(case["chem"])
     p = case["primary"]
+    if p == "llr_single":
+        p = "llr"
     spc.llr_boundaries.llr_detect = p == "llr"
     spc.cnn_boundaries.cnn_detect = p == "cnn"
     spc.rna_start_peak.detect_rna_start_peak = p == "start_peak"
