@@ -22,11 +22,28 @@ def sources():
                   + [os.path.join(ROOT, "include", "adapted_hip.h")])
 
 
+STAMP = LIB + ".sources.sha256"  # digest of the sources the library was built from (travels with it; not in git)
+
+
+def _digest() -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for s in sources():
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    """Is the library missing or built from other sources?  By content, not by time stamps: a copied tree (the GPU box
+    gets a snapshot) keeps neither their order nor their values."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in sources())
+    with open(STAMP) as fh:
+        return fh.read().strip() != _digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -49,6 +66,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
                 os.replace(tmp, LIB)
+                with open(STAMP + ".tmp", "w") as fh:
+                    fh.write(_digest() + "\n")
+                os.replace(STAMP + ".tmp", STAMP)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
