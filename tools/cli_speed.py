@@ -30,7 +30,16 @@ def main():
     print("bundle of %d reads (mean %.0f samples) written in %.1f s" % (n, lens.mean(), time.time() - t0), flush=True)
     out = os.path.join(tmp, "out")
     t0 = time.time()
-    argv = ["detect", "-i", os.path.join(tmp, "reads_0.npz"), "-o", out, "--chemistry", "RNA004", "--max_obs_trace", "200000"]
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False  # the LLR primary (the preset's default is the CNN)
+    spc.core.max_obs_trace = 200000
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    cfg = os.path.join(tmp, "cfg.toml")
+    spc.to_toml(cfg)
+    argv = ["detect", "-i", os.path.join(tmp, "reads_0.npz"), "-o", out, "--config", cfg]
     if len(sys.argv) > 2 and sys.argv[2] == "profile":
         import cProfile
         import pstats
