@@ -9,14 +9,26 @@ imports but this image lacks) and path plumbing.
 Interpreter: /opt/conda/bin/python3.9 (numpy 1.26, scipy 1.7, Cython 0.29, real
 bottleneck 1.3.2, real toml) or /usr/local/bin/python3 (numpy 2.2, scipy 1.15, torch;
 needs the bottleneck/toml shims below).  pyximport compiles the reference's Cython file
-into ``oracle/_ref/home/.pyxbld`` (HOME is redirected; /root/reference stays untouched).
+into ``$ADAPTED_REF_BUILD`` (default ``<tmpdir>/adapted_ref_build``), OUTSIDE this repository:
+the generated C file quotes the reference's source, so nothing of that build may sit in a
+tree that is pushed to the GPU box (HOME is redirected there; /root/reference stays untouched).
 """
 import os
 import sys
+import tempfile
 import types
 
 REF_ROOT = os.environ.get("ADAPTED_REFERENCE", "/root/reference")
 _HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_HERE)
+
+
+def build_dir() -> str:
+    """Where the reference-derived build outputs go: never inside the repository."""
+    d = os.path.abspath(os.environ.get("ADAPTED_REF_BUILD") or os.path.join(tempfile.gettempdir(), "adapted_ref_build"))
+    if os.path.commonpath([d, _REPO]) == _REPO:
+        raise RuntimeError("ADAPTED_REF_BUILD=%s lies inside the repository; reference-derived files must stay out of it" % d)
+    return d
 
 
 def available() -> bool:
@@ -34,7 +46,7 @@ def install(need_torch: bool = False):
     """Make ``import adapted`` (the reference) work. Returns the imported package."""
     if not available():
         raise RuntimeError("reference not present at %s" % REF_ROOT)
-    home = os.path.join(_HERE, "_ref", "home")
+    home = os.path.join(build_dir(), "home")
     os.makedirs(home, exist_ok=True)
     os.environ["HOME"] = home  # pyximport build dir = ~/.pyxbld
     import numpy  # noqa: F401

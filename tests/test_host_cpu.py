@@ -151,6 +151,22 @@ def test_product_never_imports_the_oracle():
                 assert "liboracle" not in src, f
 
 
+def test_nothing_of_the_reference_in_the_tree():
+    """SURVEY 8(c) travel rule: the snapshot pushed to the GPU box (everything but .git/ and the paths of
+    .gpurunignore) holds no reference-derived build output (pyximport's _c_llr.c quotes the reference's source)."""
+    with open(os.path.join(ROOT, ".gpurunignore")) as fh:
+        ignored = [ln.strip().rstrip("/") for ln in fh if ln.strip()]
+    assert "oracle/_ref" in ignored
+    from oracle import ref_harness
+
+    assert os.path.commonpath([ref_harness.build_dir(), ROOT]) != ROOT
+    for dirpath, dirs, files in os.walk(ROOT):
+        rel = os.path.relpath(dirpath, ROOT)
+        dirs[:] = [d for d in dirs if os.path.normpath(os.path.join(rel, d)) not in ignored]
+        for f in files + dirs:
+            assert "_c_llr" not in f and ".pyxbld" not in f, os.path.join(dirpath, f)
+
+
 def test_synth_is_deterministic_and_shaped():
     from adapted_amd import synth
 
