@@ -20,6 +20,7 @@ __device__ unsigned long long g_dbg[24] = {0};
 #include "synth.h"
 #include "validate.h"
 #include "cnn_topk.h"
+#include "cnn_conv.h"
 #include "wave_stats.h"
 
 static thread_local std::string g_err;
@@ -73,6 +74,10 @@ struct adp_handle {
     int oh1 = 5;      // head offset of the first gains pass
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
+    // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
+    DevBuf cnn_w, cnn_act[2];
+    bool cnn_have_w = false;
+    int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
 };
 
 static int geom(adp_handle *h)
@@ -203,6 +208,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
     rc = alloc_all(h);
     if (rc) { adp_destroy(h); return rc; }
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     *out = h;
     return ADP_OK;
 }
@@ -212,7 +218,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -754,6 +760,94 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
       hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, h->stream, dsig, n_reads, m, off, ds, Lc, dout); }
     if (!(flags & ADP_OUT_DEVICE))
         HIPCHK(hipMemcpyAsync(prepared_out, dout, (size_t)n_reads * Lc * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+// offsets (floats) of the layers inside the weight buffer: w0 [64][1][7], b0 [64], w1 [64][64][7], b1 [64], w2, b2, w3 [64][2][7], b3 [2]
+#define CNN_W0 0
+#define CNN_B0 (CNN_W0 + CNN_C * CNN_K)
+#define CNN_W1 (CNN_B0 + CNN_C)
+#define CNN_B1 (CNN_W1 + CNN_C * CNN_C * CNN_K)
+#define CNN_W2 (CNN_B1 + CNN_C)
+#define CNN_B2 (CNN_W2 + CNN_C * CNN_C * CNN_K)
+#define CNN_W3 (CNN_B2 + CNN_C)
+#define CNN_B3 (CNN_W3 + CNN_C * 2 * CNN_K)
+#define CNN_WTOTAL (CNN_B3 + 2)
+
+int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, const float *w3, const float *b3)
+{
+    if (!h || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    if (h->cnn_w.ensure((size_t)CNN_WTOTAL * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    std::vector<float> all((size_t)CNN_WTOTAL);
+    memcpy(&all[CNN_W0], w0, sizeof(float) * CNN_C * CNN_K); memcpy(&all[CNN_B0], b0, sizeof(float) * CNN_C);
+    memcpy(&all[CNN_W1], w1, sizeof(float) * CNN_C * CNN_C * CNN_K); memcpy(&all[CNN_B1], b1, sizeof(float) * CNN_C);
+    memcpy(&all[CNN_W2], w2, sizeof(float) * CNN_C * CNN_C * CNN_K); memcpy(&all[CNN_B2], b2, sizeof(float) * CNN_C);
+    memcpy(&all[CNN_W3], w3, sizeof(float) * CNN_C * 2 * CNN_K); memcpy(&all[CNN_B3], b3, sizeof(float) * 2);
+    HIPCHK(hipMemcpyAsync(h->cnn_w.p, all.data(), (size_t)CNN_WTOTAL * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cnn_have_w = true;
+    return ADP_OK;
+}
+
+extern "C++" {
+template <int NT>
+static int launch_conv64(adp_handle *h, const float *in, float *out, const float *w, const float *b, int n, int L1, int Lpad, int tiles)
+{
+    const size_t lds = (size_t)2 * CNN_C * (64 * NT + 8) * 4;
+    static bool attr_set = false; // (per instantiation; the attribute belongs to the function, not to the handle)
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    long long total = (long long)n * tiles;
+    int grid = (int)(total < h->n_cu ? total : h->n_cu);
+    hipLaunchKernelGGL(k_cnn_conv64<NT>, dim3(grid), dim3(256), lds, h->stream, in, out, w, b, n, L1, Lpad, tiles);
+    return 0;
+}
+} // extern "C++"
+
+int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
+{
+    if (!h || !prepared || !scores_out || n_reads < 1 || Lc < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (!h->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const int L1 = (Lc + 2 * 3 - CNN_K) / 3 + 1, Lo = (L1 - 1) * 3 - 2 * 3 + CNN_K;
+    // positions per workgroup step: the NT (32-position tiles per wave) that wastes least of the last step
+    int NT = 4; { long long best = -1; for (int nt = 4; nt >= 2; nt--) { const long long pb = 64 * nt, cover = (L1 + pb - 1) / pb * pb; if (best < 0 || cover < best) { best = cover; NT = nt; } } }
+    const int PB = 64 * NT, tiles = (L1 + PB - 1) / PB, Lpad = tiles * PB + 8;
+    size_t per_read = (size_t)CNN_C * Lpad * 4;
+    size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each if (cap_reads < 1) cap_reads = 1;
+    int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
+    if (h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
+        for (int k = 0; k < 2; k++) {
+            if (h->cnn_act[k].ensure((size_t)C * per_read)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+            HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding columns are never written again
+        }
+        h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read);
+    }
+    C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
+    const float *W = h->cnn_w.as<float>();
+    float *A = h->cnn_act[0].as<float>(), *B = h->cnn_act[1].as<float>();
+    for (int s0 = 0; s0 < n_reads; s0 += C) {
+        const int n = n_reads - s0 < C ? n_reads - s0 : C;
+        const float *x = prepared + (size_t)s0 * Lc;
+        float *sc = scores_out + (size_t)s0 * 2 * Lo;
+        { Scope s(h, s0 ? nullptr : "k_cnn_conv_in");
+          hipLaunchKernelGGL(k_cnn_conv_in, dim3((L1 + 255) / 256, n), dim3(256), 0, h->stream, x, Lc, L1, Lpad, W + CNN_W0, W + CNN_B0, A); }
+        for (int layer = 0; layer < 2; layer++) {
+            Scope s(h, s0 ? nullptr : (layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)"));
+            const float *in = layer ? B : A; float *out = layer ? A : B;
+            const float *w = W + (layer ? CNN_W2 : CNN_W1), *b = W + (layer ? CNN_B2 : CNN_B1);
+            int rc = NT == 4 ? launch_conv64<4>(h, in, out, w, b, n, L1, Lpad, tiles)
+                   : NT == 3 ? launch_conv64<3>(h, in, out, w, b, n, L1, Lpad, tiles)
+                             : launch_conv64<2>(h, in, out, w, b, n, L1, Lpad, tiles);
+            if (rc) return rc;
+        }
+        { Scope s(h, s0 ? nullptr : "k_cnn_conv_out");
+          hipLaunchKernelGGL(k_cnn_conv_out, dim3((L1 + 255) / 256, n), dim3(256), 0, h->stream, A, L1, Lpad, Lo, W + CNN_W3, W + CNN_B3, sc); }
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     return ADP_OK;

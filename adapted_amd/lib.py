@@ -124,7 +124,8 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_cnn_prepare", "adp_validate_candidates", "adp_llr_refine_polya", "adp_synth_fill", "adp_dev_alloc", "adp_dev_free",
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
-           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout"]
+           "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
+           "adp_cnn_set_weights", "adp_cnn_forward"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -405,6 +406,26 @@ class Engine:
                                           C.c_void_p(int(polya_pos_ptr)), int(n), int(Lo), int(k), cand.ctypes.data_as(C.c_void_p),
                                           cnt.ctypes.data_as(C.c_void_p), flag.ctypes.data_as(C.c_void_p)))
         return cand, cnt, int(flag[0])
+
+    def cnn_set_weights(self, state):
+        """state: mapping with the reference's state-dict keys ("0.weight" ... "6.bias") -> float32 arrays (numpy, or anything
+        np.asarray takes: torch CPU tensors included)"""
+        arrs = []
+        for key, shape in (("0.weight", (64, 1, 7)), ("0.bias", (64,)), ("2.weight", (64, 64, 7)), ("2.bias", (64,)),
+                           ("4.weight", (64, 64, 7)), ("4.bias", (64,)), ("6.weight", (64, 2, 7)), ("6.bias", (2,))):
+            a = state[key]
+            if hasattr(a, "detach"):
+                a = a.detach().cpu().numpy()
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != shape:
+                raise ValueError("CNN weight %s has shape %s, expected %s" % (key, a.shape, shape))
+            arrs.append(a)
+        self._check(self.lib.adp_cnn_set_weights(self._h, *[a.ctypes.data_as(C.c_void_p) for a in arrs]))
+        self._cnn_weights_id = id(state)
+
+    def cnn_forward(self, prepared_dev: int, n: int, Lc: int, scores_dev: int):
+        """C2 on the device (hand-written conv stack): prepared float32 [n, Lc] -> scores float32 [n, 2, Lo]"""
+        self._check(self.lib.adp_cnn_forward(self._h, C.c_void_p(int(prepared_dev)), int(n), int(Lc), C.c_void_p(int(scores_dev))))
 
     def cnn_prepare(self, signals, n: int, out_dev_ptr: int, device_ptrs: bool = False):
         """C1 into a device buffer float32 [n, Lc] (e.g. a torch tensor's data_ptr)."""

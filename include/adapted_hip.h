@@ -179,6 +179,15 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
 /* CNN head, device-side pre/post-processing around the PyTorch conv stack.
  * prepared_out: float32 [n_reads, Lc] with Lc = ceil((m - min_obs_adapter)/downscale_factor). */
 int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out);
+/* C2, the conv net itself (BoundariesCNN adapted/detect/cnn.py:16-52; cnn_score :85-98), hand-written for gfx950
+ * (adapted_amd/csrc/cnn_conv.h: the two 64 -> 64 layers on the float32 matrix cores, fixed accumulation order).
+ * adp_cnn_set_weights: HOST pointers in the layout of the reference's state dict ("0.weight" [64,1,7], "0.bias" [64],
+ * "2.weight" [64,64,7], "2.bias", "4.weight" [64,64,7], "4.bias", "6.weight" [64,2,7], "6.bias" [2]).
+ * adp_cnn_forward: prepared = DEVICE float32 [n_reads, Lc] (adp_cnn_prepare's output), scores_out = DEVICE float32
+ * [n_reads, 2, Lo], Lo = 3 * ((Lc - 1) / 3 + 1) - 2 -- what model(x) returns in the reference. */
+int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
+                        const float *b2, const float *w3, const float *b3);
+int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out);
 /* C3, the k > 1 part of cnn_predict (adapted/detect/cnn.py:136-160): per read the k best poly(A) candidates among the
  * distance-5 peaks of the masked channel-1 scores.  scores: DEVICE float32 [n, 2, Lo] (the conv net's output);
  * adapter_pos / polya_pos: DEVICE int64 [n] (the two arg-maxes cnn_predict takes first).  Host outputs:

@@ -146,3 +146,43 @@ def test_device_topk_reports_what_only_scipy_settles(kind):
     _, _, flag = eng.cnn_topk(dsc.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
     assert flag != 0, kind
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4)])
+def test_hip_conv_stack_equals_torch(Lc, n):
+    """C2: the hand-written conv stack (adp_cnn_forward, float32 matrix cores) against torch's float32 conv1d /
+    conv_transpose1d on the same device with the shipped weights.  Both are float32 sums of the same 448 products per
+    output in different orders: tolerance 2e-5 relative to the score scale (the golden test pins the scores themselves)."""
+    import torch
+
+    from adapted_amd import lib
+    from adapted_amd.detect import cnn
+    from golden_cases import CASES
+    from util import make_spc
+
+    torch.cuda.init()
+    spc = make_spc(CASES["rna004_cnn_default"])
+    model = cnn.load_cnn_model(spc.cnn_boundaries.model_name, device=0)
+    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+    eng.cnn_set_weights({k: v for k, v in model.state_dict().items()})
+    rng = np.random.default_rng(Lc)
+    x = rng.normal(0.0, 1.5, (n, 1, Lc)).astype(np.float32)
+    x[0, 0, Lc // 2:] = -5.0  # a padded tail, as prepare_data makes it
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        want = model(xt)
+    Lo = want.shape[2]
+    got = torch.full((n, 2, Lo), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    eng.cnn_forward(xt.data_ptr(), n, Lc, got.data_ptr())
+    w, g = want.cpu().numpy(), got.cpu().numpy()
+    assert not np.isnan(g).any()
+    scale = max(1.0, float(np.abs(w).max()))
+    err = float(np.abs(w - g).max())
+    assert err <= 2e-5 * scale, (err, scale)
+    # a second call on the same handle (activation buffers reused, padding still zero) gives the same bits
+    got2 = torch.empty_like(got)
+    eng.cnn_forward(xt.data_ptr(), n, Lc, got2.data_ptr())
+    assert torch.equal(got, got2)
+    eng.close()
