@@ -75,7 +75,7 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2];
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
 };
@@ -218,7 +218,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -709,30 +709,81 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
     return ADP_OK;
 }
 
-int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_pos_dev, const int64_t *polya_pos_dev,
-                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out, int32_t *flag_out)
+// C3 on the device: top-k behind given arg-maxes (dapos / dppos device int64 [n]) -> dcand / dcnt in ct_out (asynchronous)
+static int cnn_topk_dev(adp_handle *h, const float *scores, const long long *dapos, const long long *dppos, int n, int mbsize, int Lo, int k)
 {
-    if (!h || !scores_dev || !adapter_pos_dev || !polya_pos_dev || !cand_out || !n_peaks_out || !flag_out || n_reads < 1 || Lo < 3 ||
+    if ((long long)(mbsize < n ? mbsize : n) * Lo >= (1ll << 31)) { g_err = "minibatch * Lo too large for 32-bit flat positions"; return ADP_ERR_UNSUPPORTED; }
+    const size_t half = (size_t)Lo / 2 + 1;
+    const int wpr = (int)((half + 4 + 15) / 16 + 2);
+    const size_t lds = (size_t)wpr * 4;
+    if (lds > 60000) { g_err = "Lo too large for the LDS state of k_cnn_topk"; return ADP_ERR_UNSUPPORTED; }
+    if (h->ct_pk.ensure((size_t)n * 2 * half * 4) || h->ct_pv.ensure((size_t)n * half * 4) || h->ct_st.ensure((size_t)n * wpr * 4) ||
+        h->ct_lnz.ensure((size_t)n * 4) || h->ct_out.ensure(((size_t)n * (k + 1) + 1) * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    int32_t *dcand = h->ct_out.as<int32_t>(), *dcnt = dcand + (size_t)n * k;
+    const int n_mb = (n + mbsize - 1) / mbsize;
+    hipStream_t st = h->stream;
+    hipLaunchKernelGGL(k_cnn_rowlink, dim3(n_mb), dim3(1024), 0, st, dapos, dppos, n, mbsize, h->ct_lnz.as<int32_t>());
+    { Scope s(h, "k_cnn_topk");
+      hipLaunchKernelGGL(k_cnn_topk, dim3(n), dim3(64), lds, st, scores, dapos, dppos, h->ct_lnz.as<int32_t>(), n, mbsize, Lo, k,
+                         h->ct_pk.as<int32_t>(), h->ct_pk.as<int32_t>() + (size_t)n * half, h->ct_pv.as<float>(), h->ct_st.as<uint32_t>(), wpr, dcand, dcnt); }
+    return 0;
+}
+
+int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_pos_dev, const int64_t *polya_pos_dev,
+                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out)
+{
+    if (!h || !scores_dev || !adapter_pos_dev || !polya_pos_dev || !cand_out || !n_peaks_out || n_reads < 1 || Lo < 3 ||
         k < 1 || k > ADP_MAX_CAND) { g_err = "bad argument"; return ADP_ERR_INVALID; }
-    if (Lo >= (1 << 27)) { g_err = "Lo too large"; return ADP_ERR_UNSUPPORTED; }
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear(); h->ev_used = 0;
-    const size_t half = (size_t)Lo / 2 + 1;
-    const size_t lds = (((half + 4) + 15) / 16 + 2) * 4;
-    if (lds > 60000) { g_err = "Lo too large for the LDS state of k_cnn_topk"; return ADP_ERR_UNSUPPORTED; }
-    if (h->ct_pk.ensure((size_t)n_reads * 2 * half * 4) || h->ct_pv.ensure((size_t)n_reads * half * 4) ||
-        h->ct_out.ensure(((size_t)n_reads * (k + 1) + 1) * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-    int32_t *dcand = h->ct_out.as<int32_t>(), *dcnt = dcand + (size_t)n_reads * k, *dflag = dcnt + n_reads;
+    int rc = cnn_topk_dev(h, scores_dev, (const long long *)adapter_pos_dev, (const long long *)polya_pos_dev, n_reads, n_reads, Lo, k);
+    if (rc) return rc;
     hipStream_t st = h->stream;
-    HIPCHK(hipMemsetAsync(dflag, 0, 4, st));
-    { Scope s(h, "k_cnn_topk");
-      hipLaunchKernelGGL(k_cnn_topk, dim3(n_reads), dim3(64), lds, st, scores_dev, (const long long *)adapter_pos_dev,
-                         (const long long *)polya_pos_dev, n_reads, Lo, k, h->ct_pk.as<int32_t>(), h->ct_pv.as<float>(), dcand, dcnt, dflag); }
+    int32_t *dcand = h->ct_out.as<int32_t>(), *dcnt = dcand + (size_t)n_reads * k;
     HIPCHK(hipMemcpyAsync(cand_out, dcand, (size_t)n_reads * k * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(n_peaks_out, dcnt, (size_t)n_reads * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(flag_out, dflag, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+// cnn_predict + the scaling of cnn_detect: scores (device) -> h->bounds [n, 1 + max(k, 1)] (asynchronous)
+static int cnn_predict_dev(adp_handle *h, const float *scores, int n, int mbsize, int Lo, int *kmax_out)
+{
+    const adp_cfg &c = h->cfg;
+    const int k = c.polya_cand_k, kk = k < 1 ? 1 : k;
+    if (k > ADP_MAX_CAND) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
+    if (n > h->max_reads) { g_err = "n_reads exceeds the handle's capacity"; return ADP_ERR_CAPACITY; }
+    if (h->ct_ap.ensure((size_t)n * 16)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    long long *dap = h->ct_ap.as<long long>(), *dpp = dap + n;
+    const int na = (c.max_obs_adapter - c.min_obs_adapter) / c.downscale_factor;
+    hipStream_t st = h->stream;
+    { Scope s(h, "k_cnn_argmax");
+      hipLaunchKernelGGL(k_cnn_argmax, dim3(n), dim3(64), 0, st, scores, n, Lo, na, k, dap, dpp); }
+    const int32_t *dcand = nullptr, *dcnt = nullptr;
+    if (k > 1) {
+        int rc = cnn_topk_dev(h, scores, dap, dpp, n, mbsize, Lo, k);
+        if (rc) return rc;
+        dcand = h->ct_out.as<int32_t>(); dcnt = dcand + (size_t)n * k;
+    }
+    const int n_mb = (n + mbsize - 1) / mbsize;
+    hipLaunchKernelGGL(k_cnn_bounds, dim3(n_mb), dim3(1024), 0, st, dap, dpp, dcand, dcnt, n, mbsize, k, c.downscale_factor, c.min_obs_adapter,
+                       h->bounds.as<int64_t>());
+    *kmax_out = kk;
+    return 0;
+}
+
+int adp_cnn_predict(adp_handle *h, const float *scores_dev, int n_reads, int minibatch, int Lo, int64_t *bounds_out)
+{
+    if (!h || !scores_dev || !bounds_out || n_reads < 1 || minibatch < 1 || Lo < 3) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    int kk = 1;
+    int rc = cnn_predict_dev(h, scores_dev, n_reads, minibatch, Lo, &kk);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     return ADP_OK;
 }
 
@@ -807,12 +858,10 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 }
 } // extern "C++"
 
-int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
+// the conv stack over device buffers, asynchronous on the handle's stream
+static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
 {
-    if (!h || !prepared || !scores_out || n_reads < 1 || Lc < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (!h->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
     const int L1 = (Lc + 2 * 3 - CNN_K) / 3 + 1, Lo = (L1 - 1) * 3 - 2 * 3 + CNN_K;
     // positions per workgroup step: the NT (32-position tiles per wave) that wastes least of the last step
     int NT = 4; { long long best = -1; for (int nt = 4; nt >= 2; nt--) { const long long pb = 64 * nt, cover = (L1 + pb - 1) / pb * pb; if (best < 0 || cover < best) { best = cover; NT = nt; } } }
@@ -848,8 +897,53 @@ int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, f
         { Scope s(h, s0 ? nullptr : "k_cnn_conv_out");
           hipLaunchKernelGGL(k_cnn_conv_out, dim3((L1 + 255) / 256, n), dim3(256), 0, h->stream, A, L1, Lpad, Lo, W + CNN_W3, W + CNN_B3, sc); }
     }
+    return 0;
+}
+
+int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
+{
+    if (!h || !prepared || !scores_out || n_reads < 1 || Lc < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    int rc = cnn_forward_dev(h, prepared, n_reads, Lc, scores_out);
+    if (rc) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+// combined_detect_cnn up to (not including) the short-read fallback, in one call: C1 prepare -> C2 conv stack -> C3 predict
+// -> V1 with the k candidates.  bounds_out (host, may be NULL): int64 [n, 1 + max(k, 1)], what cnn_detect returns.
+int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch, int flags,
+                   adp_row *rows_out, int64_t *bounds_out)
+{
+    if (!h || !signals || !full_len || n_reads < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
+    if (m <= off) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    const int Lc = (m - off + ds - 1) / ds, L1 = (Lc - 1) / 3 + 1, Lo = 3 * L1 - 2;
+    if (h->cnn_x.ensure((size_t)n_reads * Lc * 4) || h->cnn_sc.ensure((size_t)n_reads * 2 * Lo * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    hipStream_t st = h->stream;
+    { Scope s(h, "k_cnn_prepare");
+      hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, st, dsig, n_reads, m, off, ds, Lc, h->cnn_x.as<float>()); }
+    rc = cnn_forward_dev(h, h->cnn_x.as<float>(), n_reads, Lc, h->cnn_sc.as<float>());
+    if (rc) return rc;
+    int kk = 1;
+    rc = cnn_predict_dev(h, h->cnn_sc.as<float>(), n_reads, minibatch, Lo, &kk);
+    if (rc) return rc;
+    if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
+    rc = launch_validate(h, dsig, dlen, n_reads, m, kk, n_reads, false);
+    if (rc) return rc;
+    rc = deliver_rows(h, n_reads, flags, rows_out);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
     return ADP_OK;
 }
 

@@ -1,12 +1,13 @@
 """CNN boundary head (the reference's adapted/detect/cnn.py) on MI355X.
 
-Division of labour, as BASELINE.json:north_star prescribes: the small 1-D conv net itself
-runs in PyTorch-ROCm (float32; bf16/fp16 would break score parity); everything around it is
-the HIP library: ``prepare_data`` (pool + per-read median/MAD normalisation, C1) and the
-candidate validation loop (V1 with k candidates).  The top-k candidate extraction of
-``cnn_predict`` (C3) is index bookkeeping on one float per pooled sample and stays on the
-host in numpy/scipy exactly as the reference has it, including its row-misalignment quirk
-when a read has no peak (see ``_topk_candidates``).
+Everything numeric is the HIP library: ``prepare_data`` (pool + per-read median / MAD normalisation, C1), the conv net
+itself (C2: hand-written, the two 64 -> 64 layers on the float32 matrix cores -- adapted_amd/csrc/cnn_conv.h), ``cnn_predict``
+(C3: both arg-maxes, scipy's find_peaks(distance=5) on the flattened scores, the per-read top-k and the reference's
+row-compaction quirk -- adapted_amd/csrc/cnn_topk.h) and the candidate validation loop (V1 with k candidates).  The product
+path (``detect_rows`` / ``detect_rows_device``) is ONE library call, ``adp_detect_cnn``, plus the rare short-read fallback.
+PyTorch is optional: ``load_cnn_model`` returns the reference's ``nn.Sequential`` (state-dict compatible), and
+``conv="torch"`` runs the conv stack through PyTorch-ROCm / MIOpen instead (kept as the float32 cross-check of C2; the
+hand-written stack is 3.4x faster at the 200 k window).
 
 reference: BoundariesCNN :16-52, load_cnn_model :55-67, prepare_data :70-82, cnn_score :85-98,
 cnn_predict :101-160, cnn_detect :165-182, cnn_detect_boundaries :185-201 (adapted/detect/cnn.py);
@@ -77,12 +78,40 @@ def load_cnn_model(path: str, device: Optional[Union[int, str]] = None):
     return model.to(torch.device("cuda", device) if isinstance(device, int) else torch.device(device))
 
 
+def load_cnn_weights(path: str) -> dict:
+    """The state dict as float32 numpy arrays, without PyTorch for ``.npz`` files (keys "0.weight" ... "6.bias")."""
+    f = _resolve(path)
+    if f.endswith(".npz"):
+        z = np.load(f)
+        return {k: np.ascontiguousarray(z[k], dtype=np.float32) for k in z.files if k[0].isdigit()}
+    sd = _torch().load(f, weights_only=True, map_location="cpu")
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def _state_of(model, spc=None) -> dict:
+    """model: the nn.Sequential of load_cnn_model, a state dict / dict of arrays, or None (the config's model_name)"""
+    if model is None:
+        return load_cnn_weights(spc.cnn_boundaries.model_name)
+    if isinstance(model, dict):
+        return model
+    return model.state_dict()
+
+
+def ensure_weights(eng, model, spc=None):
+    """hand the model's weights to the engine once (adp_cnn_set_weights)"""
+    key = id(model) if model is not None else ("cfg", spc.cnn_boundaries.model_name)
+    if getattr(eng, "_cnn_key", None) != key:
+        eng.cnn_set_weights(_state_of(model, spc))
+        eng._cnn_key = key
+        eng._cnn_model_ref = model  # (keeps id(model) from being reused while the engine remembers it)
+
+
 def _model_device(model):
     return next(model.parameters()).device
 
 
 def prepare_data(batch_of_signals: np.ndarray, core_params, spc=None, engine=None):
-    """float32 [N, 1, Lc] on the model's GPU (C1, computed by the HIP library)."""
+    """float32 [N, 1, Lc] on the GPU (C1, computed by the HIP library)."""
     torch = _torch()
     sig = np.ascontiguousarray(batch_of_signals, dtype=np.float32)
     n, m = sig.shape
@@ -97,74 +126,47 @@ def prepare_data(batch_of_signals: np.ndarray, core_params, spc=None, engine=Non
     return out
 
 
-def cnn_score(batch_of_prepared_signals, model):
-    if len(model.state_dict()) == 0:
-        raise ValueError("Model weights were not loaded")
+def cnn_score(batch_of_prepared_signals, model, engine=None):
+    """float32 [N, 2, Lo].  engine: the hand-written conv stack of the HIP library (adp_cnn_forward); without one the
+    PyTorch-ROCm modules of ``model`` (the float32 cross-check)."""
     torch = _torch()
-    with torch.no_grad():
-        return model(batch_of_prepared_signals)
-
-
-def _topk_candidates(ch1: np.ndarray, k: int) -> np.ndarray:
-    """Per-read top-k poly(A) candidates from the masked channel-1 scores (reference cnn.py:136-160).
-    The reference groups the peaks of the FLATTENED array by read and writes group i into row i;
-    a read without any peak therefore shifts all later groups up by one row.  Kept as is."""
-    from scipy.signal import find_peaks
-
-    n, Lo = ch1.shape
-    flat = ch1.reshape(-1)
-    cand, _ = find_peaks(flat, distance=5)
-    heights = flat[cand]
-    read_idx = cand // Lo
-    order = np.lexsort((-heights, read_idx))
-    cand = cand[order]
-    groups = np.split(np.mod(cand, Lo), np.where(np.diff(read_idx) != 0)[0] + 1)
-    out = np.zeros((n, k), dtype=np.int64)
-    for i, peaks in enumerate(groups):
-        out[i, : len(peaks)] = peaks[:k]
+    if engine is None:
+        if len(model.state_dict()) == 0:
+            raise ValueError("Model weights were not loaded")
+        with torch.no_grad():
+            return model(batch_of_prepared_signals)
+    x = batch_of_prepared_signals.contiguous()
+    n, _, Lc = x.shape
+    Lo = 3 * ((Lc - 1) // 3 + 1) - 2
+    ensure_weights(engine, model)
+    out = torch.empty((n, 2, Lo), dtype=torch.float32, device=x.device)
+    torch.cuda.current_stream(x.device).synchronize()  # the engine works on its own stream
+    engine.cnn_forward(x.data_ptr(), n, Lc, out.data_ptr())
     return out
 
 
-def cnn_predict(batch_of_prepared_signals, model, params, core_params, engine=None) -> np.ndarray:
-    """engine: with a HIP engine at hand the top-k candidate extraction runs on the device (adp_cnn_topk); batches
-    holding a case only scipy's formulation settles (exact ties, plateaus: the kernel reports them) take the host
-    formulation below, which is the reference's own."""
+def cnn_predict(batch_of_prepared_signals, model, params, core_params, engine=None, conv: str = "hip") -> np.ndarray:
+    """int [N, 1 + max(k, 1)] pooled indices: adapter position and the k poly(A) candidates (C3 on the device)."""
     torch = _torch()
-    scores = cnn_score(batch_of_prepared_signals, model)
+    if engine is None:
+        raise lib.HipLibraryError("cnn_predict runs on the HIP engine (no CPU path)")
+    if int(params.polya_cand_k) != int(engine.cfg.polya_cand_k):
+        raise ValueError("params.polya_cand_k differs from the engine's configuration")
+    scores = cnn_score(batch_of_prepared_signals, model, engine=engine if conv == "hip" else None).contiguous()
     n, _, Lo = scores.shape
-    na = (core_params.max_obs_adapter - core_params.min_obs_adapter) // core_params.downscale_factor
-    adapter_pos = torch.argmax(scores[:, 0, :na], dim=1)
-    k = int(params.polya_cand_k)
-    pos = torch.arange(Lo, device=scores.device)[None, :]
-    ch1 = scores[:, 1, :]
-    if k >= 1:
-        ch1 = torch.where(pos < adapter_pos[:, None], torch.full_like(ch1, SCORE_EXCL), ch1)
-        polya_pos = torch.argmax(ch1, dim=1)
-    else:
-        polya_pos = torch.zeros(n, dtype=torch.int64, device=scores.device)
-    a = adapter_pos.cpu().numpy().astype(np.int64)
-    if k > 1:
-        if engine is not None and scores.is_cuda and scores.is_contiguous():
-            torch.cuda.current_stream(scores.device).synchronize()  # the engine works on its own stream
-            apos = adapter_pos.to(torch.int64).contiguous()
-            ppos = polya_pos.to(torch.int64).contiguous()
-            cand, cnt, flag = engine.cnn_topk(scores.data_ptr(), apos.data_ptr(), ppos.data_ptr(), n, Lo, k)
-            if flag == 0:
-                # the reference writes the group of the i-th read THAT HAS PEAKS into row i (cnn.py:150-158)
-                topk = np.zeros((n, k), dtype=np.int64)
-                nz = np.flatnonzero(cnt > 0)
-                topk[: nz.size] = cand[nz]
-                return np.column_stack((a[:, None], topk))
-        ch1 = torch.where(pos > polya_pos[:, None], torch.full_like(ch1, SCORE_EXCL), ch1)
-        topk = _topk_candidates(ch1.cpu().numpy(), k)
-        return np.column_stack((a[:, None], topk))
-    return np.column_stack((a, polya_pos.cpu().numpy().astype(np.int64)))
+    torch.cuda.current_stream(scores.device).synchronize()
+    b = engine.cnn_predict(scores.data_ptr(), n, n, Lo)
+    off, ds = int(core_params.min_obs_adapter), int(core_params.downscale_factor)
+    return np.where(b == 0, 0, (b - off) // ds)  # (a sample position of 0 stands for index 0, cnn.py:173-179)
 
 
-def cnn_detect(batch_of_signals: np.ndarray, model, params, core_params, spc=None, engine=None) -> np.ndarray:
+def cnn_detect(batch_of_signals: np.ndarray, model, params, core_params, spc=None, engine=None, conv: str = "hip") -> np.ndarray:
     prepared = prepare_data(batch_of_signals, core_params, spc=spc, engine=engine)
-    prepared = prepared.to(_model_device(model))
-    preds = (cnn_predict(prepared, model, params, core_params, engine=engine) * core_params.downscale_factor
+    if engine is None:
+        from .combined import get_engine
+
+        engine = get_engine(spc, prepared.shape[0], np.asarray(batch_of_signals).shape[1], prepared.device.index)
+    preds = (cnn_predict(prepared, model, params, core_params, engine=engine, conv=conv) * core_params.downscale_factor
              + core_params.min_obs_adapter).astype(int)
     preds[preds == core_params.min_obs_adapter] = 0  # where the prediction was zero, set back to zero
     return preds
@@ -175,30 +177,27 @@ def cnn_detect_boundaries(batch_of_signals: np.ndarray, model, params, core_para
     return [Boundaries(adapter_start=0, adapter_end=p[0], polya_end=p[1], polya_end_topk=p[1:]) for p in preds]
 
 
-def detect_rows_device(eng, dsig: int, dlen: int, n: int, lens_host: np.ndarray, model, spc) -> np.ndarray:
-    """combined_detect_cnn over a DEVICE-resident batch (pointers) -> adp_row[]; the short-read fallback needs
-    the host copy of the few affected reads only."""
-    torch = _torch()
-    core = spc.core
+def _need_fallback(rows, bounds, lens, spc):
+    """C4 "hail mary" for short reads (combined.py:251-301): which reads take it"""
+    ae, pe = bounds[:, 0], bounds[:, 1]
+    return np.flatnonzero((rows["success"] == 0) & ~((rows["fail_code"] >= 9) & (rows["fail_code"] <= 14)) & (ae > 0) & (pe > 0)
+                          & (pe - ae > 1000) & (np.asarray(lens).astype(np.int64) < 2 * spc.core.max_obs_adapter))
+
+
+def detect_rows_device(eng, dsig: int, dlen: int, n: int, lens_host: np.ndarray, model, spc, minibatch: Optional[int] = None) -> np.ndarray:
+    """combined_detect_cnn over a DEVICE-resident batch (pointers) -> adp_row[]; ONE library call (adp_detect_cnn); the
+    short-read fallback needs the host copy of the few affected reads only.  minibatch: reads per call of the reference
+    (its find_peaks and row compaction work on one minibatch); default: the whole batch."""
+    ensure_weights(eng, model, spc)
     m = eng.m
-    Lc = (m - core.min_obs_adapter + core.downscale_factor - 1) // core.downscale_factor
-    x = torch.empty((n, 1, Lc), dtype=torch.float32, device=torch.device("cuda", eng.device))
-    eng.cnn_prepare(dsig, n, x.data_ptr(), device_ptrs=True)
-    preds = (cnn_predict(x.to(_model_device(model)), model, spc.cnn_boundaries, core, engine=eng) * core.downscale_factor
-             + core.min_obs_adapter).astype(int)
-    preds[preds == core.min_obs_adapter] = 0
-    bounds = np.ascontiguousarray(preds, dtype=np.int64)
-    rows = eng.validate_rows(dsig, dlen, n, bounds, device_ptrs=True)
+    rows, bounds = eng.detect_cnn_rows(dsig, dlen, n, minibatch or n, device_ptrs=True)
     if spc.cnn_boundaries.fallback_to_llr_short_reads:
-        ae, pe = bounds[:, 0], bounds[:, 1]
-        need = ((rows["success"] == 0) & ~((rows["fail_code"] >= 9) & (rows["fail_code"] <= 14)) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
-                & (lens_host.astype(np.int64) < 2 * core.max_obs_adapter))
-        idx = np.flatnonzero(need)
+        idx = _need_fallback(rows, bounds, lens_host, spc)
         if idx.size:
             sub = np.zeros((idx.size, m), dtype=np.float32)
             for j, i in enumerate(idx):
                 eng.d2h(sub[j], dsig + int(i) * m * 4)
-            _apply_fallback(eng, rows, idx, sub, lens_host[idx], bounds, spc)
+            _apply_fallback(eng, rows, idx, sub, np.asarray(lens_host)[idx], bounds, spc)
     return rows
 
 
@@ -217,27 +216,29 @@ def _apply_fallback(eng, rows, idx, sig_sub, lens_sub, bounds, spc):
         rows[ii] = eng.validate_rows(sig_sub[redo], lens_sub[redo], len(ii), b2)
 
 
-def detect_rows(eng, sig: np.ndarray, lens: np.ndarray, model, spc) -> np.ndarray:
-    """combined_detect_cnn over one batch -> adp_row[] (reference adapted/detect/combined.py:230-309)."""
+def detect_rows(eng, sig: np.ndarray, lens: np.ndarray, model, spc, conv: str = "hip") -> np.ndarray:
+    """combined_detect_cnn over one batch -> adp_row[] (reference adapted/detect/combined.py:230-309).
+    conv = "torch": the conv stack through PyTorch-ROCm instead of the library's own (cross-check)."""
     n = sig.shape[0]
-    preds = cnn_detect(sig, model, spc.cnn_boundaries, spc.core, spc=spc, engine=eng)
-    if preds.shape[1] < 2:
+    if int(spc.cnn_boundaries.polya_cand_k) < 1:
         raise ValueError("polya_cand_k must be >= 1")
-    bounds = np.ascontiguousarray(preds, dtype=np.int64)
-    rows = eng.validate_rows(sig, lens, n, bounds)
+    if conv == "hip":
+        ensure_weights(eng, model, spc)
+        rows, bounds = eng.detect_cnn_rows(sig, lens, n, n)
+    else:
+        preds = cnn_detect(sig, model, spc.cnn_boundaries, spc.core, spc=spc, engine=eng, conv=conv)
+        bounds = np.ascontiguousarray(preds, dtype=np.int64)
+        rows = eng.validate_rows(sig, lens, n, bounds)
     if spc.cnn_boundaries.fallback_to_llr_short_reads:
-        # C4 "hail mary" for short reads (combined.py:251-301)
-        ae, pe = bounds[:, 0], bounds[:, 1]
-        need = ((rows["success"] == 0) & ~((rows["fail_code"] >= 9) & (rows["fail_code"] <= 14)) & (ae > 0) & (pe > 0) & (pe - ae > 1000)
-                & (lens.astype(np.int64) < 2 * spc.core.max_obs_adapter))
-        idx = np.flatnonzero(need)
+        idx = _need_fallback(rows, bounds, lens, spc)
         if idx.size:
             _apply_fallback(eng, rows, idx, sig[idx], lens[idx], bounds, spc)
     return rows
 
 
 def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, model, spc,
-                        device: int = 0) -> Union[List[DetectResults], DetectResults]:
+                        device: int = 0, conv: str = "hip") -> Union[List[DetectResults], DetectResults]:
+    """model: the nn.Sequential of load_cnn_model, a dict of weight arrays (load_cnn_weights), or None (the config's model)"""
     from .combined import _as_batch, get_engine
 
     sig, lens = _as_batch(batch_of_signals, full_signal_lens)
@@ -245,6 +246,6 @@ def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarr
     eng = get_engine(spc, n, m, device)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", category=RuntimeWarning)
-        rows = detect_rows(eng, sig, lens, model, spc)
+        rows = detect_rows(eng, sig, lens, model, spc, conv=conv)
     res = lib.rows_to_results(rows, "cnn")
     return res if len(res) > 1 else res[0]

@@ -134,7 +134,7 @@ def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_si
 
 
 def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, model, spc,
-                        device: int = 0) -> Union[List[DetectResults], DetectResults]:
+                        device: int = 0, conv: str = "hip") -> Union[List[DetectResults], DetectResults]:
     from . import cnn as _cnn
 
-    return _cnn.combined_detect_cnn(batch_of_signals, full_signal_lens, model, spc, device=device)
+    return _cnn.combined_detect_cnn(batch_of_signals, full_signal_lens, model, spc, device=device, conv=conv)

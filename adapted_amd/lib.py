@@ -125,7 +125,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
            "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
-           "adp_cnn_set_weights", "adp_cnn_forward"]
+           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -398,14 +398,38 @@ class Engine:
         return rows
 
     def cnn_topk(self, scores_ptr: int, adapter_pos_ptr: int, polya_pos_ptr: int, n: int, Lo: int, k: int):
-        """C3 on the device: (cand int32 [n, k], n_peaks int32 [n], flag).  All three inputs are device pointers."""
+        """the k > 1 part of C3 behind given arg-maxes (tests): (cand int32 [n, k], n_peaks int32 [n]); device pointers in"""
         cand = np.zeros((n, k), dtype=np.int32)
         cnt = np.zeros(n, dtype=np.int32)
-        flag = np.zeros(1, dtype=np.int32)
         self._check(self.lib.adp_cnn_topk(self._h, C.c_void_p(int(scores_ptr)), C.c_void_p(int(adapter_pos_ptr)),
                                           C.c_void_p(int(polya_pos_ptr)), int(n), int(Lo), int(k), cand.ctypes.data_as(C.c_void_p),
-                                          cnt.ctypes.data_as(C.c_void_p), flag.ctypes.data_as(C.c_void_p)))
-        return cand, cnt, int(flag[0])
+                                          cnt.ctypes.data_as(C.c_void_p)))
+        return cand, cnt
+
+    def cnn_predict(self, scores_ptr: int, n: int, minibatch: int, Lo: int) -> np.ndarray:
+        """C3 + the scaling of cnn_detect on the device: int64 [n, 1 + max(k, 1)] (adapter end, poly(A) candidates; samples)"""
+        k = max(1, int(self.cfg.polya_cand_k))
+        out = np.zeros((n, 1 + k), dtype=np.int64)
+        self._check(self.lib.adp_cnn_predict(self._h, C.c_void_p(int(scores_ptr)), int(n), int(minibatch), int(Lo),
+                                             out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def detect_cnn_rows(self, signals, full_lens, n: int, minibatch: int, device_ptrs: bool = False, rows_dev: Optional[int] = None,
+                        want_bounds: bool = True):
+        """combined_detect_cnn without the short-read fallback -> (rows or None when rows_dev is given, bounds int64 [n, 1 + k])"""
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        k = max(1, int(self.cfg.polya_cand_k))
+        bounds = np.zeros((n, 1 + k), dtype=np.int64) if want_bounds else None
+        if rows_dev is not None:
+            flags |= ADP_OUT_DEVICE
+            rows, rp = None, C.c_void_p(rows_dev)
+        else:
+            rows = np.zeros(n, dtype=ROW_DTYPE)
+            rp = rows.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.adp_detect_cnn(self._h, sp, lp, int(n), self.m, int(minibatch), flags, rp,
+                                            bounds.ctypes.data_as(C.c_void_p) if want_bounds else None))
+        del keep
+        return rows, bounds
 
     def cnn_set_weights(self, state):
         """state: mapping with the reference's state-dict keys ("0.weight" ... "6.bias") -> float32 arrays (numpy, or anything

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ADP_ABI_VERSION 2
+#define ADP_ABI_VERSION 3
 
 /* error codes */
 #define ADP_OK 0
@@ -188,14 +188,24 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
 int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, const float *w3, const float *b3);
 int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out);
-/* C3, the k > 1 part of cnn_predict (adapted/detect/cnn.py:136-160): per read the k best poly(A) candidates among the
- * distance-5 peaks of the masked channel-1 scores.  scores: DEVICE float32 [n, 2, Lo] (the conv net's output);
- * adapter_pos / polya_pos: DEVICE int64 [n] (the two arg-maxes cnn_predict takes first).  Host outputs:
- * cand int32 [n, k] (positions, zero padded), n_peaks int32 [n] (peaks of the read after the distance rule),
- * *flag != 0 when the batch contains a case only the reference's scipy formulation settles (exact ties,
- * plateaus, reads meeting across the row boundary of the flattened array): the caller then runs that. */
+/* C3, cnn_predict (adapted/detect/cnn.py:101-160) and the scaling of cnn_detect (:165-182) on the device
+ * (adapted_amd/csrc/cnn_topk.h).  scores: DEVICE float32 [n, 2, Lo] (the conv net's output).  Reads [q * minibatch,
+ * (q + 1) * minibatch) are one call of the reference: its find_peaks runs over that minibatch's FLATTENED scores and the
+ * candidates of the i-th read with peaks go to row i of the minibatch (:150-158), both reproduced.
+ * bounds_out: HOST int64 [n, 1 + max(k, 1)], k = cfg.polya_cand_k: adapter end and the k poly(A) candidates in samples
+ * (index * downscale_factor + min_obs_adapter, a value equal to min_obs_adapter -> 0), i.e. what cnn_detect returns.
+ * Exact ties between peaks closer than 5 samples: the later index counts as higher (scipy leaves it to an unstable sort). */
+int adp_cnn_predict(adp_handle *h, const float *scores_dev, int n_reads, int minibatch, int Lo, int64_t *bounds_out);
+/* The k > 1 part alone, behind given arg-maxes (tests): adapter_pos / polya_pos DEVICE int64 [n]; host outputs cand int32
+ * [n, k] (positions inside the read, zero padded) and n_peaks int32 [n] (peaks of the read after the distance rule).
+ * All n reads are one minibatch. */
 int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_pos_dev, const int64_t *polya_pos_dev,
-                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out, int32_t *flag_out);
+                 int n_reads, int Lo, int k, int32_t *cand_out, int32_t *n_peaks_out);
+/* combined_detect_cnn (adapted/detect/combined.py:230-309) in one call, up to its short-read fallback (the caller applies
+ * that with adp_llr_refine_polya + adp_validate_candidates, :251-301): prepare_data -> conv net -> cnn_predict -> the
+ * validate_boundaries loop.  Needs adp_cnn_set_weights.  bounds_out (HOST, may be NULL) as adp_cnn_predict. */
+int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch, int flags,
+                   adp_row *rows_out, int64_t *bounds_out);
 /* Validate with explicit primary boundaries: bounds int64 [n_reads, 1 + k] = adapter_end, k poly(A)
  * candidates (0 terminates), exactly what cnn_detect_boundaries hands to validate_boundaries. */
 int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,

@@ -1,7 +1,7 @@
-"""GPU parity of the CNN path (C1 prepare, C2 conv head in PyTorch-ROCm, C3 predict, V1 with k
-candidates, C4 short-read fallback) against the golden vectors of the real reference.
+"""GPU parity of the CNN path (C1 prepare, C2 conv head -- hand-written, cross-checked against PyTorch-ROCm --, C3 predict,
+V1 with k candidates, C4 short-read fallback) against the golden vectors of the real reference.
 
-The conv stack runs in a different library (MIOpen vs the reference's CPU oneDNN), so C2 scores
+The conv stack sums the same float32 products in another order than the reference's CPU oneDNN, so C2 scores
 are compared within 1e-4 absolute; C3 indices are arg-max / peak picks on those scores and are
 required to be identical on this fixture (a flip would be reported read by read)."""
 import numpy as np
@@ -34,22 +34,27 @@ def test_prepare_scores_preds(setup):
     for k in st["dump_idx"]:
         k = int(k)
         assert np.array_equal(xc[k, 0], st["prep_%d" % k]), k      # C1 bit-exact
-    sc = cnn.cnn_score(x, s["model"]).cpu().numpy()
-    for k in st["dump_idx"]:
-        k = int(k)
-        assert sc[k].shape == st["scores_%d" % k].shape
-        assert np.max(np.abs(sc[k] - st["scores_%d" % k])) < 1e-4, k  # C2
-    preds = cnn.cnn_detect(s["sig"], s["model"], spc.cnn_boundaries, spc.core, spc=spc, engine=s["eng"])
-    flips = np.flatnonzero((preds != st["preds"]).any(axis=1))
-    assert flips.size == 0, ("reads whose CNN indices differ from the CPU reference", flips, preds[flips], st["preds"][flips])
+    for conv, engine in (("hip", s["eng"]), ("torch", None)):
+        sc = cnn.cnn_score(x, s["model"], engine=engine).cpu().numpy()
+        for k in st["dump_idx"]:
+            k = int(k)
+            assert sc[k].shape == st["scores_%d" % k].shape
+            assert np.max(np.abs(sc[k] - st["scores_%d" % k])) < 1e-4, (conv, k)  # C2
+        preds = cnn.cnn_detect(s["sig"], s["model"], spc.cnn_boundaries, spc.core, spc=spc, engine=s["eng"], conv=conv)
+        flips = np.flatnonzero((preds != st["preds"]).any(axis=1))
+        assert flips.size == 0, (conv, "reads whose CNN indices differ from the CPU reference", flips, preds[flips], st["preds"][flips])
 
 
 def test_cnn_rows_vs_golden(setup):
     from adapted_amd.detect.combined import combined_detect_cnn
 
     s = setup
-    got = combined_detect_cnn(s["sig"], s["lens"], s["model"], s["spc"])
-    bad = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) for d in row_diffs(g, w, float_rel=1e-5)]
+    for model in (s["model"], None):  # (None: the weights named in the config, loaded without PyTorch)
+        got = combined_detect_cnn(s["sig"], s["lens"], model, s["spc"])
+        bad = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) for d in row_diffs(g, w, float_rel=1e-5)]
+        assert not bad, bad[:10]
+    got_t = combined_detect_cnn(s["sig"], s["lens"], s["model"], s["spc"], conv="torch")
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got_t, s["want"])) for d in row_diffs(g, w, float_rel=1e-5)]
     assert not bad, bad[:10]
     inexact = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) for d in row_diffs(g, w, float_rel=0.0)]
     print("cnn rows: %d float fields differ in the last bits" % len(inexact), inexact[:5])
@@ -64,87 +69,183 @@ def test_cnn_single_read_returns_bare_result(setup):
     assert isinstance(r, DetectResults)
 
 
-def _host_topk(scores, apos, ppos, k):
-    """the reference's formulation of C3 (adapted_amd.detect.cnn._topk_candidates) on explicit arg-max positions"""
-    from adapted_amd.detect import cnn as cnn_mod
+def _select_by_distance_stable(peaks, priority, distance):
+    """scipy's _select_by_peak_distance with a STABLE priority order (equal heights: the later index first), which is what
+    the device implements; scipy itself takes the order from an unstable np.argsort."""
+    keep = np.ones(peaks.size, dtype=bool)
+    order = np.argsort(priority, kind="stable")
+    for i in range(peaks.size - 1, -1, -1):
+        j = order[i]
+        if not keep[j]:
+            continue
+        k = j - 1
+        while k >= 0 and peaks[j] - peaks[k] < distance:
+            keep[k] = False
+            k -= 1
+        k = j + 1
+        while k < peaks.size and peaks[k] - peaks[j] < distance:
+            keep[k] = False
+            k += 1
+    return keep
 
-    n, _, Lo = scores.shape
+
+def _ref_predict(scores, na, k, stable=True):
+    """numpy / scipy formulation of cnn_predict (reference adapted/detect/cnn.py:101-160) on given scores [n, 2, Lo]"""
+    from scipy.signal import find_peaks
+
+    sc = scores.copy()
+    n, _, Lo = sc.shape
+    a = np.argmax(sc[:, 0, :na], axis=1)
     pos = np.arange(Lo)[None, :]
-    ch1 = scores[:, 1, :].copy()
-    ch1[(pos < apos[:, None]) | (pos > ppos[:, None])] = cnn_mod.SCORE_EXCL
-    return cnn_mod._topk_candidates(ch1, k)
+    sc[:, 1, :][pos < a[:, None]] = -5.0
+    p = np.argmax(sc[:, 1, :], axis=1)
+    if k <= 1:
+        return np.column_stack((a, p))
+    sc[:, 1, :][pos > p[:, None]] = -5.0
+    flat = sc[:, 1, :].flatten()
+    if stable:
+        cand, _ = find_peaks(flat)  # every local maximum (plateaus: their midpoint)
+        cand = cand[_select_by_distance_stable(cand, flat[cand], 5)]
+    else:
+        cand, _ = find_peaks(flat, distance=5)
+    heights = flat[cand]
+    read_idx = cand // Lo
+    order = np.lexsort((-heights, read_idx))
+    cand = cand[order]
+    groups = np.split(np.mod(cand, Lo), np.where(np.diff(read_idx) != 0)[0] + 1)
+    out = np.zeros((n, k), dtype=np.int64)
+    for i, peaks in enumerate(groups):
+        out[i, : len(peaks)] = peaks[:k]
+    return np.column_stack((a[:, None], out))
+
+
+def _dev_predict(eng, scores, spc, minibatch=None):
+    import torch
+
+    d = torch.from_numpy(np.ascontiguousarray(scores)).cuda()
+    torch.cuda.synchronize()
+    n, _, Lo = scores.shape
+    b = eng.cnn_predict(d.data_ptr(), n, minibatch or n, Lo)
+    off, ds = spc.core.min_obs_adapter, spc.core.downscale_factor
+    return np.where(b == 0, 0, (b - off) // ds)
+
+
+def _cnn_engine(n=8):
+    import torch
+    from adapted_amd import lib
+    from golden_cases import CASES
+    from util import make_spc
+
+    torch.cuda.init()  # (torch's bundled HIP runtime has to claim the GPU before the library's does, see INTEGRATION.md)
+    spc = make_spc(CASES["rna004_cnn_default"])
+    return lib.Engine(spc, n, spc.sig_preload_size, device=0), spc
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("Lo,n", [(257, 40), (1650, 64), (20050, 12)])
-def test_device_topk_equals_scipy_formulation(Lo, n):
-    """adp_cnn_topk (k_cnn_topk) against the host numpy/scipy formulation of cnn_predict's top-k on random scores,
-    including reads without any peak (the row-misalignment quirk) and reads whose stretch touches the row ends."""
-    import torch
-    from adapted_amd import lib
-    from util import make_spc
-    from golden_cases import CASES
-
-    torch.cuda.init()  # (torch's bundled HIP runtime has to claim the GPU before the library's does, see INTEGRATION.md)
-    spc = make_spc(CASES["rna004_cnn_default"])
-    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
+def test_device_predict_equals_scipy_formulation(Lo, n):
+    """adp_cnn_predict (k_cnn_argmax / k_cnn_topk / k_cnn_bounds) against the numpy / scipy formulation of cnn_predict on
+    random scores, including reads without any peak (the row-misalignment quirk), reads whose stretch touches the row
+    ends and reads with nothing above the mask level."""
+    eng, spc = _cnn_engine(n)
     rng = np.random.default_rng(Lo)
-    k = 10
+    k = int(spc.cnn_boundaries.polya_cand_k)
+    na = (spc.core.max_obs_adapter - spc.core.min_obs_adapter) // spc.core.downscale_factor
     scores = rng.normal(0.0, 2.0, (n, 2, Lo)).astype(np.float32)
-    apos = rng.integers(1, Lo // 3, n).astype(np.int64)
-    apos[1] = 0                             # no masked prefix
+    scores[1, 0, 0] = 60.0                  # adapter position 0: no masked prefix
     scores[5:9, 1, :] -= 8.0                # most scores below the mask level (-5)
-    scores[9, 1, :] = -9.0 - rng.random(Lo).astype(np.float32)  # ALL below it: the arg-max is a masked sample, nothing
-    scores[2, 1, Lo - 1] = 50.0             # is unmasked, a read without peaks (rows shift up, cnn.py:150-158); arg-max at the row end
-    pos = np.arange(Lo)[None, :]
-    # polya_pos as cnn_predict takes it: the (first) arg-max of the scores masked before the adapter position
-    ppos = np.argmax(np.where(pos < apos[:, None], np.float32(-5.0), scores[:, 1, :]), axis=1).astype(np.int64)
-    assert ppos[9] < apos[9] and ppos[2] == Lo - 1
-    dsc = torch.from_numpy(scores).cuda()
-    da, dp = torch.from_numpy(apos).cuda(), torch.from_numpy(ppos).cuda()
-    torch.cuda.synchronize()
-    cand, cnt, flag = eng.cnn_topk(dsc.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
-    assert flag == 0
-    got = np.zeros((n, k), dtype=np.int64)
-    nz = np.flatnonzero(cnt > 0)
-    got[: nz.size] = cand[nz]
-    want = _host_topk(scores, apos, ppos, k)
+    scores[9, 1, :] = -9.0 - rng.random(Lo).astype(np.float32)  # ALL below it (behind a masked prefix): a read without peaks
+    scores[2, 1, Lo - 1] = 50.0             # arg-max at the row end
+    scores[3, 0, min(na, Lo) - 1] = 70.0    # adapter at the end of its search range
+    want = _ref_predict(scores, na, k, stable=False)
+    assert (want == _ref_predict(scores, na, k, stable=True)).all()  # (no ties in random data: both orders agree)
+    got = _dev_predict(eng, scores, spc)
     assert (got == want).all(), np.argwhere(got != want)[:5]
+    # two minibatches in one call = two calls of the reference
+    half = n // 2
+    got2 = _dev_predict(eng, scores, spc, minibatch=half)
+    want2 = np.concatenate([_ref_predict(scores[:half], na, k), _ref_predict(scores[half:], na, k)])
+    assert (got2 == want2).all(), np.argwhere(got2 != want2)[:5]
     eng.close()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["plateau", "tie", "below_mask", "boundary", "empty"])
-def test_device_topk_reports_what_only_scipy_settles(kind):
-    import torch
-    from adapted_amd import lib
-    from util import make_spc
-    from golden_cases import CASES
-
-    torch.cuda.init()
-    spc = make_spc(CASES["rna004_cnn_default"])
-    eng = lib.Engine(spc, 8, spc.sig_preload_size, device=0)
-    n, Lo, k = 6, 300, 10
+@pytest.mark.parametrize("kind", ["plateau", "plateau_at_start", "tie", "tie_chain", "below_mask", "below_mask_rows", "boundary", "boundary_chain",
+                                  "equals_mask", "all_masked", "last_row_end", "nan"])
+def test_device_predict_settles_corner_cases(kind):
+    """what round 1 sent to scipy on the host: plateaus, equal heights within the minimum distance, reads at or below the
+    mask level with nothing masked in front (the masked run behind them can be a peak, possibly in a later read's row),
+    stretches that meet across a row boundary -- all settled on the device, equal to scipy's formulation run with a
+    stable priority order (and to scipy itself wherever it does not depend on the order of equal heights)."""
+    eng, spc = _cnn_engine(8)
+    k = int(spc.cnn_boundaries.polya_cand_k)
+    n, Lo = 6, 300
+    na = 120
+    spc.core.max_obs_adapter = spc.core.min_obs_adapter + na * spc.core.downscale_factor
+    eng.set_config(spc)
     rng = np.random.default_rng(3)
     scores = rng.normal(0.0, 2.0, (n, 2, Lo)).astype(np.float32)
-    apos = np.full(n, 20, dtype=np.int64); ppos = np.full(n, 250, dtype=np.int64)
-    scores[:, 1, 20] = 1.0
-    scores[:, 1, 250] = 30.0  # the arg-max of every read
+    scores[:, 0, 20] = 50.0   # adapter position 20 ...
+    scores[:, 1, 250] = 30.0  # ... poly(A) arg-max 250 for every read, unless changed below
+    same_as_scipy = True
     if kind == "plateau":
-        scores[2, 1, 100] = scores[2, 1, 101] = 9.0
+        scores[2, 1, 100:103] = 9.0; scores[2, 1, 150:152] = 8.0
+    elif kind == "plateau_at_start":
+        scores[2, 1, 20:24] = 9.0; scores[2, 1, 24] = 0.0
     elif kind == "tie":
-        scores[2, 1, 100] = 9.0; scores[2, 1, 101] = 0.0; scores[2, 1, 102] = 9.0; scores[2, 1, 99] = 0.0; scores[2, 1, 103] = 0.0
-    elif kind == "below_mask":
-        apos[2] = 0; scores[2, 1, :] = -6.0 - rng.random(Lo).astype(np.float32); ppos[2] = int(np.argmax(scores[2, 1, :]))
+        scores[2, 1, 99:104] = [0.0, 9.0, 0.0, 9.0, 0.0]; same_as_scipy = False
+    elif kind == "tie_chain":
+        scores[2, 1, 99:110] = [0.0, 9.0, 0.0, 9.0, 0.0, 9.0, 0.0, 9.0, 0.0, 9.0, 0.0]; same_as_scipy = False
+    elif kind == "below_mask":      # a read with everything below -5 and no masked prefix: the masked run behind it is a peak
+        scores[2, 0, :] = 0.0; scores[2, 0, 0] = 50.0
+        scores[2, 1, :] = -6.0 - rng.random(Lo).astype(np.float32)
+        scores[3, 1, 20] = -7.0       # ... if the next stretch starts below the mask level too
+    elif kind == "below_mask_rows":   # the same with fully masked reads in between: the peak lands in a later row
+        scores[1, 0, :] = 0.0; scores[1, 0, 0] = 50.0
+        scores[1, 1, :] = -6.0 - rng.random(Lo).astype(np.float32)
+        scores[2:4, 1, :] = -9.0      # behind a masked prefix: arg-max 0, nothing unmasked
+        scores[4, 1, 20] = -7.0
     elif kind == "boundary":
-        scores[2, 1, Lo - 2] = 40.0; ppos[2] = Lo - 2; apos[3] = 1
-    elif kind == "empty":
-        scores[2, 1, 250] = -5.0; scores[2, 1, 20:250] = -7.0  # the maximum equals the mask level: a plateau with the mask
-    dsc = torch.from_numpy(scores).cuda()
-    da, dp = torch.from_numpy(apos).cuda(), torch.from_numpy(ppos).cuda()
+        scores[2, 1, Lo - 2] = 40.0; scores[3, 0, :] = 0.0; scores[3, 0, 1] = 50.0; scores[3, 1, 1] = 35.0; scores[3, 1, 2] = 3.0
+    elif kind == "boundary_chain":
+        for r in (1, 2, 3):
+            scores[r, 1, Lo - 1] = 40.0 + r; scores[r + 1, 0, :] = 0.0; scores[r + 1, 0, 0] = 50.0; scores[r + 1, 1, 0] = 20.0; scores[r + 1, 1, 1] = 21.0 + r
+    elif kind == "equals_mask":       # samples that equal -5.0 exactly next to masked ones
+        scores[2, 0, :] = 0.0; scores[2, 0, 0] = 50.0
+        scores[2, 1, :] = -5.0; scores[2, 1, 100] = -7.0
+        scores[3, 1, 20] = -5.0; scores[3, 1, 21] = -6.0
+    elif kind == "all_masked":
+        scores[:, 1, :] = -9.0
+    elif kind == "last_row_end":
+        scores[n - 1, 1, Lo - 1] = 60.0; scores[0, 0, :] = 0.0; scores[0, 0, 0] = 50.0; scores[0, 1, 0] = 45.0
+    elif kind == "nan":
+        scores[2, 1, 200] = np.nan; scores[3, 0, 7] = np.nan
+    want = _ref_predict(scores, na, k, stable=True)
+    if same_as_scipy:
+        assert (want == _ref_predict(scores, na, k, stable=False)).all()
+    got = _dev_predict(eng, scores, spc)
+    assert (got == want).all(), (kind, np.argwhere(got != want)[:5], got[got != want][:5], want[got != want][:5])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_device_topk_behind_given_argmaxes():
+    """adp_cnn_topk (the k > 1 part alone) on explicit positions"""
+    import torch
+
+    eng, spc = _cnn_engine(8)
+    n, Lo, k = 5, 400, 10
+    rng = np.random.default_rng(9)
+    scores = rng.normal(0.0, 2.0, (n, 2, Lo)).astype(np.float32)
+    apos = np.full(n, 30, dtype=np.int64)
+    scores[:, 1, 300] = 25.0
+    ppos = np.full(n, 300, dtype=np.int64)
+    d = torch.from_numpy(scores).cuda(); da = torch.from_numpy(apos).cuda(); dp = torch.from_numpy(ppos).cuda()
     torch.cuda.synchronize()
-    _, _, flag = eng.cnn_topk(dsc.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
-    assert flag != 0, kind
+    cand, cnt = eng.cnn_topk(d.data_ptr(), da.data_ptr(), dp.data_ptr(), n, Lo, k)
+    sc = scores.copy(); sc[:, 0, :] = 0.0; sc[:, 0, 30] = 1.0
+    want = _ref_predict(sc, Lo, k)[:, 1:]
+    assert (cnt > 0).all() and (cand == want).all()
     eng.close()
 
 

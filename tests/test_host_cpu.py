@@ -115,7 +115,7 @@ def test_abi_library_loads_and_exports_header_symbols():
     from adapted_amd import lib
 
     L = lib.load()
-    assert L.adp_abi_version() == 2
+    assert L.adp_abi_version() == 3
     assert L.adp_sizeof_row() == lib.ROW_DTYPE.itemsize == 536
     assert L.adp_sizeof_cfg() == ctypes.sizeof(lib.AdpCfg)
     with open(os.path.join(ROOT, "include", "adapted_hip.h")) as fh:
