@@ -75,7 +75,7 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap;
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
 };
@@ -218,7 +218,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -358,11 +358,33 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     in.kmax = kmax; in.n_reads = n; in.m = m; in.mbsize = mbsize;
     in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
     in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
-    in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>();
+    // several candidates per read (the CNN path): moving-window series up to the LARGEST candidate for every read (the
+    // window, not MVS_CAP, bounds them), then the order statistics of all candidates in shared sweeps (cand_stats.h)
+    // (below ~32 k samples of preload the slices are short enough for k_validate's own wave-per-read statistics, which then
+    // cost less than the workgroup-per-read sweeps: 14 vs 51 ms per 32 000 reads at the default window)
+    const bool multi = kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite && h->m > 32768 &&
+                       h->cfg.pA_var_window <= MV_HIST && h->cfg.pA_mean_window <= MV_HIST;
+    const int cap = multi ? h->vstride : MVS_CAP;
+    if (multi && (h->series.ensure((size_t)n * 2 * cap * 4) || h->cstat.ensure((size_t)n * kmax * sizeof(CandStat)))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>(); in.series_cap = cap;
+    in.cstat = multi ? h->cstat.as<CandStat>() : nullptr;
     if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
-        Scope s(h, "k_mvs_series");
-        hipLaunchKernelGGL(k_mvs_series, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
-                           h->series.as<float>(), h->have_series.as<int8_t>());
+        if (multi) {
+            Scope s(h, "k_mvs_series_wave");
+            hipLaunchKernelGGL(k_mvs_series_wave, dim3(n), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                               h->series.as<float>(), cap, h->have_series.as<int8_t>());
+        } else {
+            Scope s(h, "k_mvs_series");
+            hipLaunchKernelGGL(k_mvs_series, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                               h->series.as<float>(), cap, h->have_series.as<int8_t>());
+        }
+        if (multi) {
+            static bool attr_set = false;
+            if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared))); attr_set = true; }
+            Scope s(h, "k_cand_stats");
+            hipLaunchKernelGGL(k_cand_stats, dim3(n), dim3(CS_THREADS), sizeof(CsShared), h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                               (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
+        }
     } else {
         (void)hipMemsetAsync(h->have_series.p, 0, (size_t)n, h->stream);
     }

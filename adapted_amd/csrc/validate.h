@@ -15,6 +15,7 @@
 #include "common.h"
 #include "wave_stats.h"
 #include "block_stats.h"
+#include "cand_stats.h"
 
 struct ValidateIn {
     const float *sig;          // [n_reads, m]
@@ -26,8 +27,10 @@ struct ValidateIn {
     const MbState *mbs;        // may be nullptr (no minibatch gating)
     float *scratch;            // [slots, 2, scratch_stride]
     int scratch_stride;
-    const float *series;       // [n_reads, 2, MVS_CAP] moving mean / var of candidate 0 (k_mvs_series) or nullptr
+    const float *series;       // [n_reads, 2, series_cap] moving mean / var up to the largest candidate (k_mvs_series) or nullptr
     const int8_t *have_series; // [n_reads]
+    int series_cap;
+    const CandStat *cstat;     // [n_reads, kmax] the candidates' order statistics (k_cand_stats) or nullptr
 };
 
 static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
@@ -270,9 +273,10 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
 
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
+// shift_cache: the median shift across the adapter end is the same for every candidate of a read (value, flag)
 static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
                                    double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
-                                   const float *pre_mean, const float *pre_var)
+                                   const float *pre_mean, const float *pre_var, const CandStat *cst, float &shift_val, bool &shift_have)
 {
     MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
     if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return o;
@@ -284,6 +288,11 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) {
         o.exc = ADP_F_EXC_MOVE_WINDOW; return o;
     }
+    float fvar, fmean, fmed;
+    double lrange;
+    if (cst && cst->ready && wvar && wmean) { // all five order statistics of this candidate came out of the shared sweeps
+        fvar = cst->fvar; fmean = cst->fmean; fmed = cst->fmed; lrange = cst->q85 - cst->q15;
+    } else {
     // the two sequential recurrences run side by side in lanes 0 and 1
     __syncthreads();
     if (pre_mean) { scr_mean = const_cast<float *>(pre_mean); scr_var = const_cast<float *>(pre_var); }
@@ -299,16 +308,20 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     __syncthreads();
     if (sc && lane_id() == 0) sc->n = 0; // the scratch series were rewritten: drop any mirror of them
     __syncthreads();
-    float fvar, fmean;
     if (wvar) fvar = wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws, sc);
     else fvar = wave_np_var(x, n, ws, nullptr);
     if (wmean) fmean = wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws, sc);
     else fmean = wave_np_mean(x, n, ws);
-    float fmed = wave_median(x, n, 0, 0.f, ws, sc);
-    double lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws, sc) - wave_percentile(x, n, 15.0, ws, sc) : (double)__builtin_nanf("");
-    long long r1 = a_e + cfg.median_shift_window; if (r1 > S) r1 = S;
-    long long l0 = a_e - cfg.median_shift_window; if (l0 < 0) l0 = 0;
-    float shift = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws, sc) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws, sc);
+    fmed = wave_median(x, n, 0, 0.f, ws, sc);
+    lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws, sc) - wave_percentile(x, n, 15.0, ws, sc) : (double)__builtin_nanf("");
+    }
+    if (!shift_have) {
+        long long r1 = a_e + cfg.median_shift_window; if (r1 > S) r1 = S;
+        long long l0 = a_e - cfg.median_shift_window; if (l0 < 0) l0 = 0;
+        shift_val = wave_median(sig + a, (int)(r1 - a), 0, 0.f, ws, sc) - wave_median(sig + l0, (int)(a - l0), 0, 0.f, ws, sc);
+        shift_have = true;
+    }
+    const float shift = shift_val;
     o.mean = (double)fmean; o.var = (double)fvar; o.med = (double)fmed; o.lrange = lrange; o.shift = (double)shift;
     int f = 0;
     if (!in_range_d(o.mean, pr0, pr1)) f |= 1;
@@ -387,7 +400,7 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S,
 #define MVS_CAP 8192
 __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                    int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
-                                                   float *__restrict__ series, int8_t *__restrict__ have)
+                                                   float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_reads) return;
@@ -405,12 +418,42 @@ __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sig
     const int n = b - a;
     const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
     if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) return;
-    if (n > MVS_CAP) return;
+    if (n > cap) return;
     const float *x = sigs + (size_t)r * m + a;
-    float *smean = series + (size_t)r * 2 * MVS_CAP, *svar = smean + MVS_CAP;
+    float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
     if (wvar) bn_move_var(x, n, cfg.pA_var_window, svar);
     if (wmean) bn_move_mean(x, n, cfg.pA_mean_window, smean);
     have[r] = 1;
+}
+
+// The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload): one WAVE per read --
+// coalesced chunk loads into LDS, the two chains in lanes 0 and 1 (wave_move_series).  With one lane per read the chains
+// wait on scattered loads (38 ms per 4000 reads at the 200 k window); here they run from LDS.
+// grid = n_reads; block = 64.
+__global__ void __launch_bounds__(64) k_mvs_series_wave(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+                                                        int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
+                                                        float *__restrict__ series, int cap, int8_t *__restrict__ have)
+{
+    __shared__ WaveScratch ws_;
+    LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
+    const int r = blockIdx.x;
+    if (lane_id() == 0) have[r] = 0;
+    const long long fl = full_len[r];
+    const int S = (int)(fl < m ? fl : m);
+    const long long a_e = bounds[(size_t)r * (1 + kmax)];
+    long long p_e = 0;
+    for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
+    if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return;
+    if ((long long)S < a_e + cfg.median_shift_window) return;
+    const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
+    const int n = b - a;
+    const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
+    if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) return;
+    if (n > cap || cfg.pA_var_window > MV_HIST || cfg.pA_mean_window > MV_HIST) return;
+    const float *x = sigs + (size_t)r * m + a;
+    float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
+    wave_move_series(x, n, cfg.pA_var_window, cfg.pA_mean_window, wvar, wmean, svar, smean, ws);
+    if (lane_id() == 0) have[r] = 1;
 }
 
 static __device__ void row_clear(adp_row *row)
@@ -540,6 +583,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
                 // several candidates, no prepared series: run the recurrences ONCE up to the largest candidate (they are
                 // causal: every other candidate's series is a prefix) into this slot's scratch
                 const float *own_mean = nullptr, *own_var = nullptr;
+                float shift_val = 0.f; bool shift_have = false;
                 if (p_series == 0 && !exception && !cfg.mvs_detect_overwrite && in.kmax > 1 && bd[1] != 0 && bd[2] != 0 && cfg.pA_var_window <= MV_HIST &&
                     cfg.pA_mean_window <= MV_HIST && cfg.pA_var_window >= 1 && cfg.pA_mean_window >= 1) {
                     long long pmx = 0;
@@ -574,9 +618,10 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
                         break;
                     }
                     const bool pre = p_series > 0 && p_e <= p_series;
-                    const float *pm = !pre ? nullptr : (own_mean ? own_mean : in.series + (size_t)r * 2 * MVS_CAP);
-                    const float *pv = !pre ? nullptr : (own_var ? own_var : in.series + (size_t)r * 2 * MVS_CAP + MVS_CAP);
-                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pv);
+                    const float *pm = !pre ? nullptr : (own_mean ? own_mean : in.series + (size_t)r * 2 * in.series_cap);
+                    const float *pv = !pre ? nullptr : (own_var ? own_var : in.series + (size_t)r * 2 * in.series_cap + in.series_cap);
+                    MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pv,
+                                         in.cstat ? in.cstat + (size_t)r * in.kmax + c : nullptr, shift_val, shift_have);
                     if (o.exc) { row_exception(row, o.exc); exception = true; break; }
                     rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
                     rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);

@@ -247,7 +247,7 @@ def main():
         spc.update_primary_method()
         from adapted_amd.detect import cnn as cnn_mod
 
-        cnn_model = cnn_mod.load_cnn_model(spc.cnn_boundaries.model_name, device=local)
+        cnn_model = None  # the weights named in the config, handed to the engine once (no PyTorch module involved)
     m = spc.sig_preload_size
     R, mb = args.reads, args.minibatch
     assert R % mb == 0, "--reads must be a whole number of minibatches"
@@ -280,11 +280,11 @@ def main():
     import threading
 
     def run_part(k):
-        if args.primary == "cnn":  # one call per minibatch: conv head in torch, pre/post in the HIP library
-            for s0 in range(k * Rs, (k + 1) * Rs, mb):
-                rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, mb,
-                                                  lens_host[s0:s0 + mb], cnn_model, spc)
-                engines[k].h2d(rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize, rows)
+        if args.primary == "cnn":  # one library call (adp_detect_cnn) per engine; find_peaks / row compaction per minibatch
+            s0 = k * Rs
+            rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs,
+                                              lens_host[s0:s0 + Rs], cnn_model, spc, minibatch=mb)
+            engines[k].h2d(rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize, rows)
             return
         engines[k].detect_llr_rows(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, mb,
                                    with_start_peak=not args.no_start_peak, device_ptrs=True,

@@ -251,3 +251,45 @@ def test_tails_nan_flag_skips_the_padding_without_changing_a_bit(oracle_mod):
         eng.dev_free(dsig)
         eng.dev_free(dlen)
         eng.close()
+
+
+def test_cnn_path_at_the_200k_window_vs_oracle(oracle_mod):
+    """BASELINE configs[2] at its size: the FULL CNN path (prepare -> hand-written conv stack -> predict -> the candidate
+    loop of validate_boundaries -> short-read fallback) at m = 201 500.  The shipped weights are off-distribution there:
+    most reads fail and run all 10 candidates over slices of up to ~190 k samples -- the shared-sweep statistics of
+    cand_stats.h.  The oracle validates the DEVICE's predictions (the conv stacks differ in summation order, so the
+    predictions themselves are pinned at the default window by the golden case): every field of every row identical."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+    from adapted_amd.detect import cnn
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.core.max_obs_trace = 200000
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    assert spc.primary_method == "cnn"
+    m = spc.sig_preload_size
+    n = 72
+    lens = np.array([m if i % 3 else synth.pareto_length(5, i) for i in range(n)], dtype=np.int32)
+    lens[5], lens[11], lens[17] = 9000, 12500, 1012  # short reads: the LLR fallback of combined.py:251-301
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+    eng.h2d(dlen, lens)
+    eng.synth_fill(dsig, dlen, n, seed=5, first_read=0)
+    sig = np.zeros((n, m), dtype=np.float32)
+    eng.d2h(sig, dsig)
+    cnn.ensure_weights(eng, None, spc)
+    _, bounds = eng.detect_cnn_rows(dsig, dlen, n, n, device_ptrs=True)
+    rows = cnn.detect_rows_device(eng, dsig, dlen, n, lens, None, spc)
+    got = lib.rows_to_results(rows, "cnn")
+    want = oracle_mod.detect_cnn_from_preds(sig, lens, bounds, spc)
+    bad = _rows_equal(got, want)
+    assert not bad, bad[:10]
+    n_all10 = sum(1 for b in bounds if (b[1:] != 0).all())
+    assert n_all10 > n // 4  # (the candidate loop is exercised)
+    # the same reads through host buffers and in two minibatches give the same rows where the minibatch split allows:
+    rows_h = cnn.detect_rows(eng, sig, lens, None, spc)
+    assert rows_h.tobytes() == rows.tobytes()
+    eng.dev_free(dsig)
+    eng.dev_free(dlen)
+    eng.close()
