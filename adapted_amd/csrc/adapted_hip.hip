@@ -905,10 +905,10 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
-        { Scope s(h, s0 ? nullptr : "k_cnn_conv_in");
+        { Scope s(h, "k_cnn_conv_in");
           hipLaunchKernelGGL(k_cnn_conv_in, dim3((L1 + 255) / 256, n), dim3(256), 0, h->stream, x, Lc, L1, Lpad, W + CNN_W0, W + CNN_B0, A); }
         for (int layer = 0; layer < 2; layer++) {
-            Scope s(h, s0 ? nullptr : (layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)"));
+            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
             const float *in = layer ? B : A; float *out = layer ? A : B;
             const float *w = W + (layer ? CNN_W2 : CNN_W1), *b = W + (layer ? CNN_B2 : CNN_B1);
             int rc = NT == 4 ? launch_conv64<4>(h, in, out, w, b, n, L1, Lpad, tiles)
@@ -916,7 +916,7 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
                              : launch_conv64<2>(h, in, out, w, b, n, L1, Lpad, tiles);
             if (rc) return rc;
         }
-        { Scope s(h, s0 ? nullptr : "k_cnn_conv_out");
+        { Scope s(h, "k_cnn_conv_out");
           hipLaunchKernelGGL(k_cnn_conv_out, dim3((L1 + 255) / 256, n), dim3(256), 0, h->stream, A, L1, Lpad, Lo, W + CNN_W3, W + CNN_B3, sc); }
     }
     return 0;

@@ -32,33 +32,74 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def make_spc(max_obs_trace: int):
+def make_spc(max_obs_trace: int, primary: str = "llr"):
     from adapted_amd.config import get_chemistry_specific_config
 
     spc = get_chemistry_specific_config("RNA004")
-    spc.llr_boundaries.llr_detect = True
-    spc.cnn_boundaries.cnn_detect = False
+    spc.llr_boundaries.llr_detect = primary == "llr"
+    spc.cnn_boundaries.cnn_detect = primary == "cnn"
     spc.core.max_obs_trace = max_obs_trace
     spc.update_primary_method()
     spc.update_sig_preload_size()
     return spc
 
 
-def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens=None):
-    """Time the CPU oracle (a single-threaded C port of the reference path) on the first
-    n_sample reads of the resident batch, as ONE minibatch, and check the GPU rows of an
-    identically composed minibatch against it."""
+# ---------------------------------------------------------------------------------------------- CPU baseline (the checker, timed)
+def _cpu_worker(task):
+    """one minibatch through the CPU oracle in a worker PROCESS (the reference's layout: adapted/file_proc.py:738-784)"""
+    shm_name, off, n, m, max_obs_trace = task
+    from multiprocessing import shared_memory
+
+    from oracle import oracle
+
+    oracle.lib()
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        sig = np.ndarray((n, m), dtype=np.float32, buffer=shm.buf, offset=off)
+        lens = np.full(n, m, dtype=np.int32)
+        spc = make_spc(max_obs_trace)
+        t0 = time.perf_counter()
+        res = oracle.detect_llr(sig, lens, spc, with_start_peak=True)
+        dt = time.perf_counter() - t0
+        return dt, sum(bool(r["success"]) for r in res)
+    finally:
+        shm.close()
+
+
+def _cpu_pool_start(procs: int):
+    """worker processes for the all-cores baseline, started BEFORE this process touches the GPU (spawned, not forked)"""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    pool = ctx.Pool(procs)
+    pool.map(_cpu_noop, range(procs))  # (workers up, modules imported)
+    return pool
+
+
+def _cpu_noop(i):
+    from oracle import oracle
+
+    oracle.lib()
+    return i
+
+
+def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens, pool, procs: int, n_all: int, max_obs_trace: int):
+    """Time the CPU oracle (a C port of the reference path, oracle/adapted_oracle.c) on the first minibatches of the resident
+    batch: ONE thread on n_sample reads (checked against the GPU rows of an identically composed minibatch), then `procs`
+    worker processes with one minibatch of n_all reads each, the reference's own process layout.  The port / reference
+    ratio measured in the build container (tools/time_reference.py -> profiles/r02_reference_timing.json) turns both into
+    reference-equivalent figures (the reference cannot travel to the GPU box)."""
     from adapted_amd import lib
     from oracle import oracle
 
     oracle.lib()
     sig = np.zeros((n_sample, m), dtype=np.float32)
     eng.d2h(sig, dsig)
-    lens = np.full(n_sample, m, dtype=np.int32) if lens is None else np.ascontiguousarray(lens[:n_sample], dtype=np.int32)
+    lens1 = np.ascontiguousarray(lens[:n_sample], dtype=np.int32)
     t0 = time.perf_counter()
-    want = oracle.detect_llr(sig, lens, spc, with_start_peak=True)
+    want = oracle.detect_llr(sig, lens1, spc, with_start_peak=True)
     dt = time.perf_counter() - t0
-    rows, _ = eng.detect_llr_rows(sig, lens, n_sample, n_sample, with_start_peak=True)
+    rows, _ = eng.detect_llr_rows(sig, lens1, n_sample, n_sample, with_start_peak=True)
     got = lib.rows_to_results(rows, "llr")
     mism = 0
     for g, w in zip(got, want):
@@ -73,10 +114,41 @@ def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens=None):
                     mism += 1
             elif a != v:
                 mism += 1
-    return {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "%d reads (one minibatch) of the same synthetic workload, oracle/adapted_oracle.c, "
-                      "1 thread, %.1f s; GPU rows of the same minibatch differ from it in %d fields"
-                      % (n_sample, dt, mism)}
+    out = {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+           "sample": "%d reads (one minibatch) of the same synthetic workload, oracle/adapted_oracle.c, 1 thread, %.1f s; "
+                     "GPU rows of the same minibatch differ from it in %d fields" % (n_sample, dt, mism),
+           "host_cpus": os.cpu_count()}
+    del sig
+    if pool is not None and procs > 1:
+        from multiprocessing import shared_memory
+
+        shm = shared_memory.SharedMemory(create=True, size=procs * n_all * m * 4)
+        try:
+            for k in range(procs):  # minibatch k of the resident batch -> worker k
+                blk = np.ndarray((n_all, m), dtype=np.float32, buffer=shm.buf, offset=k * n_all * m * 4)
+                eng.d2h(blk, dsig + k * n_all * m * 4)
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_worker, [(shm.name, k * n_all * m * 4, n_all, m, max_obs_trace) for k in range(procs)])
+            wall = time.perf_counter() - t0
+        finally:
+            shm.close()
+            shm.unlink()
+        out["cores_all"] = procs
+        out["value_all_cores"] = procs * n_all / wall
+        out["sample_all_cores"] = ("%d worker processes x one minibatch of %d reads each (the reference's layout, adapted/file_proc.py:738-784), "
+                                   "%.1f s wall, slowest worker %.1f s" % (procs, n_all, wall, max(d for d, _ in res)))
+    tfile = os.path.join(ROOT, "profiles", "r02_reference_timing.json")
+    if os.path.exists(tfile):
+        with open(tfile) as fh:
+            t = json.load(fh)
+        rp, ra = t["port_over_reference_per_proc"], t["port_over_reference_all_procs"]
+        out["port_over_reference"] = {"per_process": rp, "all_processes": ra,
+                                      "source": "profiles/r02_reference_timing.json (tools/time_reference.py: the real reference beside "
+                                                "the port, %d processes, build container)" % t["reference_all_procs"]["procs"]}
+        out["reference_equivalent"] = {"per_core": out["value"] / rp, "unit": "reads/s"}
+        if "value_all_cores" in out:
+            out["reference_equivalent"]["all_cores"] = out["value_all_cores"] / ra
+    return out
 
 
 def host_pipeline_bench(args, spc, device):
@@ -181,114 +253,62 @@ def host_pipeline_bench(args, spc, device):
                       "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}}))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=96000,
-                    help="reads per step per GPU (whole minibatches); 96 000 x 806 KB = 77 GB of signal + ~55 GB of workspace in the 288 GB HBM")
-    ap.add_argument("--minibatch", type=int, default=1000)
-    ap.add_argument("--max_obs_trace", type=int, default=200000)
-    ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle (rank 0, N=1)")
-    ap.add_argument("--lens", choices=["full", "pareto"], default="full",
-                    help="read lengths: full (the headline workload: every read fills the window) or pareto (BASELINE configs[4]: "
-                         "Pareto(1.2) clipped to [10k, 1M] samples -- most reads much shorter than the window, NaN padded; a probe)")
-    ap.add_argument("--ragged", action="store_true", help="with --host-pipeline: reads packed back to back in the staging slots, "
-                                                          "the padded matrix laid out on the device (adp_expand_ragged)")
-    ap.add_argument("--adc-step", type=float, default=0.0,
-                    help="(robustness probe, not the headline workload) round the synthetic samples to multiples of this many pA, "
-                         "like calibrated int16 ADC data (~0.18 pA): exercises the tie handling of the exact selections")
-    ap.add_argument("--no-start-peak", action="store_true")
-    ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--primary", choices=["llr", "cnn"], default="llr",
-                    help="llr: BASELINE configs[1] (default); cnn: configs[2] (PyTorch-ROCm conv head, per-minibatch calls)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
-    ap.add_argument("--host-pipeline", type=int, default=0, metavar="N",
-                    help="instead of the resident benchmark: stream N minibatches from HOST memory through adapted_amd.pipeline "
-                         "(pinned staging, H2D overlapped with detect) and print the PCIe-inclusive rate -- never the headline value")
-    ap.add_argument("--group", type=int, default=4, help="with --host-pipeline: minibatches per staging slot / detect call")
-    ap.add_argument("--fill-threads", type=int, default=1, help="with --host-pipeline: host threads copying a slot's reads (the stand-in reader)")
-    ap.add_argument("--int16", action="store_true", help="with --host-pipeline: stream raw int16 ADC samples and calibrate on the device")
-    args = ap.parse_args()
+CNN_FLOP_PER_POS = 2.0 * (64 * 7 + 2 * 64 * 64 * 7 + 64 * 2 * 7)  # F_alg = this x L1 per read
+F32_MFMA_PEAK_TF = 157.3  # MI355X float32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=0):
+    """One workload (w: argparse-like namespace) on this rank's GPU; rank 0 returns the JSON object, the others None."""
+    import threading
 
     import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
-    dist = None
-    # ADP_BENCH_BACKEND=gloo rehearses the N > 1 code path on fewer GPUs than ranks (ranks share devices, the row gather
-    # goes through host memory); the real multi-GPU run uses RCCL ("nccl"), one GPU per rank
-    backend = os.environ.get("ADP_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        import torch.distributed as dist
-
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    comm_dev = dev if backend == "nccl" else torch.device("cpu")
-
     from adapted_amd import lib
 
-    spc = make_spc(args.max_obs_trace)
-    if args.host_pipeline > 0:
-        return host_pipeline_bench(args, spc, local)
-    if args.primary == "cnn":
-        spc.llr_boundaries.llr_detect = False
-        spc.cnn_boundaries.cnn_detect = True
-        spc.update_primary_method()
+    dev = torch.device("cuda", local)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
+    spc = make_spc(w.max_obs_trace, w.primary)
+    cnn_mod = None
+    if w.primary == "cnn":
         from adapted_amd.detect import cnn as cnn_mod
-
-        cnn_model = None  # the weights named in the config, handed to the engine once (no PyTorch module involved)
     m = spc.sig_preload_size
-    R, mb = args.reads, args.minibatch
+    R, mb = w.reads, w.minibatch
     assert R % mb == 0, "--reads must be a whole number of minibatches"
-    NS = max(1, args.streams)
+    NS = max(1, w.streams)
     assert (R // mb) % NS == 0, "--reads must split into whole minibatches per stream"
     Rs = R // NS
     engines = [lib.Engine(spc, Rs, m, device=local) for _ in range(NS)]
     eng = engines[0]
     sig_t = torch.empty((R, m), dtype=torch.float32, device=dev)
     lens_host = np.full(R, m, dtype=np.int32)
-    if args.lens == "pareto":
+    if w.lens == "pareto":
         from adapted_amd import synth as _synth
 
-        lens_host = np.array([_synth.pareto_length(args.seed, rank * R + i) for i in range(R)], dtype=np.int32)
+        lens_host = np.array([_synth.pareto_length(w.seed, rank * R + i) for i in range(R)], dtype=np.int32)
     len_t = torch.from_numpy(lens_host).to(dev)
     rows_t = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     # rank r owns reads [r*R, (r+1)*R) of the global stream: contiguous whole minibatches
     for k, e in enumerate(engines):
-        e.synth_fill(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, seed=args.seed,
+        e.synth_fill(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, seed=w.seed,
                      first_read=rank * R + k * Rs, decorate=True)
-    if args.adc_step > 0:
+    if w.adc_step > 0:
         for s0 in range(0, R, 1000):
-            sig_t[s0:s0 + 1000].div_(args.adc_step).round_().mul_(args.adc_step)
+            sig_t[s0:s0 + 1000].div_(w.adc_step).round_().mul_(w.adc_step)
         torch.cuda.synchronize()
     gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
 
-    import threading
-
     def run_part(k):
-        if args.primary == "cnn":  # one library call (adp_detect_cnn) per engine; find_peaks / row compaction per minibatch
-            s0 = k * Rs
+        s0 = k * Rs
+        if w.primary == "cnn":  # one library call (adp_detect_cnn) per engine; find_peaks / row compaction per minibatch
             rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs,
-                                              lens_host[s0:s0 + Rs], cnn_model, spc, minibatch=mb)
+                                              lens_host[s0:s0 + Rs], None, spc, minibatch=mb)
             engines[k].h2d(rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize, rows)
             return
-        engines[k].detect_llr_rows(sig_t.data_ptr() + k * Rs * m * 4, len_t.data_ptr() + k * Rs * 4, Rs, mb,
-                                   with_start_peak=not args.no_start_peak, device_ptrs=True,
-                                   rows_dev=rows_t.data_ptr() + k * Rs * lib.ROW_DTYPE.itemsize,
+        engines[k].detect_llr_rows(sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs, mb,
+                                   with_start_peak=not w.no_start_peak, device_ptrs=True,
+                                   rows_dev=rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize,
                                    tails_nan=True)  # (the generator pads with NaN; no padding at all in the headline workload)
 
     def step():
@@ -308,17 +328,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(w.warmup):
         step()
     for e in engines:
         e.set_profiling(True)
     ktimes = {}
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(w.steps):
         step()
         for e in engines:
-            for name, ms in e.kernel_times():  # HIP events recorded on each engine's stream
+            per = {}
+            for name, ms in e.kernel_times():  # HIP events recorded on each engine's stream; one entry per launch
+                per[name] = per.get(name, 0.0) + ms
+            for name, ms in per.items():
                 ktimes.setdefault(name, []).append(ms)
     sync()
     dt = time.perf_counter() - t0
@@ -328,62 +351,216 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_reads = R * world * args.steps
+    total_reads = R * world * w.steps
     value = total_reads / dt
-
+    out = None
     if rank == 0:
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tfile):
-            with open(tfile) as fh:
-                traffic = json.load(fh)
+        for tname in ("r02_traffic.json", "r01_traffic.json"):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tfile):
+                with open(tfile) as fh:
+                    traffic = json.load(fh)
+                traffic["_file"] = "profiles/" + tname
+                break
         rows = np.zeros(R, dtype=lib.ROW_DTYPE)
         eng.d2h(rows, rows_t.data_ptr())
         n_ok = int(rows["success"].sum())
-        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()} or {"(torch conv stack + host top-k)": dt / args.steps * 1e3}
+        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
         dom = max(kavg, key=kavg.get)
-        b_alg = 4.0 * m * Rs  # 4*m input bytes per read, each launch covers Rs reads
+        # 4 bytes per PRELOADED sample, each read once; a launch covers the Rs reads of one engine
+        mean_samples = float(np.minimum(lens_host, m).mean())
+        b_alg = 4.0 * mean_samples * Rs
         achieved = b_alg / (kavg[dom] * 1e-3) / 1e9
-        ksum = sum(kavg.values())
+        step_s = dt / w.steps
         out = {
             "metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 samples/statistics, f64 cumulative sums + LLR trace", "data": "synthetic (device-generated, adapted_amd/synth.py twin)",
-            "config": {"workload": ("BASELINE configs[1]: RNA004 LLR + start_peak + validate" if args.primary == "llr" else
-                                    "BASELINE configs[2]: RNA004 CNN head (PyTorch-ROCm fp32) + validate") +
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": w.steps, "warmup": w.warmup,
+            "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 samples/statistics, f64 cumulative sums + LLR trace" if w.primary == "llr" else "f32 (conv net on the float32 matrix cores, statistics)",
+            "data": "synthetic (device-generated, adapted_amd/synth.py twin)",
+            "config": {"workload": ("BASELINE configs[1]: RNA004 LLR + start_peak + validate" if w.primary == "llr" else
+                                    "BASELINE configs[2]: RNA004 CNN head (hand-written float32 MFMA conv stack) + predict + validate") +
                                    ", max_obs_trace=%d (m=%d), minibatch=%d, %d reads/step/GPU resident in HBM"
-                                   % (args.max_obs_trace, m, mb, R),
+                                   % (w.max_obs_trace, m, mb, R),
                        "reads_per_step_per_gpu": R, "minibatch": mb, "m": m, "pass_rate": n_ok / R, "streams_per_gpu": NS},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic.get(dom, {}).get("hbm_bytes") * (Rs / traffic["_reads_per_launch"])
-                                     if traffic and dom in traffic else None),
-                         "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc, FETCH_SIZE doubled per MI355X_MICROARCH.md)",
+                                     if traffic and dom in traffic and w.lens == "full" and w.primary == "llr" else None),
+                         "traffic_source": (traffic["_file"] + " (rocprofv3 --pmc, FETCH_SIZE doubled per MI355X_MICROARCH.md)") if traffic else None,
                          "kernel_ms": kavg[dom], "algorithmic_bytes_per_launch": b_alg,
-                         "whole_path_frac": (4.0 * m * R / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS},
+                         "whole_path_frac": (4.0 * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
-            "kernel_ms_sum": ksum,
+            "kernel_ms_sum": sum(kavg.values()),
         }
-        if args.lens != "full":
+        if w.primary == "cnn":
+            # configs[2] is a dense contraction: the float32 matrix peak bounds the conv stack
+            Lc = (m - spc.core.min_obs_adapter + spc.core.downscale_factor - 1) // spc.core.downscale_factor
+            L1 = (Lc - 1) // 3 + 1
+            f_alg = CNN_FLOP_PER_POS * L1 * Rs
+            conv_ms = sum(v for k, v in kavg.items() if k.startswith("k_cnn_conv"))
+            out["roofline"] = {"bound": "mfma", "dtype": "f32", "kernel": "conv stack (k_cnn_conv_in + k_cnn_conv64 x 2 + k_cnn_conv_out)",
+                               "achieved": f_alg / (conv_ms * 1e-3) / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": f_alg / (conv_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF, "traffic": None,
+                               "kernel_ms": conv_ms, "algorithmic_flop_per_launch": f_alg,
+                               "whole_path_frac": CNN_FLOP_PER_POS * L1 * R / step_s / 1e12 / F32_MFMA_PEAK_TF,
+                               "whole_path_hbm_frac": (4.0 * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS,
+                               "slowest_kernel": dom, "slowest_kernel_ms": kavg[dom]}
+        if w.lens != "full":
             out["config"]["lens"] = "%s: mean %.0f samples of m = %d preloaded (%.0f %% of the matrix is NaN padding)" % (
-                args.lens, float(np.minimum(lens_host, m).mean()), m, 100.0 * (1.0 - float(np.minimum(lens_host, m).mean()) / m))
-        if args.adc_step > 0 or args.lens != "full":
+                w.lens, mean_samples, m, 100.0 * (1.0 - mean_samples / m))
+        if w.adc_step > 0 or w.lens != "full":
             c = eng.debug_counters(24)  # k_partition_stats tallies over the large segments (cumulative over all steps)
-            if args.adc_step > 0:
-                out["config"]["adc_step_pa"] = args.adc_step
+            if w.adc_step > 0:
+                out["config"]["adc_step_pa"] = w.adc_step
             out["partition_paths"] = {"large_segments": int(c[0]), "mad_proven_in_bracket": int(c[1]), "median_generic_select": int(c[2]),
                                       "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
                                       "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7]),
-                                      "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23]), "n1_dbg": [int(c[19]), int(c[18]), int(c[17]), int(c[6]), int(c[7])]}
-        if world == 1 and args.cpu_sample > 0 and args.primary == "llr":
-            n_s = min(args.cpu_sample, R)
-            out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows, lens_host)
+                                      "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23])}
+        if world == 1 and w.cpu_sample > 0 and w.primary == "llr" and w.lens == "full" and w.adc_step == 0:
+            n_s = min(w.cpu_sample, R)
+            n_all = min(w.cpu_sample_all, R // max(cpu_procs, 1)) if cpu_procs > 1 else 0
+            out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows, lens_host, cpu_pool, cpu_procs if n_all > 0 else 0,
+                                               n_all, w.max_obs_trace)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
     for e in engines:
         e.close()
+    del sig_t, rows_t, len_t
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, as a CHILD process (this
+    process never touches the GPU), relay rank 0's JSON line and exit with the child's code."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line is not None:
+        print(line)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=None,
+                    help="reads per step per GPU (whole minibatches); default 96 000 (LLR: 96 000 x 806 KB = 77 GB of signal + ~55 GB of "
+                         "workspace in the 288 GB HBM) or 4 000 (CNN at the 200 k window) / 32 000 (CNN, shorter windows)")
+    ap.add_argument("--minibatch", type=int, default=1000)
+    ap.add_argument("--max_obs_trace", type=int, default=200000)
+    ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle, one thread (rank 0, N=1)")
+    ap.add_argument("--cpu-sample-all", type=int, default=500, help="reads per worker process of the all-cores CPU baseline")
+    ap.add_argument("--cpu-procs", type=int, default=None, help="worker processes of the all-cores CPU baseline (default: the host's cores, at most 16)")
+    ap.add_argument("--lens", choices=["full", "pareto"], default="full",
+                    help="read lengths: full (the headline workload: every read fills the window) or pareto (BASELINE configs[4]: "
+                         "Pareto(1.2) clipped to [10k, 1M] samples -- most reads much shorter than the window, NaN padded; a probe)")
+    ap.add_argument("--ragged", action="store_true", help="with --host-pipeline: reads packed back to back in the staging slots, "
+                                                          "the padded matrix laid out on the device (adp_expand_ragged)")
+    ap.add_argument("--adc-step", type=float, default=0.0,
+                    help="(robustness probe, not the headline workload) round the synthetic samples to multiples of this many pA, "
+                         "like calibrated int16 ADC data (~0.18 pA): exercises the tie handling of the exact selections")
+    ap.add_argument("--no-start-peak", action="store_true")
+    ap.add_argument("--seed", type=int, default=2024)
+    ap.add_argument("--primary", choices=["llr", "cnn"], default="llr",
+                    help="llr: BASELINE configs[1] (default, the headline); cnn: configs[2] (hand-written conv head)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary workloads (configs[2] at the 200 k and the default window, configs[4]'s Pareto lengths) that a "
+                         "default 1-GPU run attaches to its JSON line")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
+    ap.add_argument("--host-pipeline", type=int, default=0, metavar="N",
+                    help="instead of the resident benchmark: stream N minibatches from HOST memory through adapted_amd.pipeline "
+                         "(pinned staging, H2D overlapped with detect) and print the PCIe-inclusive rate -- never the headline value")
+    ap.add_argument("--group", type=int, default=4, help="with --host-pipeline: minibatches per staging slot / detect call")
+    ap.add_argument("--fill-threads", type=int, default=1, help="with --host-pipeline: host threads copying a slot's reads (the stand-in reader)")
+    ap.add_argument("--int16", action="store_true", help="with --host-pipeline: stream raw int16 ADC samples and calibrate on the device")
+    args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "0"))
+    if args.gpus > 1 and world_env == 0:  # no launcher around us: be the launcher (before anything touches the GPU)
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", "0"))
+    world = max(world_env, 1)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d" % (args.gpus, world))
+    if args.reads is None:
+        args.reads = 96000 if args.primary == "llr" else (4000 if args.max_obs_trace > 32000 else 32000)
+    default_run = (args.primary == "llr" and args.lens == "full" and args.adc_step == 0 and args.host_pipeline == 0 and
+                   args.max_obs_trace == 200000 and not args.no_start_peak)
+
+    # the all-cores CPU baseline runs in worker processes: start them before this process initialises the GPU
+    cpu_pool, cpu_procs = None, 0
+    if world == 1 and args.cpu_sample > 0 and args.cpu_sample_all > 0 and default_run:
+        cpu_procs = args.cpu_procs or min(len(os.sched_getaffinity(0)), 16)
+        if cpu_procs > 1:
+            cpu_pool = _cpu_pool_start(cpu_procs)
+
+    import torch
+
+    dist = None
+    # ADP_BENCH_BACKEND=gloo rehearses the N > 1 code path on fewer GPUs than ranks (ranks share devices, the row gather
+    # goes through host memory); the real multi-GPU run uses RCCL ("nccl"), one GPU per rank
+    backend = os.environ.get("ADP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks but only %d device(s) visible" % (world, ndev))
+    if backend != "nccl":
+        local = local % max(ndev, 1)
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.host_pipeline > 0:
+        return host_pipeline_bench(args, make_spc(args.max_obs_trace), local)
+    out = run_workload(args, rank, world, local, dist, backend, cpu_pool, cpu_procs)
+    if cpu_pool is not None:
+        cpu_pool.close()
+        cpu_pool.join()
+    if rank == 0 and world == 1 and default_run and not args.no_secondary:
+        # the other single-GPU configurations of BASELINE.json, driver-run with the headline (each its own roofline)
+        sec = {}
+        for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=4000, steps=4, warmup=1)),
+                         ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
+                         ("pareto", dict(lens="pareto", steps=4, warmup=1))):
+            w = argparse.Namespace(**vars(args))
+            w.cpu_sample = 0
+            for k, v in kw.items():
+                setattr(w, k, v)
+            o = run_workload(w, 0, 1, local, None, backend)
+            sec[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "kernel_ms")}
+        out["secondary"] = sec
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
