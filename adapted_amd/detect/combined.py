@@ -17,7 +17,10 @@ import numpy as np
 from .. import lib
 from ..container_types import Boundaries, DetectResults
 
-_ENGINES: Dict[Tuple, "lib.Engine"] = {}
+from collections import OrderedDict
+
+_ENGINES: "OrderedDict[Tuple, lib.Engine]" = OrderedDict()
+_MAX_ENGINES = 6  # each holds streams, events and workspace: the cache is bounded, least recently used first out
 
 
 def _cfg_key(spc) -> bytes:
@@ -29,10 +32,13 @@ def get_engine(spc, n: int, m: int, device: int = 0) -> "lib.Engine":
     key = (_cfg_key(spc), int(m), int(device))
     eng = _ENGINES.get(key)
     if eng is None or eng.max_reads < n:
-        if eng is not None:
-            eng.close()
+        # (a smaller engine is only dropped from the cache, not closed: a caller may still hold it; it closes itself
+        # when the last reference goes)
         eng = lib.Engine(spc, max(int(n), 1), int(m), device=device)
         _ENGINES[key] = eng
+    _ENGINES.move_to_end(key)
+    while len(_ENGINES) > _MAX_ENGINES:
+        _ENGINES.popitem(last=False)
     return eng
 
 
@@ -117,10 +123,16 @@ def combined_detect_start_peak(batch_of_signals: np.ndarray, full_signal_lens: n
 
 def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_signal_len: int,
                         device: int = 0) -> DetectResults:
-    """Single-read validator (the reference calls it with ``signal[:full_signal_len]``)."""
-    sig = np.ascontiguousarray(signal, dtype=np.float32).reshape(1, -1)
-    m = sig.shape[1]
+    """Single-read validator (the reference calls it with ``signal[:full_signal_len]``, i.e. with min(full_signal_len,
+    sig_preload_size) samples).  The row is NaN-padded to ONE engine width per configuration (the preload size; longer
+    arrays to the next multiple of 16 384), so that looping over reads of different lengths reuses one engine."""
+    x = np.ascontiguousarray(signal, dtype=np.float32).reshape(-1)
+    have = x.size
+    m = int(spc.sig_preload_size) if have <= int(spc.sig_preload_size) else -(-have // 16384) * 16384
+    sig = np.full((1, m), np.nan, dtype=np.float32)
+    sig[0, :have] = x
     eng = get_engine(spc, 1, m, device)
+    eff_len = int(full_signal_len) if have >= min(int(full_signal_len), m) else have  # (an array shorter than the read: what is there)
     topk = boundaries.polya_end_topk
     none = topk is None
     cands = [int(boundaries.polya_end or 0)] if none else [int(x) for x in np.asarray(topk).ravel()]
@@ -129,7 +141,9 @@ def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_si
     b[0, 1:1 + len(cands)] = cands
     if not none and len(cands) and cands[0] != int(boundaries.polya_end or 0):
         raise ValueError("polya_end_topk[0] must equal polya_end")
-    rows = eng.validate_rows(sig, np.array([full_signal_len], dtype=np.int32), 1, b, topk_none=none)
+    rows = eng.validate_rows(sig, np.array([eff_len], dtype=np.int32), 1, b, topk_none=none)
+    if eff_len != int(full_signal_len) and int(rows[0]["present"]) & 1:
+        rows[0]["col"][0] = float(full_signal_len)  # signal_len reports the read's true length
     return lib.rows_to_results(rows, spc.primary_method)[0]
 
 

@@ -40,8 +40,30 @@ def input_to_filelist(inputs: Iterable[str], endswiths=EXTS) -> List[str]:
     return sorted(files, key=_num_suffix_key)
 
 
+class GroupSharder:
+    """Which rank owns which GROUP of reads (a group = one staging slot = a whole number of minibatches, so that the
+    minibatch membership -- the unit of the LLR path's normalisation -- is the same for any number of GPUs).  Every rank
+    walks the same stream of read METADATA (id, length) and only decodes the signals of its own groups.  A group goes
+    to the rank with the fewest preloaded samples so far (balance by preloaded samples, in whole
+    minibatches; ties to the lowest rank), which every rank computes identically from the metadata alone."""
+
+    def __init__(self, world_size: int, rank: int, preload_size: int):
+        self.ws, self.rank, self.m = int(world_size), int(rank), int(preload_size)
+        self.load = [0] * self.ws
+        self.owner = 0
+        self.groups = 0
+
+    def start_group(self) -> bool:
+        self.owner = min(range(self.ws), key=lambda r: (self.load[r], r))
+        self.groups += 1
+        return self.owner == self.rank
+
+    def add(self, n_samples: int):
+        self.load[self.owner] += max(0, min(int(n_samples), self.m))
+
+
 def _iter_reads(filename: str, selection: Optional[List[str]]):
-    """yield (read_id, n_samples, signal_pa[:] accessor)"""
+    """yield (read_id, n_samples, get) -- get() decodes and returns the pA signal; reads nobody asks for cost nothing"""
     if filename.endswith(".npz"):
         z = np.load(filename, allow_pickle=True)
         ids = [str(x) for x in z["read_ids"]]
@@ -51,8 +73,7 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
         for i, rid in enumerate(ids):
             if sel is not None and rid not in sel:
                 continue
-            sig = dense[i] if dense is not None else z["signal_%d" % i]
-            yield rid, int(lens[i]), sig
+            yield rid, int(lens[i]), (lambda i=i: dense[i] if dense is not None else z["signal_%d" % i])
     else:
         try:
             from pod5 import Reader
@@ -60,7 +81,7 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
             raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
         with Reader(filename) as fh:
             for rec in fh.reads(selection=selection, missing_ok=True):
-                yield str(rec.read_id), int(rec.num_samples), rec.signal_pa
+                yield str(rec.read_id), int(rec.num_samples), (lambda rec=rec: rec.signal_pa)
 
 
 def _copy_pool(workers: Optional[int]):
@@ -74,9 +95,12 @@ def _copy_pool(workers: Optional[int]):
 
 
 def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                      preload_size: int, buffers=None, workers: Optional[int] = None
+                      preload_size: int, buffers=None, workers: Optional[int] = None, sharder: Optional[GroupSharder] = None,
+                      ordinals: Optional[list] = None
                       ) -> Generator[Tuple[np.ndarray, np.ndarray, np.ndarray], None, None]:
-    """buffers: optional callable returning (signals float32 [batch_size, preload_size], lengths int32 [batch_size]) to
+    """sharder: only the groups (minibatches of this call) it assigns to this rank are decoded and yielded.
+    ordinals: a list that receives, per yielded minibatch, the stream index of its first read (stream order of the output).
+    buffers: optional callable returning (signals float32 [batch_size, preload_size], lengths int32 [batch_size]) to
     fill IN PLACE for the next minibatch (pinned staging memory of adapted_amd.pipeline); called when the first read of
     a minibatch arrives, never while the previous minibatch's arrays may still be in use by the consumer of the yield."""
     if read_ids_incl and read_ids_excl:
@@ -109,27 +133,40 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
 
     sig = lens = ids = None
     k = 0
+    g = 0  # stream index of the next read (after the id filters)
+    mine = True
     try:
         for fn in files:
-            for rid, n_samples, signal in _iter_reads(fn, selection):
+            for rid, n_samples, get in _iter_reads(fn, selection):
                 if rid in read_ids_excl:
                     continue
-                if sig is None:
-                    sig, lens, ids = fresh()
-                if pool is not None:
-                    pending.append(pool.submit(put_row, sig[k], signal, n_samples))
-                else:
-                    put_row(sig[k], signal, n_samples)
-                lens[k] = n_samples
-                ids[k] = rid
+                if k == 0 and sharder is not None:
+                    mine = sharder.start_group()
+                if sharder is not None:
+                    sharder.add(n_samples)
+                if mine:
+                    if sig is None:
+                        sig, lens, ids = fresh()
+                    if pool is not None:
+                        pending.append(pool.submit(lambda d, gt, ns: put_row(d, gt(), ns), sig[k], get, n_samples))
+                    else:
+                        put_row(sig[k], get(), n_samples)
+                    lens[k] = n_samples
+                    ids[k] = rid
                 k += 1
+                g += 1
                 if k == N:
-                    finish()
-                    yield sig, lens, ids
+                    if mine:
+                        finish()
+                        if ordinals is not None:
+                            ordinals.append(g - k)
+                        yield sig, lens, ids
                     sig = None
                     k = 0
-        if k:
+        if k and mine:
             finish()
+            if ordinals is not None:
+                ordinals.append(g - k)
             yield sig[:k], lens[:k], ids[:k]
     finally:
         if pool is not None:
@@ -137,7 +174,7 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
 
 
 def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
-    """yield (read_id, n_samples, int16 signal accessor, scale, offset)"""
+    """yield (read_id, n_samples, get, scale, offset) -- get() returns the raw int16 samples"""
     if filename.endswith(".npz"):
         z = np.load(filename, allow_pickle=True)
         if "raw" not in z and "raw_0" not in z:
@@ -149,8 +186,7 @@ def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
         for i, rid in enumerate(ids):
             if sel is not None and rid not in sel:
                 continue
-            sig = dense[i] if dense is not None else z["raw_%d" % i]
-            yield rid, int(lens[i]), sig, float(scale[i]), float(offset[i])
+            yield rid, int(lens[i]), (lambda i=i: dense[i] if dense is not None else z["raw_%d" % i]), float(scale[i]), float(offset[i])
     else:
         try:
             from pod5 import Reader
@@ -158,11 +194,13 @@ def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
             raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
         with Reader(filename) as fh:
             for rec in fh.reads(selection=selection, missing_ok=True):
-                yield str(rec.read_id), int(rec.num_samples), rec.signal, float(rec.calibration.scale), float(rec.calibration.offset)
+                yield (str(rec.read_id), int(rec.num_samples), (lambda rec=rec: rec.signal), float(rec.calibration.scale),
+                       float(rec.calibration.offset))
 
 
 def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                          preload_size: int, buffers=None, workers: Optional[int] = None):
+                          preload_size: int, buffers=None, workers: Optional[int] = None, sharder: Optional[GroupSharder] = None,
+                          ordinals: Optional[list] = None):
     """Raw-ADC twin of yield_minibatches for the int16 ingestion path (adapted_amd.pipeline, int16_input=True):
     yields (raw int16 [n, preload_size] -- the tail of a short read is left untouched, the device writes NaN there --,
     lengths int32, scale float32, offset float32, ids).  pA = scale * (float32(adc) + offset) is applied on the device."""
@@ -196,28 +234,41 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
 
     cur = None
     k = 0
+    g = 0
+    mine = True
     try:
         for fn in files:
-            for rid, n_samples, signal, scale, offset in _iter_reads_i16(fn, selection):
+            for rid, n_samples, get, scale, offset in _iter_reads_i16(fn, selection):
                 if rid in read_ids_excl:
                     continue
-                if cur is None:
-                    cur = fresh()
-                raw, lens, sc, of, ids = cur
-                if pool is not None:
-                    pending.append(pool.submit(put_row, raw[k], signal, n_samples, rid))
-                else:
-                    put_row(raw[k], signal, n_samples, rid)
-                lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
+                if k == 0 and sharder is not None:
+                    mine = sharder.start_group()
+                if sharder is not None:
+                    sharder.add(n_samples)
+                if mine:
+                    if cur is None:
+                        cur = fresh()
+                    raw, lens, sc, of, ids = cur
+                    if pool is not None:
+                        pending.append(pool.submit(lambda d, gt, ns, r: put_row(d, gt(), ns, r), raw[k], get, n_samples, rid))
+                    else:
+                        put_row(raw[k], get(), n_samples, rid)
+                    lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
                 k += 1
+                g += 1
                 if k == N:
-                    finish()
-                    yield raw, lens, sc, of, ids
+                    if mine:
+                        finish()
+                        if ordinals is not None:
+                            ordinals.append(g - k)
+                        yield raw, lens, sc, of, ids
                     cur = None
                     k = 0
-        if k:
+        if k and mine:
             finish()
             raw, lens, sc, of, ids = cur
+            if ordinals is not None:
+                ordinals.append(g - k)
             yield raw[:k], lens[:k], sc[:k], of[:k], ids[:k]
     finally:
         if pool is not None:
@@ -225,7 +276,8 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
 
 
 def yield_minibatches_packed(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
-                             preload_size: int, buffers, int16: bool = False, workers: Optional[int] = None):
+                             preload_size: int, buffers, int16: bool = False, workers: Optional[int] = None,
+                             sharder: Optional[GroupSharder] = None, ordinals: Optional[list] = None):
     """The reads of a minibatch packed back to back, for the ragged ingestion of adapted_amd.pipeline (ragged=True): fills
     the buffers handed out by `buffers()` -- (flat, lengths int32 [N], offsets int64 [N + 1]) plus (scale, offset) float32
     [N] when int16 -- with each read's first min(length, preload_size) samples at flat[offsets[k] : offsets[k + 1]] and
@@ -251,36 +303,50 @@ def yield_minibatches_packed(files: Iterable[str], read_ids_incl: Set[str], read
         pending.clear()
 
     cur = None
+    ids = None
     k = 0
+    g = 0
+    mine = True
     it = _iter_reads_i16 if int16 else (lambda fn, sel: ((r, n, s, None, None) for r, n, s in _iter_reads(fn, sel)))
     try:
         for fn in files:
-            for rid, n_samples, signal, scale, offset in it(fn, selection):
+            for rid, n_samples, get, scale, offset in it(fn, selection):
                 if rid in read_ids_excl:
                     continue
-                if cur is None:
-                    cur = buffers()
-                    ids = np.empty(N, dtype=object)
-                    cur[2][0] = 0
-                flat, lens, offs = cur[0], cur[1], cur[2]
-                take = max(0, min(m, int(n_samples)))
-                a = int(offs[k])
-                if pool is not None:
-                    pending.append(pool.submit(put, flat[a:a + take], signal, take, rid))
-                else:
-                    put(flat[a:a + take], signal, take, rid)
-                offs[k + 1] = a + take
-                lens[k], ids[k] = n_samples, rid
-                if int16:
-                    cur[3][k], cur[4][k] = scale, offset
+                if k == 0 and sharder is not None:
+                    mine = sharder.start_group()
+                if sharder is not None:
+                    sharder.add(n_samples)
+                if mine:
+                    if cur is None:
+                        cur = buffers()
+                        ids = np.empty(N, dtype=object)
+                        cur[2][0] = 0
+                    flat, lens, offs = cur[0], cur[1], cur[2]
+                    take = max(0, min(m, int(n_samples)))
+                    a = int(offs[k])
+                    if pool is not None:
+                        pending.append(pool.submit(lambda d, gt, tk, r: put(d, gt(), tk, r), flat[a:a + take], get, take, rid))
+                    else:
+                        put(flat[a:a + take], get(), take, rid)
+                    offs[k + 1] = a + take
+                    lens[k], ids[k] = n_samples, rid
+                    if int16:
+                        cur[3][k], cur[4][k] = scale, offset
                 k += 1
+                g += 1
                 if k == N:
-                    finish()
-                    yield k, ids
+                    if mine:
+                        finish()
+                        if ordinals is not None:
+                            ordinals.append(g - k)
+                        yield k, ids
                     cur = None
                     k = 0
-        if k:
+        if k and mine:
             finish()
+            if ordinals is not None:
+                ordinals.append(g - k)
             yield k, ids[:k]
     finally:
         if pool is not None:

@@ -103,105 +103,89 @@ class _Writer:
                 self.pending[ok] = []
 
 
+def _init_dist(device=None):
+    """one process per GPU: the process group (RCCL = "nccl"; ADAPTED_DIST_BACKEND=gloo for CPU-side rehearsals / tests)"""
+    rank, ws, local = parallel.world()
+    if ws <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+
+    backend = os.environ.get("ADAPTED_DIST_BACKEND", "nccl")
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local if device is None else device)
+        dist.init_process_group(backend)
+    return dist
+
+
 def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, batch_out, device, start_peak=False,
                bidx_pass=0, bidx_fail=0, int16_ingest=False):
     rank, ws, local = parallel.world()
     if device is None:
         device = local
-    if ws > 1:
-        import torch
-        import torch.distributed as dist
-
-        torch.cuda.set_device(device)
-        if not dist.is_initialized():
-            dist.init_process_group("nccl")
+        if ws > 1 and os.environ.get("ADAPTED_DIST_BACKEND", "nccl") != "nccl":
+            device = local % max(lib.load().adp_device_count(), 1)  # (a rehearsal may share devices)
+    dist = _init_dist(device)
     primary = spc.primary_method
-    if primary == "cnn":
-        from .detect import cnn as _cnn
-
-        model = _cnn.load_cnn_model(spc.cnn_boundaries.model_name)
+    model = None  # CNN primary: the weights named in the config go to the engine on first use (no PyTorch module needed)
     m = spc.sig_preload_size
     writer = _Writer(run_dir, batch_out, bidx_pass, bidx_fail) if rank == 0 else None
     t0 = time.time()
-    my_rows, my_ids = [], []
+    my_rows, my_ids, my_ord = [], [], []
     dropped_text = {1: "MAD normalization failed: scale is 0", 2: "a read has no signal after min_obs_adapter"}
+    from .io_utils import GroupSharder
     from .pipeline import HostPipeline
 
     # pinned staging slots filled in place by a producer thread, H2D overlapped with the detect call, CSV writing in
-    # a third thread (adapted_amd/pipeline.py); ranks take whole minibatches round-robin
+    # a third thread (adapted_amd/pipeline.py).  The reads travel packed back to back and the padded matrix is laid out on
+    # the device (only the samples that exist cross PCIe).  Several ranks: every rank walks the stream's METADATA and
+    # decodes only the groups of whole minibatches a GroupSharder assigns to it (balanced by preloaded samples).
     GROUP = 4  # minibatches per staging slot and detect call (normalisation stays per minibatch)
-    # one rank: the reads travel packed back to back and the padded matrix is laid out on the device (only the samples that
-    # exist cross PCIe); several ranks keep the dense slots (each takes every ws-th group out of the common stream)
-    ragged = ws == 1
     pipe = HostPipeline(spc, minibatch, m, device=device, primary=primary, with_start_peak=start_peak,
-                        model=model if primary == "cnn" else None, int16_input=int16_ingest, group=GROUP, ragged=ragged)
+                        model=model, int16_input=int16_ingest, group=GROUP, ragged=True)
+    sharder = GroupSharder(ws, rank, m) if ws > 1 else None
+    ordinals: List[int] = []  # stream index of the first read of every group this rank yields
 
-    def fill_i16(get_buffers):
-        # raw ADC samples + calibration travel to the device, pA values are made there (extension, see pipeline.py)
-        from .io_utils import yield_minibatches_i16
-
-        it = yield_minibatches_i16(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, buffers=get_buffers if ws == 1 else None)
-        for i, (raw, lens, sc, of, ids) in enumerate(it):
-            if ws > 1:
-                if i % ws != rank:
-                    continue
-                braw, bl, bsc, bof = get_buffers()
-                k = raw.shape[0]
-                braw[:k], bl[:k], bsc[:k], bof[:k] = raw, lens, sc, of
-            yield raw.shape[0], ids.copy()
-
-    def fill_packed(get_buffers):
+    def fill(get_buffers):
         from .io_utils import yield_minibatches_packed
 
         for k, ids in yield_minibatches_packed(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, get_buffers,
-                                               int16=int16_ingest):
-            yield k, ids.copy()
+                                               int16=int16_ingest, sharder=sharder, ordinals=ordinals):
+            # ids travel with the stream position of each read: (id, ordinal) pairs survive the slicing of dropped minibatches
+            tagged = np.empty((k, 2), dtype=object)
+            tagged[:, 0] = ids[:k]
+            tagged[:, 1] = np.arange(ordinals[-1], ordinals[-1] + k)
+            yield k, tagged
 
-    def fill(get_buffers):
-        if ragged:
-            yield from fill_packed(get_buffers)
-            return
-        if int16_ingest:
-            yield from fill_i16(get_buffers)
-            return
-        it = yield_minibatches(files, read_ids_incl, read_ids_excl, minibatch * GROUP, m, buffers=get_buffers if ws == 1 else None)
-        for i, (sig, lens, ids) in enumerate(it):
-            if ws > 1:
-                if i % ws != rank:
-                    continue  # (the stream length is unknown up front)
-                bs, bl = get_buffers()
-                bs[: sig.shape[0]] = sig
-                bl[: sig.shape[0]] = lens
-            yield sig.shape[0], ids.copy()
-
-    def on_rows(ids, rows):
+    def on_rows(tagged, rows):
         if ws > 1:
             my_rows.append(rows)
-            my_ids.extend(ids.tolist())
+            my_ids.extend(tagged[:, 0].tolist())
+            my_ord.extend(int(x) for x in tagged[:, 1])
         else:
             res = lib.rows_to_results(rows, primary)
             writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
-                        for rid, r in zip(ids, res)])
+                        for rid, r in zip(tagged[:, 0], res)])
 
-    def on_dropped(ids, status):
-        logging.error("minibatch of %d reads dropped: %s", len(ids), dropped_text.get(status, status))
+    def on_dropped(tagged, status):
+        logging.error("minibatch of %d reads dropped: %s", len(tagged), dropped_text.get(status, status))
 
     try:
         pipe.run(fill, on_rows, on_dropped)
     finally:
         pipe.close()
     if ws > 1:
-        import torch.distributed as dist
-
         rows = np.concatenate(my_rows) if my_rows else np.zeros(0, dtype=lib.ROW_DTYPE)
         allrows = parallel.gather_rows(rows, dst=0)
-        idlists = [None] * ws if rank == 0 else None
-        dist.gather_object(my_ids, idlists, dst=0)
+        lists = [None] * ws if rank == 0 else None
+        dist.gather_object((my_ids, my_ord), lists, dst=0)
         if rank == 0:
-            ids = [x for part in idlists for x in part]
-            res = lib.rows_to_results(allrows, primary)
-            writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
-                        for rid, r in zip(ids, res)])
+            ids = [x for part in lists for x in part[0]]
+            order = np.argsort(np.array([x for part in lists for x in part[1]], dtype=np.int64), kind="stable")
+            res = lib.rows_to_results(allrows[order], primary)  # stream order: the files read like a one-GPU run's
+            writer.add([ReadResult(read_id=str(ids[i]), success=r.success, fail_reason=r.fail_reason, detect_results=r)
+                        for i, r in zip(order, res)])
     if writer is not None:
         writer.close()
         tot = writer.n[True] + writer.n[False]
@@ -209,6 +193,8 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
                      tot / max(time.time() - t0, 1e-9), ws)
         if tot:
             logging.info("Pass: %d (%.2f%%), fail: %d", writer.n[True], 100.0 * writer.n[True] / tot, writer.n[False])
+    if ws > 1:
+        dist.barrier()
 
 
 def main(argv=None):
@@ -227,6 +213,11 @@ def main(argv=None):
     else:
         args.output = args.output or os.getcwd()
         run_dir = os.path.join(args.output, "adapted_" + __version__.replace(".", "_") + "_" + str(uuid.uuid4())[:8])
+        if parallel.world()[1] > 1:  # one run directory for all ranks: rank 0's name
+            dist = _init_dist(getattr(args, "device", None))
+            box = [run_dir]
+            dist.broadcast_object_list(box, src=0)
+            run_dir = box[0]
     if not args.config and not args.chemistry:
         raise SystemExit("Either --config or --chemistry must be provided.")
     read_ids: List[str] = []
@@ -244,8 +235,8 @@ def main(argv=None):
     spc.update_primary_method()
     spc.update_sig_preload_size()
     rank = parallel.world()[0]
-    os.makedirs(run_dir, exist_ok=True)
     if rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
         with open(os.path.join(run_dir, "command.json"), "w") as fh:
             json.dump(vars(args), fh, indent=2)
         spc.to_toml(os.path.join(run_dir, "config.toml"))

@@ -45,7 +45,8 @@ def gather_rows(rows, dst: int = 0, group=None):
     as_numpy = isinstance(rows, np.ndarray)
     if as_numpy:
         dtype = rows.dtype
-        t = torch.from_numpy(np.ascontiguousarray(rows).view(np.uint8).reshape(rows.shape[0], -1).copy())
+        # (explicit width: reshape(0, -1) of an empty block is an error, and a rank may well end up with no rows)
+        t = torch.from_numpy(np.ascontiguousarray(rows).view(np.uint8).reshape(rows.shape[0], dtype.itemsize).copy())
     else:
         t = rows
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")

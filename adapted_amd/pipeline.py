@@ -117,7 +117,8 @@ class HostPipeline:
             return self.eng.detect_start_peak_rows(dsig, dlen, n, self.mb, device_ptrs=True), None
         from .detect import cnn as _cnn
 
-        return _cnn.detect_rows_device(self.eng, dsig, dlen, n, s["lens"][:n], self.model, self.spc), None
+        # (the reference runs find_peaks and its row compaction per minibatch: adapted/detect/cnn.py:136-160)
+        return _cnn.detect_rows_device(self.eng, dsig, dlen, n, s["lens"][:n], self.model, self.spc, minibatch=self.mb), None
 
     # -- driver -------------------------------------------------------------------------------
     def run(self, fill: Callable[[Callable[[], Tuple[np.ndarray, np.ndarray]]], Iterable[Tuple[int, object]]],
@@ -139,14 +140,32 @@ class HostPipeline:
                 return head + (sl["cal"][0], sl["cal"][1])
             return head
 
+        stop = threading.Event()
+
+        def put_filled(item):
+            while not stop.is_set():
+                try:
+                    filled.put(item, timeout=0.2)
+                    return
+                except queue.Full:
+                    continue
+
         def producer():
+            gen = fill(get_buffers)
             try:
-                for n, ids in fill(get_buffers):
-                    filled.put((cur["j"], int(n), ids))
+                for n, ids in gen:
+                    if stop.is_set():
+                        break
+                    put_filled((cur["j"], int(n), ids))
             except BaseException as e:  # noqa: BLE001 -- handed to the caller's thread
                 err.append(e)
             finally:
-                filled.put(None)
+                if hasattr(gen, "close"):
+                    try:
+                        gen.close()  # (lets the reader shut its copy pool down)
+                    except BaseException as e:  # noqa: BLE001
+                        err.append(e)
+                put_filled(None)
 
         def consumer():
             while True:
@@ -191,8 +210,27 @@ class HostPipeline:
                 if err:
                     break
         finally:
+            # an error (or an exception out of _detect) may leave the producer mid-slot: it has to be gone before the caller
+            # frees the pinned slots it writes into (close()), so stop it, unblock it and wait for it
+            stop.set()
+            while True:
+                try:
+                    filled.get_nowait()
+                except queue.Empty:
+                    break
+            for j in range(len(self.slots)):
+                self.free.put(j)
+            tp.join(timeout=60)
             done.put(None)
             tc.join()
+            # the free list back to one token per slot for the next run()
+            while True:
+                try:
+                    self.free.get_nowait()
+                except queue.Empty:
+                    break
+            for j in range(len(self.slots)):
+                self.free.put(j)
         if err:
             raise err[0]
         return total

@@ -390,3 +390,61 @@ def test_single_read_api_vs_golden_and_oracle(oracle_mod, name):
                          {k: v for k, v in oracle_mod.detect_llr_single(odd, odd.size, spc, m).items() if not k.startswith("_")})
     with pytest.raises(ValueError, match="scale is 0"):
         combined_detect_llr(np.full(min(m, 9000), 80.0, dtype=np.float32), min(m, 9000), spc)
+
+
+@pytest.mark.parametrize("primary", ["llr", "cnn"])
+def test_cli_two_ranks_equal_one_rank(tmp_path, primary):
+    """`adapted detect` under torchrun with 2 ranks (gloo rendezvous, both ranks on this box's one GPU): one run directory
+    (rank 0's name, broadcast), every rank decodes only its own groups of whole minibatches, rows come back in stream
+    order -- the CSV files equal the 1-rank run's byte for byte.  Also a stream with fewer groups than ranks (a rank
+    without any row must not break the gather)."""
+    import subprocess
+    import sys
+
+    from adapted_amd import synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect = primary == "llr"
+    spc.cnn_boundaries.cnn_detect = primary == "cnn"
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m = spc.sig_preload_size
+    mb, n = 8, 8 * 4 * 5 + 11                     # 5 groups of 4 minibatches and a ragged tail
+    lens = np.array([m if i % 4 else synth.pareto_length(3, i) for i in range(n)], dtype=np.int32)
+    sig, _ = synth.synth_batch(31, 0, n, m, lens)
+    ids = np.array(["read_%04d" % i for i in range(n)], dtype=object)
+    np.savez(tmp_path / "reads_0.npz", signals=sig[: n // 2], full_lengths=lens[: n // 2], read_ids=ids[: n // 2])
+    np.savez(tmp_path / "reads_1.npz", signals=sig[n // 2:], full_lengths=lens[n // 2:], read_ids=ids[n // 2:])
+    np.savez(tmp_path / "few.npz", signals=sig[:20], full_lengths=lens[:20], read_ids=ids[:20])
+    cfg = tmp_path / "cfg.toml"
+    spc.to_toml(str(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(inputs, out, ranks):
+        cmd = [sys.executable]
+        env = dict(os.environ, PYTHONPATH=root, ADAPTED_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+        if ranks > 1:
+            cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
+                    "--master-port", "29741"]
+            cmd += ["-m", "adapted_amd.main"]
+        else:
+            cmd += ["-m", "adapted_amd.main"]
+        cmd += ["detect", "-i"] + [str(x) for x in inputs] + ["-o", str(out), "--config", str(cfg), "-s", str(mb), "-b", "50"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        runs = [d for d in os.listdir(out) if d.startswith("adapted_")]
+        assert len(runs) == 1, runs            # no stray directories from the other ranks
+        files = {}
+        for sub in ("boundaries", "failed_reads"):
+            d = out / runs[0] / sub
+            for f in sorted(os.listdir(d)) if d.exists() else []:
+                files[sub + "/" + f] = (d / f).read_text()
+        return files
+
+    for inputs, tag in (([tmp_path / "reads_0.npz", tmp_path / "reads_1.npz"], "all"), ([tmp_path / "few.npz"], "few")):
+        one = run(inputs, tmp_path / ("out1_" + tag), 1)
+        two = run(inputs, tmp_path / ("out2_" + tag), 2)
+        assert one.keys() == two.keys() and len(one) >= 1
+        for k in one:
+            assert one[k] == two[k], (tag, k)

@@ -212,6 +212,16 @@ if rank == 0:
     print("GATHER_OK", out.shape[0])
 else:
     assert out is None
+# a rank without any row (fewer minibatches than ranks) must not break the collective
+a, b = parallel.shard_reads(500, mb, ws, rank)
+rows = np.zeros(b - a, dtype=ROW_DTYPE)
+rows["col"][:, 0] = np.arange(a, b)
+out = parallel.gather_rows(rows, dst=0)
+if rank == 0:
+    assert out.shape[0] == 500 and np.array_equal(out["col"][:, 0], np.arange(500))
+    print("EMPTY_RANK_OK", b - a)
+else:
+    assert b - a == 0 and out is None
 dist.destroy_process_group()
 """
 
@@ -224,7 +234,7 @@ def test_row_gather_two_ranks_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "GATHER_OK 7300" in r.stdout
+    assert "GATHER_OK 7300" in r.stdout and "EMPTY_RANK_OK 500" in r.stdout
 
 
 def test_minibatches_fill_caller_buffers_in_place(tmp_path):
