@@ -75,7 +75,8 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat;
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used;
+    unsigned int op_last_used = 0;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
 };
@@ -218,7 +219,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -390,8 +391,21 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     }
     int grid = n < h->vslots ? n : h->vslots;
     sync_ablate(h->stream);
-    { Scope s(h, "k_validate");
-      hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+    // open-pore lists longer than a row holds go to an arena; if it turns out too small the kernel runs again on a larger one
+    if (h->op_used.ensure(8) || (h->op_arena.cap == 0 && h->op_arena.ensure((size_t)65536 * 4))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    for (int attempt = 0; attempt < 3; attempt++) {
+        in.op_arena = h->op_arena.as<int32_t>(); in.op_used = h->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(h->op_arena.cap / 4);
+        HIPCHK(hipMemsetAsync(h->op_used.p, 0, 4, h->stream));
+        { Scope s(h, attempt ? nullptr : "k_validate");
+          hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+        if (!h->cfg.detect_open_pores) { h->op_last_used = 0; break; }
+        unsigned int used = 0;
+        HIPCHK(hipMemcpyAsync(&used, h->op_used.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->op_last_used = used;
+        if ((size_t)used * 4 <= h->op_arena.cap) break;
+        if (h->op_arena.ensure((size_t)used * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    }
     { Scope s(h, "k_partition_stats");
       hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
@@ -1024,6 +1038,19 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     HIPCHK(hipMemcpyAsync(status_out, dstat, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+int adp_open_pores_arena(adp_handle *h, int32_t *out, uint64_t cap, uint64_t *used)
+{
+    if (!h || !used || (cap && !out)) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    *used = h->op_last_used;
+    const uint64_t n = h->op_last_used < cap ? h->op_last_used : cap;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(out, h->op_arena.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return ADP_OK;
 }
 

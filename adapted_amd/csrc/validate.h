@@ -31,6 +31,9 @@ struct ValidateIn {
     const int8_t *have_series; // [n_reads]
     int series_cap;
     const CandStat *cstat;     // [n_reads, kmax] the candidates' order statistics (k_cand_stats) or nullptr
+    int32_t *op_arena;         // whole open_pores lists of the reads with more than ADP_MAX_OPEN_PORES entries
+    unsigned int *op_used;     // entries handed out (may exceed op_cap: the host then grows the arena and repeats the kernel)
+    unsigned int op_cap;
 };
 
 static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
@@ -461,7 +464,7 @@ static __device__ void row_clear(adp_row *row)
     uint32_t *w = reinterpret_cast<uint32_t *>(row);
     for (int i = lane_id(); i < (int)(sizeof(adp_row) / 4); i += 64) w[i] = 0;
     __syncthreads();
-    if (lane_id() == 0) { row->n_cand = -1; row->n_open_pores = -1; }
+    if (lane_id() == 0) { row->n_cand = -1; row->n_open_pores = -1; row->open_pores_more = -1; }
 }
 
 static __device__ void row_exception(adp_row *row, int code)
@@ -540,6 +543,32 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
             if (npos == 0) n_open = 0;
             else if (npos == 1 || nvalid == 0) { n_open = 1; last = lastpos; if (ln == 0) row->open_pores[0] = lastpos; }
             else { n_open = nvalid; last = lastvalid; }
+            if (n_open > ADP_MAX_OPEN_PORES) {
+                // the reference's list has no length limit: the whole of it goes to the call's arena (second scan, rare)
+                unsigned int off = 0;
+                if (ln == 0) off = atomicAdd(in.op_used, (unsigned int)n_open);
+                off = __shfl(off, 0);
+                if ((unsigned long long)off + (unsigned long long)n_open <= in.op_cap) {
+                    int np2 = 0, nv2 = 0, pl2 = -1;
+                    for (int base = 0; base < b; base += 64) {
+                        const int i = base + ln;
+                        const bool f = (i < b) && (200.0f <= sig[i]);
+                        const unsigned long long mk = __ballot(f);
+                        if (mk) {
+                            const unsigned long long lower = mk & ((1ull << ln) - 1ull);
+                            const int prev = lower ? (base + 63 - __clzll((long long)lower)) : pl2;
+                            const bool first_overall = (np2 == 0) && (lower == 0);
+                            const bool valid = f && !first_overall && (i - prev >= 10);
+                            const unsigned long long vm = __ballot(valid);
+                            if (valid) in.op_arena[off + nv2 + __popcll(vm & ((1ull << ln) - 1ull))] = i;
+                            nv2 += __popcll(vm);
+                            np2 += __popcll(mk);
+                            pl2 = base + 63 - __clzll((long long)mk);
+                        }
+                    }
+                    if (ln == 0) row->open_pores_more = (int32_t)off;
+                } else if (ln == 0) row->open_pores_more = -2; // (the host grows the arena and runs the kernel again)
+            }
             if (n_open > 0) {
                 a_s = last;
                 if (a_e - a_s < cfg.min_obs_adapter) { success = 0; fail = ADP_F_OPEN_PORE; }
@@ -799,7 +828,7 @@ __global__ void k_sp_decorate(const SpOut *__restrict__ sp, adp_row *__restrict_
     if (r >= n_reads) return;
     adp_row *o = rows + r;
     if (mode == 1 && any_none && any_none[0]) {
-        memset(o, 0, sizeof(*o)); o->n_cand = -1; o->n_open_pores = -1; o->success = 0; o->fail_code = ADP_F_EXC_SLICE;
+        memset(o, 0, sizeof(*o)); o->n_cand = -1; o->n_open_pores = -1; o->open_pores_more = -1; o->success = 0; o->fail_code = ADP_F_EXC_SLICE;
         return;
     }
     if (ADP_F_IS_EXCEPTION(o->fail_code)) return; // (the reference raised: a bare DetectResults)

@@ -205,9 +205,7 @@ def _apply_fallback(eng, rows, idx, sig_sub, lens_sub, bounds, spc):
     new_pe, status = eng.llr_refine_polya(sig_sub, lens_sub, idx.size, bounds[idx, :2])
     for j, i in enumerate(idx):
         if status[j] != 0:  # the reference raised inside its per-read try block
-            rows[i] = np.zeros(1, dtype=lib.ROW_DTYPE)[0]
-            rows[i]["n_cand"] = -1
-            rows[i]["n_open_pores"] = -1
+            rows[i] = lib.empty_rows(1)[0]
             rows[i]["fail_code"] = status[j]
     redo = [j for j in range(idx.size) if status[j] == 0 and new_pe[j] > 0]
     if redo:

@@ -43,7 +43,34 @@ _F32_COLS = {23, 25, 27}
 
 ROW_DTYPE = np.dtype([("col", "<f8", (NCOL,)), ("present", "<u8"), ("success", "<i4"), ("fail_code", "<i4"),
                       ("mvs_fail_mask", "<i4"), ("start_peak_type", "<i4"), ("n_cand", "<i4"),
-                      ("n_open_pores", "<i4"), ("cand", "<i8", (MAX_CAND,)), ("open_pores", "<i4", (MAX_OPEN_PORES,))])
+                      ("n_open_pores", "<i4"), ("cand", "<i8", (MAX_CAND,)), ("open_pores", "<i4", (MAX_OPEN_PORES,)),
+                      ("open_pores_more", "<i4"), ("reserved_", "<i4")])
+
+# open_pores lists longer than a row holds (the reference's list has no length limit): host rows carry a token into this
+# registry in `open_pores_more` (Engine._attach_open_pores swaps the arena offset of the call for it), so that rows can be
+# sliced, concatenated and gathered freely before they become DetectResults
+_OPEN_PORES_MORE: dict = {}
+_open_pores_token = [0]
+
+
+def register_open_pores(arr) -> int:
+    _open_pores_token[0] += 1
+    _OPEN_PORES_MORE[_open_pores_token[0]] = np.asarray(arr, dtype=np.int64)
+    return _open_pores_token[0]
+
+
+def clear_open_pores():
+    _OPEN_PORES_MORE.clear()
+
+
+def empty_rows(n: int) -> np.ndarray:
+    """n zeroed result rows (the all-None rows of exceptions and dropped minibatches)"""
+    rows = np.zeros(n, dtype=ROW_DTYPE)
+    rows["n_cand"] = -1
+    rows["n_open_pores"] = -1
+    rows["open_pores_more"] = -1
+    return rows
+
 
 FAIL_REASONS = {
     0: None,
@@ -125,7 +152,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
            "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
-           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn"]
+           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -210,7 +237,14 @@ def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
             d.polya_candidates = np.asarray(r["cand"][:nc], dtype=np.int64)
         no = int(r["n_open_pores"])
         if no >= 0:
-            d.open_pores = np.asarray(r["open_pores"][:min(no, MAX_OPEN_PORES)], dtype=np.int64)
+            if no <= MAX_OPEN_PORES:
+                d.open_pores = np.asarray(r["open_pores"][:no], dtype=np.int64)
+            else:  # the whole list was fetched from the call's arena (Engine._attach_open_pores)
+                more = _OPEN_PORES_MORE.get(int(r["open_pores_more"]))
+                if more is None or more.size != no:
+                    raise HipLibraryError("a row with %d open pores lost its overflow list (rows from a device buffer? fetch them "
+                                          "through Engine.attach_open_pores)" % no)
+                d.open_pores = more
         d.mvs_llr_polya_end_adjust_ignored = False
         d.mvs_llr_polya_end_to_early_stop = bool(int(r["mvs_fail_mask"]) >> 8 & 1)  # (mvs_detect_overwrite only)
         fr = fail_reason_of(r)
@@ -341,6 +375,24 @@ class Engine:
                                             C.c_uint32(seed), C.c_uint32(first_read), int(decorate)))
 
     # -- operators ------------------------------------------------------------------------
+    def attach_open_pores(self, rows: Optional[np.ndarray]):
+        """rows (host) of the LAST call: reads with more open pores than a row holds get their whole list out of the
+        call's arena (the offset in `open_pores_more` becomes a registry token)"""
+        if rows is None or rows.size == 0:
+            return rows
+        big = np.flatnonzero(rows["n_open_pores"] > MAX_OPEN_PORES)
+        if big.size:
+            used = C.c_uint64(0)
+            self._check(self.lib.adp_open_pores_arena(self._h, None, C.c_uint64(0), C.byref(used)))
+            arena = np.zeros(int(used.value), dtype=np.int32)
+            self._check(self.lib.adp_open_pores_arena(self._h, arena.ctypes.data_as(C.c_void_p), C.c_uint64(arena.size), C.byref(used)))
+            for i in big:
+                off, no = int(rows[i]["open_pores_more"]), int(rows[i]["n_open_pores"])
+                if off < 0 or off + no > arena.size:
+                    raise HipLibraryError("open-pore arena inconsistent (offset %d, %d entries, %d in use)" % (off, no, arena.size))
+                rows[i]["open_pores_more"] = register_open_pores(arena[off:off + no])
+        return rows
+
     def _in_ptrs(self, signals, full_lens, n, device_ptrs):
         if device_ptrs:
             return C.c_void_p(int(signals)), C.c_void_p(int(full_lens)), ADP_IN_DEVICE, None
@@ -371,15 +423,24 @@ class Engine:
         self._check(self.lib.adp_detect_llr(self._h, sp, lp, int(n), self.m, int(minibatch), flags, rp,
                                             mbs.ctypes.data_as(C.c_void_p)))
         del keep
-        return rows, mbs
+        return self.attach_open_pores(rows), mbs
 
     def detect_start_peak_rows(self, signals, full_lens, n: int, minibatch: int, device_ptrs: bool = False):
-        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
-        rows = np.zeros(n, dtype=ROW_DTYPE)
-        self._check(self.lib.adp_detect_start_peak(self._h, sp, lp, int(n), self.m, int(minibatch), flags,
-                                                   rows.ctypes.data_as(C.c_void_p)))
-        del keep
-        return rows
+        """one library call per minibatch (the pandas float-column quirk couples the reads of a minibatch, and the open-pore
+        arena belongs to one call)"""
+        parts = []
+        for s0 in range(0, n, minibatch):
+            k = min(minibatch, n - s0)
+            if device_ptrs:
+                sp, lp, flags, keep = self._in_ptrs(int(signals) + s0 * self.m * 4, int(full_lens) + s0 * 4, k, True)
+            else:
+                sp, lp, flags, keep = self._in_ptrs(signals[s0:s0 + k], full_lens[s0:s0 + k], k, False)
+            rows = np.zeros(k, dtype=ROW_DTYPE)
+            self._check(self.lib.adp_detect_start_peak(self._h, sp, lp, int(k), self.m, int(minibatch), flags,
+                                                       rows.ctypes.data_as(C.c_void_p)))
+            del keep
+            parts.append(self.attach_open_pores(rows))
+        return parts[0] if len(parts) == 1 else np.concatenate(parts)
 
     def validate_rows(self, signals, full_lens, n: int, bounds: np.ndarray, device_ptrs: bool = False,
                       topk_none: bool = False):
@@ -395,7 +456,7 @@ class Engine:
         self._check(self.lib.adp_validate_candidates(self._h, sp, lp, int(n), self.m, b.ctypes.data_as(C.c_void_p), int(k),
                                                      flags, rows.ctypes.data_as(C.c_void_p)))
         del keep
-        return rows
+        return self.attach_open_pores(rows)
 
     def cnn_topk(self, scores_ptr: int, adapter_pos_ptr: int, polya_pos_ptr: int, n: int, Lo: int, k: int):
         """the k > 1 part of C3 behind given arg-maxes (tests): (cand int32 [n, k], n_peaks int32 [n]); device pointers in"""
@@ -429,7 +490,7 @@ class Engine:
         self._check(self.lib.adp_detect_cnn(self._h, sp, lp, int(n), self.m, int(minibatch), flags, rp,
                                             bounds.ctypes.data_as(C.c_void_p) if want_bounds else None))
         del keep
-        return rows, bounds
+        return self.attach_open_pores(rows), bounds
 
     def cnn_set_weights(self, state):
         """state: mapping with the reference's state-dict keys ("0.weight" ... "6.bias") -> float32 arrays (numpy, or anything

@@ -1,7 +1,7 @@
 """Multi-GPU layout of ``adapted detect``: one process per GPU, reads sharded in WHOLE
 minibatches (the LLR path normalises per minibatch -- reference adapted/detect/normalize.py:
 15-22 -- so results do not depend on the GPU count), no collective on the data path, and ONE
-gather of the fixed-width result rows (536 B each) to the writer rank.  With the "nccl"
+gather of the fixed-width result rows (544 B each) to the writer rank.  With the "nccl"
 backend (= RCCL over xGMI on ROCm) the gather runs on device tensors; the same code runs on
 "gloo"/CPU tensors (used by the world_size-2 CPU tests)."""
 from __future__ import annotations
@@ -60,9 +60,25 @@ def gather_rows(rows, dst: int = 0, group=None):
     pad[: t.shape[0]] = t
     bufs = [torch.empty_like(pad) for _ in range(ws)] if rk == dst else None
     dist.gather(pad, bufs, dst=dst, group=group)
+    more = None
+    if as_numpy and "open_pores_more" in (dtype.names or ()):
+        # open_pores lists longer than a row holds travel beside the fixed-width rows (rare, small): tokens of this
+        # process's registry -> the lists -> tokens of the destination's registry
+        from . import lib as _lib
+
+        mine = [(int(i), _lib._OPEN_PORES_MORE[int(rows[i]["open_pores_more"])]) for i in np.flatnonzero(rows["n_open_pores"] > _lib.MAX_OPEN_PORES)]
+        more = [None] * ws if rk == dst else None
+        dist.gather_object(mine, more, dst=dst, group=group)
     if rk != dst:
         return None
     out = torch.cat([bufs[r][: int(counts[r].item())] for r in range(ws)], dim=0)
     if as_numpy:
-        return out.cpu().numpy().reshape(-1).view(dtype)
+        res = out.cpu().numpy().reshape(-1).view(dtype)
+        if more is not None:
+            base = 0
+            for r in range(ws):
+                for i, arr in more[r]:
+                    res[base + i]["open_pores_more"] = _lib.register_open_pores(arr)
+                base += int(counts[r].item())
+        return res
     return out

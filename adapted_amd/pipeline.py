@@ -9,7 +9,7 @@ path busy and nothing else in the way:
   producer thread   fills pinned (page-locked) staging slots in place -- no intermediate copy -- from any
                     iterator of (signals, lengths, ids) writers (io_utils.yield_minibatches(buffers=...));
   transfer/compute  (caller's thread) per slot: one asynchronous H2D copy on a copy stream, the detect call
-                    on device pointers, the 536-byte result rows back; the H2D of slot k+1 is started
+                    on device pointers, the 544-byte result rows back; the H2D of slot k+1 is started
                     BEFORE the detect call of slot k, so copies and kernels overlap;
   consumer          `on_rows(ids, rows)` (CSV writer) runs in a third thread.
 

@@ -135,9 +135,12 @@ typedef struct adp_row {
     int32_t mvs_fail_mask;     /* bit0 mean, bit1 var, bit2 med, bit3 range, bit4 shift failed; bit8 ADP_MVS_TO_EARLY_STOP */
     int32_t start_peak_type;   /* 0 None, 1 "open pore in adapter", 2 "potential concatemer adapter-only read" */
     int32_t n_cand;            /* polya_candidates length; -1 <=> None */
-    int32_t n_open_pores;      /* open_pores length (may exceed ADP_MAX_OPEN_PORES); -1 <=> None */
+    int32_t n_open_pores;      /* open_pores length (may exceed ADP_MAX_OPEN_PORES: see open_pores_more); -1 <=> None */
     int64_t cand[ADP_MAX_CAND];
-    int32_t open_pores[ADP_MAX_OPEN_PORES];
+    int32_t open_pores[ADP_MAX_OPEN_PORES]; /* the first ADP_MAX_OPEN_PORES positions */
+    int32_t open_pores_more;   /* n_open_pores > ADP_MAX_OPEN_PORES: the WHOLE list lies at this offset of the call's
+                                  open-pore arena (adp_open_pores_arena); -1 otherwise */
+    int32_t reserved_;
 } adp_row;
 
 typedef struct adp_handle adp_handle;
@@ -216,6 +219,12 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
  * status_out[i] = 0 or the ADP_F_EXC_* code of the exception the reference would have raised. */
 int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                          const int64_t *ranges, int flags, int64_t *polya_out, int32_t *status_out);
+
+/* The open-pore arena of the LAST detect / validate call on this handle: find_open_pores (adapted/detect/anomalies.py:15-35)
+ * returns a list without a length limit, and the CSV prints all of it; rows with more than ADP_MAX_OPEN_PORES entries keep
+ * their whole list here (row.open_pores_more = offset, row.n_open_pores = length).  Copies min(used, cap) int32 entries to
+ * the HOST buffer `out` and the number in use to *used (the arena grows by itself; a call never loses entries). */
+int adp_open_pores_arena(adp_handle *h, int32_t *out, uint64_t cap, uint64_t *used);
 
 /* Synthetic squiggles generated on the device (bit-identical to adapted_amd/synth.py).
  * dev_signals: device float32 [n, m]; dev_full_len: device int32 [n] or NULL (=> all m). */

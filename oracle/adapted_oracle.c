@@ -105,7 +105,7 @@ enum { /* fail codes <-> the reference's fail_reason strings (combined.py:396-58
 #define MVS_FLAG_TO_EARLY_STOP 256 /* mvs_fail_mask bit 8: mvs_llr_polya_end_to_early_stop (combined.py:559-561) */
 
 #define ORC_MAX_CAND 16
-#define ORC_MAX_OPEN_PORES 16
+#define ORC_MAX_OPEN_PORES 4096 /* (test infrastructure: rows may be large; the reference's list is unbounded) */
 
 typedef struct {
     double col[ORC_NCOL];

@@ -21,14 +21,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness  # noqa: E402
 
 import numpy as np  # noqa: E402
-from golden_cases import CASES, apply_overrides, resolve_lens  # noqa: E402
+from golden_cases import CASES, apply_blips, apply_overrides, resolve_lens  # noqa: E402
 
 _spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "adapted_amd", "synth.py"))
 synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-CSV_CASES = ("rna004_llr_default", "rna004_llr_mvs_overwrite_wide")  # cases whose CSV text is kept as well
+CSV_CASES = ("rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores")  # cases whose CSV text is kept as well
 
 
 def make_spc(case):
@@ -86,6 +86,7 @@ def run_case(name, case):
     n = case["n"]
     lens = np.asarray(resolve_lens(case["lens"], n, m), dtype=np.int32)
     sig, lens = synth.synth_batch(case["seed"], case["first"], n, m, lens)
+    apply_blips(sig, case)
     mb = case["minibatch"]
     results = []
     model = None

@@ -28,7 +28,7 @@ INT_COLS = {"signal_len", "preloaded", "adapter_start", "adapter_end", "adapter_
             "polya_end", "polya_len", "rna_preloaded_start", "rna_preloaded_len", "start_peak_idx",
             "start_peak_next_max_idx", "start_peak_open_pore_idx", "PRIMARY_adapter_end",
             "PRIMARY_polya_end", "mvs_adapter_end"}
-MAX_CAND, MAX_OP = 16, 16
+MAX_CAND, MAX_OP = 16, 4096
 
 ROW_DTYPE = np.dtype([("col", "<f8", (len(COLS),)), ("present", "<u8"), ("success", "<i4"),
                       ("fail_code", "<i4"), ("mvs_fail_mask", "<i4"), ("start_peak_type", "<i4"),

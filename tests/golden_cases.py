@@ -53,10 +53,26 @@ CASES = {
                               lens="mixed", minibatch=1, dump=[]),
     "rna002_llr_single_4k": dict(chem="RNA002", primary="llr_single", max_obs_trace=4000, seed=13, first=0, n=48,
                                  lens="mixed002", minibatch=1, dump=[]),
+    # reads with MANY open-pore events inside the adapter (>= 200 pA blips, anomalies.py:15-35): the open_pores list the CSV
+    # prints has no length limit (23 and 39 entries here, beside reads with 15, 16, 1, 0)
+    "rna004_llr_open_pores": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=23, first=0, n=24, lens="full",
+                                  minibatch=24, dump=[], blips=[24, 17, 16, 40, 2, 1]),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
 }
+
+
+def apply_blips(sig, case):
+    """case["blips"]: read i gets blips[i % len] open-pore events -- 3 samples at 260 pA every 40 samples from sample 120 on
+    (inside the adapter, in front of min_obs_adapter) -- written over the synthetic signal."""
+    spec = case.get("blips")
+    if not spec:
+        return sig
+    for i in range(sig.shape[0]):
+        for j in range(spec[i % len(spec)]):
+            sig[i, 120 + 40 * j: 123 + 40 * j] = 260.0
+    return sig
 
 
 def apply_overrides(spc, case):

@@ -93,7 +93,7 @@ def _results_from_golden(name):
     return out
 
 
-@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide"])
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores"])
 def test_csv_text_equals_reference(tmp_path, name):
     from adapted_amd.output import CSV_COLUMNS, save_detected_boundaries
 
@@ -116,7 +116,7 @@ def test_abi_library_loads_and_exports_header_symbols():
 
     L = lib.load()
     assert L.adp_abi_version() == 3
-    assert L.adp_sizeof_row() == lib.ROW_DTYPE.itemsize == 536
+    assert L.adp_sizeof_row() == lib.ROW_DTYPE.itemsize == 544
     assert L.adp_sizeof_cfg() == ctypes.sizeof(lib.AdpCfg)
     with open(os.path.join(ROOT, "include", "adapted_hip.h")) as fh:
         declared = set(re.findall(r"\b(adp_[a-z0-9_]+)\s*\(", fh.read()))
