@@ -364,7 +364,7 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     // (below ~32 k samples of preload the slices are short enough for k_validate's own wave-per-read statistics, which then
     // cost less than the workgroup-per-read sweeps: 14 vs 51 ms per 32 000 reads at the default window)
     const bool multi = kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite && h->m > 32768 &&
-                       h->cfg.pA_var_window <= MV_HIST && h->cfg.pA_mean_window <= MV_HIST;
+                       h->cfg.pA_var_window <= MS_HIST && h->cfg.pA_mean_window <= MS_HIST;
     const int cap = multi ? h->vstride : MVS_CAP;
     if (multi && (h->series.ensure((size_t)n * 2 * cap * 4) || h->cstat.ensure((size_t)n * kmax * sizeof(CandStat)))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>(); in.series_cap = cap;
@@ -372,7 +372,7 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
         if (multi) {
             Scope s(h, "k_mvs_series_wave");
-            hipLaunchKernelGGL(k_mvs_series_wave, dim3(n), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+            hipLaunchKernelGGL(k_mvs_series_wave, dim3(n), dim3(128), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         } else {
             Scope s(h, "k_mvs_series");

@@ -175,9 +175,9 @@ static __device__ __forceinline__ double div_by_len(double a, double b, double y
 
 // the library log for zero / negative / subnormal / non-finite arguments: out of line, it is next to never called
 static __device__ __noinline__ double gains_log_slow(double u) { return log(u); }
-static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, int len)
+static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, double chi, double clo, double dl) // dl = (double)length
 {
-    const double dl = (double)len, y = recip_refined(dl);
+    const double y = recip_refined(dl);
     double mu = div_by_len(chi - clo, dl, y);
     return div_by_len(c2hi - c2lo, dl, y) - mu * mu;
 }
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
     }
     double vs;
     {
-        double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, E - start);
+        double v = (start == E) ? 0.0 : var_seg(te.y, c2s, te.x, cs, (double)(E - start));
         vs = (double)(E - start) * flog(v);
     }
     int first_pos = 0x7fffffff, last_pos = -1;
@@ -270,21 +270,26 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
         // INTERIOR tiles -- every point has both segments and lies inside the read -- take a body without the range
         // tests, and the rare values (NaN, infinities) leave the straight path through branches: the kernel is bound
         // by float64 instruction issue, and scalar branches cost no vector slots where selects do.
+        // the two segment lengths of a lane's points as float64 counters (+1 / -1 per point, exact): an int -> float64
+        // conversion runs at a quarter of the add rate, and the kernel is bound by float64 issue (profiles/r02_sq_counters_*)
+        double dlh = (double)(i0 - start), dlt = (double)(E - i0);
         auto point = [&](auto interior_c, int t, int i, float qf) {
             constexpr bool INTERIOR = decltype(interior_c)::value;
             double gi = 0.0;
+            const double lh_len = dlh, lt_len = dlt;
+            dlh += 1.0; dlt -= 1.0;
             if (INTERIOR || i < n) {
                 if (INTERIOR || (i >= start + oh && i < E - ot)) {
-                    double vh = var_seg(b, c2s, a, cs, i - start);
-                    double vt = var_seg(te.y, b, te.x, a, E - i);
+                    double vh = var_seg(b, c2s, a, cs, lh_len);
+                    double vt = var_seg(te.y, b, te.x, a, lt_len);
                     // both logarithms side by side (independent instruction streams), exceptions patched afterwards
                     double lh = log_cr_fast(vh, lt), ll = log_cr_fast(vt, lt);
                     if (!(log_cr_ok(vh) && log_cr_ok(vt))) {
                         if (!log_cr_ok(vh)) lh = gains_log_slow(vh);
                         if (!log_cr_ok(vt)) ll = gains_log_slow(vt);
                     }
-                    double h = (double)(i - start) * lh;
-                    double tl = (double)(E - i) * ll;
+                    double h = lh_len * lh;
+                    double tl = lt_len * ll;
                     gi = vs - (h + tl);
                 }
                 if (PASS == 1 && !(gi <= 0.0)) { first_pos = min(first_pos, i); last_pos = i; } // (i grows along a lane)

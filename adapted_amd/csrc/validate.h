@@ -429,34 +429,132 @@ __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sig
     have[r] = 1;
 }
 
-// The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload): one WAVE per read --
-// coalesced chunk loads into LDS, the two chains in lanes 0 and 1 (wave_move_series).  With one lane per read the chains
-// wait on scattered loads (38 ms per 4000 reads at the 200 k window); here they run from LDS.
-// grid = n_reads; block = 64.
-__global__ void __launch_bounds__(64) k_mvs_series_wave(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
-                                                        int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
-                                                        float *__restrict__ series, int cap, int8_t *__restrict__ have)
+// The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload).  A workgroup of two
+// waves per read: wave 0 runs the moving variance, wave 1 the moving mean -- each a strictly sequential float32 chain in
+// ONE lane (same operations, same order as bn_move_var / bn_move_mean), fed from an LDS image of the slice that all 64 lanes
+// fill with coalesced loads (16-byte LDS reads in the chain when the window is a multiple of 4), its results collected in
+// LDS and written out coalesced.  With one lane per read straight from global memory (k_mvs_series) the chains waited on
+// scattered loads: 38 ms per 4000 reads at the 200 k window; lanes 0 / 1 of ONE wave with scalar LDS reads and single-lane
+// stores: 23 ms.
+#define MS_CHUNK 1024
+#define MS_HIST 320   // longest window served (as MV_HIST)
+struct MsStage { float buf[MS_HIST + MS_CHUNK]; float out[MS_CHUNK]; };
+
+template <bool VAR>
+static __device__ void ms_chain(const float *__restrict__ x_, int n, int w, float *__restrict__ series_, LDS MsStage *st)
 {
-    __shared__ WaveScratch ws_;
-    LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
+    const GLB float *x = (const GLB float *)x_;
+    GLB float *series = (GLB float *)series_;
+    const int ln = lane_id();
+    float amean = 0.f, assqdm = 0.f, asum = 0.f;
+    int count = 0;
+    const float inv = (float)(1.0 / (double)w);
+    const int H = (w + 3) & ~3; // history kept in front of a chunk (a multiple of 4: the chunk's own samples stay 16-byte aligned)
+    const bool vec = (w & 3) == 0;
+    for (int i0 = 0; i0 < n; i0 += MS_CHUNK) {
+        const int lo = i0 >= H ? i0 - H : 0; // st->buf[k] = x[lo + k]
+        const int hi = min(n, i0 + MS_CHUNK);
+        ws_sync();
+        for (int k = ln; k < hi - lo; k += 64) st->buf[k] = x[lo + k];
+        ws_sync();
+        if (ln == 0) {
+            int i = i0;
+            // the window fills (i < w): the reference's first phase, scalar
+            for (; i < hi && i < w; i++) {
+                const float ai = st->buf[i - lo];
+                if (VAR) {
+                    count++;
+                    const float delta = ai - amean;
+                    amean += delta / (float)count;
+                    assqdm += delta * (ai - amean);
+                    if (i == w - 1) { if (assqdm < 0) assqdm = 0; st->out[i - i0] = assqdm / (float)count; }
+                } else {
+                    asum += ai;
+                    if (i == w - 1) st->out[i - i0] = asum / (float)w;
+                }
+            }
+            // sliding steps, four at a time
+            for (; i + 4 <= hi; i += 4) {
+                float an[4], ao[4], res[4];
+                if (vec && ((i - lo) & 3) == 0) {
+                    const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&st->buf[i - lo]);
+                    const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&st->buf[i - w - lo]);
+                    an[0] = a4.x; an[1] = a4.y; an[2] = a4.z; an[3] = a4.w; ao[0] = o4.x; ao[1] = o4.y; ao[2] = o4.z; ao[3] = o4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { an[j] = st->buf[i + j - lo]; ao[j] = st->buf[i + j - w - lo]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (VAR) {
+                        float ai = an[j], aold = ao[j];
+                        const float delta = ai - aold;
+                        aold -= amean;
+                        amean += delta * inv;
+                        ai -= amean;
+                        assqdm += (ai + aold) * delta;
+                        if (assqdm < 0) assqdm = 0;
+                        res[j] = assqdm * inv;
+                    } else {
+                        asum += an[j] - ao[j];
+                        res[j] = asum * inv;
+                    }
+                }
+                if (((i - i0) & 3) == 0) { const adp_v4f r4 = {res[0], res[1], res[2], res[3]}; *reinterpret_cast<LDS adp_v4f *>(&st->out[i - i0]) = r4; }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) st->out[i + j - i0] = res[j];
+                }
+            }
+            for (; i < hi; i++) {
+                float ai = st->buf[i - lo], aold = st->buf[i - w - lo];
+                if (VAR) {
+                    const float delta = ai - aold;
+                    aold -= amean;
+                    amean += delta * inv;
+                    ai -= amean;
+                    assqdm += (ai + aold) * delta;
+                    if (assqdm < 0) assqdm = 0;
+                    st->out[i - i0] = assqdm * inv;
+                } else {
+                    asum += ai - aold;
+                    st->out[i - i0] = asum * inv;
+                }
+            }
+        }
+        ws_sync();
+        // out[i - i0] is the series value at index i - w + 1 (defined from i = w - 1 on)
+        const int first = i0 > w - 1 ? i0 : w - 1;
+        for (int i = first + ln; i < hi; i += 64) series[i - w + 1] = st->out[i - i0];
+    }
+}
+
+// grid = n_reads; block = 128 (wave 0: moving variance, wave 1: moving mean)
+__global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+                                                         int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
+                                                         float *__restrict__ series, int cap, int8_t *__restrict__ have)
+{
+    __shared__ MsStage stage_[2];
+    const int wave = threadIdx.x >> 6;
+    LDS MsStage *st = (LDS MsStage *)&stage_[wave];
     const int r = blockIdx.x;
-    if (lane_id() == 0) have[r] = 0;
     const long long fl = full_len[r];
     const int S = (int)(fl < m ? fl : m);
     const long long a_e = bounds[(size_t)r * (1 + kmax)];
     long long p_e = 0;
     for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
-    if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return;
-    if ((long long)S < a_e + cfg.median_shift_window) return;
+    bool ok = !(p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) && !((long long)S < a_e + cfg.median_shift_window);
     const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
     const int n = b - a;
     const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
-    if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) return;
-    if (n > cap || cfg.pA_var_window > MV_HIST || cfg.pA_mean_window > MV_HIST) return;
+    if (ok && ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1)))) ok = false;
+    if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
+    if (threadIdx.x == 0) have[r] = ok ? 1 : 0;
+    if (!ok) return;
     const float *x = sigs + (size_t)r * m + a;
     float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
-    wave_move_series(x, n, cfg.pA_var_window, cfg.pA_mean_window, wvar, wmean, svar, smean, ws);
-    if (lane_id() == 0) have[r] = 1;
+    if (wave == 0) { if (wvar) ms_chain<true>(x, n, cfg.pA_var_window, svar, st); }
+    else { if (wmean) ms_chain<false>(x, n, cfg.pA_mean_window, smean, st); }
 }
 
 static __device__ void row_clear(adp_row *row)
