@@ -372,7 +372,11 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
         if (multi) {
             Scope s(h, "k_mvs_series_wave");
-            hipLaunchKernelGGL(k_mvs_series_wave, dim3(n), dim3(128), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+            auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
+            const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 2 * (MS_CHUNK + 4)) * 4;
+            static size_t lds_set = 0;
+            if (lds > lds_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set = lds; }
+            hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         } else {
             Scope s(h, "k_mvs_series");

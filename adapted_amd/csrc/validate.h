@@ -429,132 +429,171 @@ __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sig
     have[r] = 1;
 }
 
-// The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload).  A workgroup of two
-// waves per read: wave 0 runs the moving variance, wave 1 the moving mean -- each a strictly sequential float32 chain in
-// ONE lane (same operations, same order as bn_move_var / bn_move_mean), fed from an LDS image of the slice that all 64 lanes
-// fill with coalesced loads (16-byte LDS reads in the chain when the window is a multiple of 4), its results collected in
-// LDS and written out coalesced.  With one lane per read straight from global memory (k_mvs_series) the chains waited on
-// scattered loads: 38 ms per 4000 reads at the 200 k window; lanes 0 / 1 of ONE wave with scalar LDS reads and single-lane
-// stores: 23 ms.
-#define MS_CHUNK 1024
-#define MS_HIST 320   // longest window served (as MV_HIST)
-struct MsStage { float buf[MS_HIST + MS_CHUNK]; float out[MS_CHUNK]; };
+// The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload).  The chains are
+// strictly sequential float32 recurrences (same operations, same order as bn_move_var / bn_move_mean), so a read cannot be
+// spread over lanes -- but several READS can share a wave: a workgroup of two waves takes MS_G reads, wave 0 runs their
+// moving variances (lane = read), wave 1 their moving means, one vector instruction advancing all MS_G chains.  Each wave
+// keeps an LDS ring per read, filled with coalesced loads (64 lanes fetch 64 consecutive samples of one read at a time,
+// requested a chunk ahead of the chains) and read by the chains with 16-byte accesses (rows 4 x odd floats apart:
+// conflict-free); the results go back through LDS and leave as coalesced stores.  The kernel is bound by the LATENCY of the
+// longest chain, not by throughput (the same time for 1000 and 4000 reads).  History at the 200 k window, per 4000 reads:
+// one lane per read straight from global memory (k_mvs_series) 38 ms -- the chains waited on scattered loads; one chain per
+// WAVE from LDS 23 ms -- eight waves per SIMD, one lane in 64 working, bound by instruction issue; MS_G chains per wave with
+// the chunk loads waited for one by one 23 ms; with the next chunk's loads in flight during the chains 13 ms.
+#define MS_CHUNK 64
+#define MS_HIST 320   // longest window served
+#define MS_G 16       // reads per wave (= chains advanced by one vector instruction)
+
+// ring of RB floats per read (RB = a power of two >= window + MS_CHUNK): sample i of the slice lives at ring[i & (RB - 1)];
+// rows are RB + 4 floats apart (4 x odd: the 16-byte accesses of the 16 chain lanes fall into different bank groups)
+static __device__ __forceinline__ int ms_ring(int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; }
 
 template <bool VAR>
-static __device__ void ms_chain(const float *__restrict__ x_, int n, int w, float *__restrict__ series_, LDS MsStage *st)
+static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LDS int32_t *a_of, const LDS int32_t *n_of,
+                                 int r0, int n_reads, int w, float *__restrict__ series, int cap, LDS float *buf, LDS float *out)
 {
-    const GLB float *x = (const GLB float *)x_;
-    GLB float *series = (GLB float *)series_;
     const int ln = lane_id();
+    const int RB = ms_ring(w), S = RB + 4, SO = MS_CHUNK + 4, MASK = RB - 1;
+    const int g = ln & (MS_G - 1);
+    const int r = r0 + g;
+    const bool chain = ln < MS_G && r < n_reads;
+    const int n = (r < n_reads) ? n_of[g] : 0;        // every lane knows the length of read (lane % MS_G)
+    int nmax = n;
+#pragma unroll
+    for (int o = MS_G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
     float amean = 0.f, assqdm = 0.f, asum = 0.f;
     int count = 0;
     const float inv = (float)(1.0 / (double)w);
-    const int H = (w + 3) & ~3; // history kept in front of a chunk (a multiple of 4: the chunk's own samples stay 16-byte aligned)
+    LDS float *mybuf = buf + g * S;
+    LDS float *myout = out + g * SO;
     const bool vec = (w & 3) == 0;
-    for (int i0 = 0; i0 < n; i0 += MS_CHUNK) {
-        const int lo = i0 >= H ? i0 - H : 0; // st->buf[k] = x[lo + k]
-        const int hi = min(n, i0 + MS_CHUNK);
+    // lengths and slice starts of the wave's reads in registers (wave-uniform values)
+    int nq[MS_G];
+    const GLB float *xq[MS_G];
+#pragma unroll
+    for (int q = 0; q < MS_G; q++) {
+        nq[q] = (r0 + q < n_reads) ? n_of[q] : 0;
+        xq[q] = (const GLB float *)sigs + (size_t)(r0 + q < n_reads ? r0 + q : r0) * m + a_of[q];
+    }
+    // the samples of the NEXT chunk are requested before the chains of the current one run (one load per read, all in
+    // flight together; waiting for them one by one cost 8 us per chunk) and land in LDS after it
+    float pre[MS_G];
+    auto fetch = [&](int i0) {
+#pragma unroll
+        for (int q = 0; q < MS_G; q++) { const int i = i0 + ln; pre[q] = (i < nq[q]) ? xq[q][i] : 0.f; }
+    };
+    fetch(0);
+    for (int i0 = 0; i0 < nmax; i0 += MS_CHUNK) {
         ws_sync();
-        for (int k = ln; k < hi - lo; k += 64) st->buf[k] = x[lo + k];
+#pragma unroll
+        for (int q = 0; q < MS_G; q++) { const int i = i0 + ln; if (i < nq[q]) buf[q * S + (i & MASK)] = pre[q]; }
         ws_sync();
-        if (ln == 0) {
+        if (i0 + MS_CHUNK < nmax) fetch(i0 + MS_CHUNK);
+        if (chain && i0 < n) {
+            const int hi = min(n, i0 + MS_CHUNK);
             int i = i0;
-            // the window fills (i < w): the reference's first phase, scalar
-            for (; i < hi && i < w; i++) {
-                const float ai = st->buf[i - lo];
+            for (; i < hi && i < w; i++) { // the window fills: the reference's first phase
+                const float ai = mybuf[i & MASK];
                 if (VAR) {
                     count++;
                     const float delta = ai - amean;
                     amean += delta / (float)count;
                     assqdm += delta * (ai - amean);
-                    if (i == w - 1) { if (assqdm < 0) assqdm = 0; st->out[i - i0] = assqdm / (float)count; }
+                    if (i == w - 1) { if (assqdm < 0) assqdm = 0; myout[i - i0] = assqdm / (float)count; }
                 } else {
                     asum += ai;
-                    if (i == w - 1) st->out[i - i0] = asum / (float)w;
+                    if (i == w - 1) myout[i - i0] = asum / (float)w;
                 }
             }
-            // sliding steps, four at a time
-            for (; i + 4 <= hi; i += 4) {
-                float an[4], ao[4], res[4];
-                if (vec && ((i - lo) & 3) == 0) {
-                    const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&st->buf[i - lo]);
-                    const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&st->buf[i - w - lo]);
-                    an[0] = a4.x; an[1] = a4.y; an[2] = a4.z; an[3] = a4.w; ao[0] = o4.x; ao[1] = o4.y; ao[2] = o4.z; ao[3] = o4.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { an[j] = st->buf[i + j - lo]; ao[j] = st->buf[i + j - w - lo]; }
-                }
+            for (; i < hi && (!vec || (i & 3)); i++) { // single sliding steps up to a multiple of 4 (all of them for odd windows)
+                float ai = mybuf[i & MASK], aold = mybuf[(i - w) & MASK];
+                if (VAR) {
+                    const float delta = ai - aold;
+                    aold -= amean; amean += delta * inv; ai -= amean;
+                    assqdm += (ai + aold) * delta;
+                    if (assqdm < 0) assqdm = 0;
+                    myout[i - i0] = assqdm * inv;
+                } else { asum += ai - aold; myout[i - i0] = asum * inv; }
+            }
+            for (; i + 4 <= hi; i += 4) { // four sliding steps on 16-byte LDS accesses
+                const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
+                const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - w) & MASK]);
+                const float an[4] = {a4.x, a4.y, a4.z, a4.w}, ao[4] = {o4.x, o4.y, o4.z, o4.w};
+                float res[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (VAR) {
                         float ai = an[j], aold = ao[j];
                         const float delta = ai - aold;
-                        aold -= amean;
-                        amean += delta * inv;
-                        ai -= amean;
+                        aold -= amean; amean += delta * inv; ai -= amean;
                         assqdm += (ai + aold) * delta;
                         if (assqdm < 0) assqdm = 0;
                         res[j] = assqdm * inv;
-                    } else {
-                        asum += an[j] - ao[j];
-                        res[j] = asum * inv;
-                    }
+                    } else { asum += an[j] - ao[j]; res[j] = asum * inv; }
                 }
-                if (((i - i0) & 3) == 0) { const adp_v4f r4 = {res[0], res[1], res[2], res[3]}; *reinterpret_cast<LDS adp_v4f *>(&st->out[i - i0]) = r4; }
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) st->out[i + j - i0] = res[j];
-                }
+                const adp_v4f r4 = {res[0], res[1], res[2], res[3]};
+                *reinterpret_cast<LDS adp_v4f *>(&myout[i - i0]) = r4;
             }
             for (; i < hi; i++) {
-                float ai = st->buf[i - lo], aold = st->buf[i - w - lo];
+                float ai = mybuf[i & MASK], aold = mybuf[(i - w) & MASK];
                 if (VAR) {
                     const float delta = ai - aold;
-                    aold -= amean;
-                    amean += delta * inv;
-                    ai -= amean;
+                    aold -= amean; amean += delta * inv; ai -= amean;
                     assqdm += (ai + aold) * delta;
                     if (assqdm < 0) assqdm = 0;
-                    st->out[i - i0] = assqdm * inv;
-                } else {
-                    asum += ai - aold;
-                    st->out[i - i0] = asum * inv;
-                }
+                    myout[i - i0] = assqdm * inv;
+                } else { asum += ai - aold; myout[i - i0] = asum * inv; }
             }
         }
         ws_sync();
-        // out[i - i0] is the series value at index i - w + 1 (defined from i = w - 1 on)
-        const int first = i0 > w - 1 ? i0 : w - 1;
-        for (int i = first + ln; i < hi; i += 64) series[i - w + 1] = st->out[i - i0];
+        // out[q][i - i0] is read q's series value at index i - w + 1 (defined from i = w - 1 on): coalesced per read
+#pragma unroll
+        for (int q = 0; q < MS_G; q++) {
+            GLB float *sp = (GLB float *)series + (size_t)(r0 + q < n_reads ? r0 + q : r0) * 2 * cap + (VAR ? cap : 0);
+            const int i = i0 + ln;
+            if (i < nq[q] && i >= w - 1) sp[i - w + 1] = out[q * SO + ln];
+        }
     }
 }
 
-// grid = n_reads; block = 128 (wave 0: moving variance, wave 1: moving mean)
+// grid = ceil(n_reads / MS_G); block = 128 (wave 0: MS_G moving variances, wave 1: MS_G moving means); dynamic LDS
 __global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                          int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
                                                          float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
-    __shared__ MsStage stage_[2];
-    const int wave = threadIdx.x >> 6;
-    LDS MsStage *st = (LDS MsStage *)&stage_[wave];
-    const int r = blockIdx.x;
-    const long long fl = full_len[r];
-    const int S = (int)(fl < m ? fl : m);
-    const long long a_e = bounds[(size_t)r * (1 + kmax)];
-    long long p_e = 0;
-    for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
-    bool ok = !(p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) && !((long long)S < a_e + cfg.median_shift_window);
-    const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
-    const int n = b - a;
-    const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
-    if (ok && ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1)))) ok = false;
-    if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
-    if (threadIdx.x == 0) have[r] = ok ? 1 : 0;
-    if (!ok) return;
-    const float *x = sigs + (size_t)r * m + a;
-    float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
-    if (wave == 0) { if (wvar) ms_chain<true>(x, n, cfg.pA_var_window, svar, st); }
-    else { if (wmean) ms_chain<false>(x, n, cfg.pA_mean_window, smean, st); }
+    extern __shared__ float ms_raw[];
+    __shared__ int32_t a_of_[MS_G], n_of_[MS_G];
+    LDS int32_t *a_of = (LDS int32_t *)a_of_, *n_of = (LDS int32_t *)n_of_;
+    const int wave = threadIdx.x >> 6, ln = lane_id();
+    const int r0 = blockIdx.x * MS_G;
+    if (wave == 0 && ln < MS_G) {
+        const int r = r0 + ln;
+        int a = 0, n = 0;
+        if (r < n_reads) {
+            const long long fl = full_len[r];
+            const int S = (int)(fl < m ? fl : m);
+            const long long a_e = bounds[(size_t)r * (1 + kmax)];
+            long long p_e = 0;
+            for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
+            bool ok = !(p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) && !((long long)S < a_e + cfg.median_shift_window);
+            a = (int)(a_e < S ? a_e : S);
+            const int b = (int)(p_e < S ? p_e : S);
+            n = b - a;
+            // (both series or none: a slice shorter than a window + 2 is k_validate's business, as is a window that does not fit)
+            if (ok && (p_e - a_e <= cfg.pA_var_window + 2 || p_e - a_e <= cfg.pA_mean_window + 2)) ok = false;
+            if (ok && (cfg.pA_var_window > n || cfg.pA_var_window < 1 || cfg.pA_mean_window > n || cfg.pA_mean_window < 1)) ok = false;
+            if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
+            if (!ok) n = 0;
+            have[r] = ok ? 1 : 0;
+        }
+        a_of[ln] = a; n_of[ln] = n;
+    }
+    __syncthreads();
+    const int Sv = ms_ring(cfg.pA_var_window) + 4, Sm = ms_ring(cfg.pA_mean_window) + 4;
+    LDS float *base = (LDS float *)ms_raw;
+    LDS float *buf_v = base, *out_v = buf_v + MS_G * Sv, *buf_m = out_v + MS_G * (MS_CHUNK + 4), *out_m = buf_m + MS_G * Sm;
+    if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_var_window, series, cap, buf_v, out_v);
+    else ms_chains<false>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_mean_window, series, cap, buf_m, out_m);
 }
 
 static __device__ void row_clear(adp_row *row)
