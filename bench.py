@@ -285,7 +285,9 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
 
         lens_host = np.array([_synth.pareto_length(w.seed, rank * R + i) for i in range(R)], dtype=np.int32)
     len_t = torch.from_numpy(lens_host).to(dev)
-    rows_t = torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    # two row buffers: with several ranks the gather of step k (RCCL, its own stream) runs beside the kernels of step k + 1
+    rows_bufs = [torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    rows_t = rows_bufs[0]
     torch.cuda.synchronize()
     # rank r owns reads [r*R, (r+1)*R) of the global stream: contiguous whole minibatches
     for k, e in enumerate(engines):
@@ -299,8 +301,11 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
 
+    state = {"rows": rows_t, "pending": None, "i": 0}
+
     def run_part(k):
         s0 = k * Rs
+        rows_t = state["rows"]
         if w.primary == "cnn":  # one library call (adp_detect_cnn) per engine; find_peaks / row compaction per minibatch
             rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs,
                                               lens_host[s0:s0 + Rs], None, spc, minibatch=mb)
@@ -321,9 +326,19 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             for t in ths:
                 t.join()
         if world > 1:
-            dist.gather(rows_t if backend == "nccl" else rows_t.cpu(), gathered, dst=0)
+            # every detect call ends with its stream drained, so the rows are complete here; the gather is left running
+            # and waited for before the next one starts (and before the clock stops)
+            if state["pending"] is not None:
+                state["pending"].wait()
+            cur = state["rows"]
+            state["pending"] = dist.gather(cur if backend == "nccl" else cur.cpu(), gathered, dst=0, async_op=True)
+            state["i"] += 1
+            state["rows"] = rows_bufs[state["i"] % 2]
 
     def sync():
+        if state["pending"] is not None:
+            state["pending"].wait()
+            state["pending"] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -364,7 +379,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                 traffic["_file"] = "profiles/" + tname
                 break
         rows = np.zeros(R, dtype=lib.ROW_DTYPE)
-        eng.d2h(rows, rows_t.data_ptr())
+        eng.d2h(rows, rows_bufs[(state["i"] - 1) % 2 if world > 1 else 0].data_ptr())  # (the last step's rows)
         n_ok = int(rows["success"].sum())
         kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
         dom = max(kavg, key=kavg.get)
@@ -427,7 +442,8 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             out["cpu_baseline"] = None
     for e in engines:
         e.close()
-    del sig_t, rows_t, len_t
+    del sig_t, rows_t, rows_bufs, len_t
+    state.clear()
     torch.cuda.empty_cache()
     return out
 

@@ -1,6 +1,10 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big | candidates]
+    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big | candidates | cnn | predict]
+cnn: the whole CNN path (prepare -> hand-written conv stack -> predict -> candidate validation, incl. the shared-sweep
+statistics of cand_stats.h at windows beyond 32 k samples -> short-read fallback), the oracle validating the device's
+predictions; predict: cnn_predict on random scores quantised to a coarse grid (ties, plateaus, reads below the mask level)
+against the scipy formulation with a stable priority order.
 """
 import os
 import sys
@@ -17,8 +21,95 @@ from oracle import oracle  # noqa: E402
 from util import row_diffs  # noqa: E402
 
 
+def soak_cnn(rounds):
+    from adapted_amd.detect import cnn
+
+    rng = np.random.default_rng(77)
+    bad_total = 0
+    for it in range(rounds):
+        spc = get_chemistry_specific_config("RNA004")
+        spc.core.max_obs_trace = int(rng.choice([16000, 34000, 60000, 120000, 200000]))
+        spc.cnn_boundaries.polya_cand_k = int(rng.choice([1, 3, 10, 15]))
+        spc.med_shift.detect_med_shift = bool(it % 2)
+        if it % 3 == 2:
+            spc.mvs_polya.pA_var_window = int(rng.choice([50, 100, 200, 101]))
+            spc.mvs_polya.pA_mean_window = int(rng.choice([10, 20, 60, 23]))
+            spc.mvs_polya.median_shift_window = int(rng.choice([500, 1000, 2000]))
+        spc.update_primary_method()
+        spc.update_sig_preload_size()
+        m = spc.sig_preload_size
+        n = 96 if m > 100000 else 192
+        lens = np.array([m if rng.random() < 0.5 else max(1012, synth.pareto_length(it, i, lo=3000, hi=4 * m)) for i in range(n)], dtype=np.int32)
+        sig, lens = synth.synth_batch(300 + it, 0, n, m, lens)
+        step = [0.0, 0.18][it % 2]
+        if step:
+            q = np.float32(step)
+            sig = (np.round(sig / q) * q).astype(np.float32)
+        eng = lib.Engine(spc, n, m, device=0)
+        cnn.ensure_weights(eng, None, spc)
+        mb = n // 2
+        _, bounds = eng.detect_cnn_rows(sig, lens, n, mb)
+        rows = cnn.detect_rows(eng, sig[:mb], lens[:mb], None, spc)
+        rows2 = cnn.detect_rows(eng, sig[mb:], lens[mb:], None, spc)
+        got = lib.rows_to_results(np.concatenate([rows, rows2]), "cnn")
+        want = oracle.detect_cnn_from_preds(sig, lens, bounds, spc)
+        bad = 0
+        shown = 0
+        for i, (g, w) in enumerate(zip(got, want)):
+            d = row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")})
+            bad += len(d)
+            if d and shown < 3:
+                shown += 1
+                print("   read %d (len %d): %s" % (i, lens[i], d[:6]), flush=True)
+        print("cnn round %d T=%d m=%d k=%d step=%.2f windows=(%d,%d) pass=%d/%d all-candidates=%d differing fields: %d" % (
+            it, spc.core.max_obs_trace, m, spc.cnn_boundaries.polya_cand_k, step, spc.mvs_polya.pA_var_window, spc.mvs_polya.pA_mean_window,
+            sum(1 for g in got if g.success), n, int((bounds[:, 1:] != 0).all(axis=1).sum()), bad), flush=True)
+        bad_total += bad
+        eng.close()
+    print("TOTAL differing fields:", bad_total)
+    return 1 if bad_total else 0
+
+
+def soak_predict(rounds):
+    import torch
+    from test_gpu_cnn import _ref_predict
+
+    rng = np.random.default_rng(5)
+    bad_total = 0
+    spc = get_chemistry_specific_config("RNA004")
+    eng = lib.Engine(spc, 512, spc.sig_preload_size, device=0)
+    na = (spc.core.max_obs_adapter - spc.core.min_obs_adapter) // spc.core.downscale_factor
+    k = int(spc.cnn_boundaries.polya_cand_k)
+    for it in range(rounds):
+        n, Lo = int(rng.integers(2, 200)), int(rng.choice([40, 257, 1650, 6001]))
+        grid = float(rng.choice([0.0, 0.5, 1.0, 2.0]))  # a coarse grid makes ties, plateaus and samples equal to the mask level
+        scores = rng.normal(-3.0 if it % 2 else 0.0, 3.0, (n, 2, Lo)).astype(np.float32)
+        if grid:
+            scores = (np.round(scores / grid) * grid).astype(np.float32)
+        scores[rng.random(n) < 0.2, 1, :] -= 12.0  # reads at or below the mask level
+        scores[rng.random(n) < 0.2, 0, 0] = 90.0   # adapter position 0
+        want = _ref_predict(scores, min(na, Lo), k, stable=True)
+        d = torch.from_numpy(scores).cuda()
+        torch.cuda.synchronize()
+        b = eng.cnn_predict(d.data_ptr(), n, n, Lo)
+        got = np.where(b == 0, 0, (b - spc.core.min_obs_adapter) // spc.core.downscale_factor)
+        bad = int((got != want).sum())
+        print("predict round %d n=%d Lo=%d grid=%.1f differing entries: %d" % (it, n, Lo, grid, bad), flush=True)
+        bad_total += bad
+    eng.close()
+    print("TOTAL differing entries:", bad_total)
+    return 1 if bad_total else 0
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    if len(sys.argv) > 2 and sys.argv[2] == "cnn":
+        return soak_cnn(rounds)
+    if len(sys.argv) > 2 and sys.argv[2] == "predict":
+        import torch
+
+        torch.cuda.init()
+        return soak_predict(rounds)
     rng = np.random.default_rng(2024)
     bad_total = 0
     for it in range(rounds):

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Evidence of a round, collected on the GPU box (run through gpurun from the repository root):
+#   tools/profile_round.sh r02
+# writes everything under gpurun_out/<tag>_*; the summaries worth keeping are copied to profiles/ by hand afterwards
+# (profiles/summarize_pmc.py, profiles/summarize_sq.py).  Counter passes run on their own (no --stats / trace domains with --pmc).
+set -e
+TAG=${1:-r02}
+export TMPDIR=/tmp
+OUT=gpurun_out
+BENCH="python3 bench.py --steps 6 --warmup 2"
+# 1. the default run (headline + secondaries + CPU baselines), plain
+$BENCH > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+# 2. the same command under the kernel trace (per-kernel average durations)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o run -- $BENCH --cpu-sample 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.err
+# 3. HBM traffic of the headline workload at its real launch size (96 000 reads): FETCH_SIZE and WRITE_SIZE in separate passes
+LLR="python3 bench.py --steps 2 --warmup 1 --no-secondary --cpu-sample 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o run --output-format csv -- $LLR > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run --output-format csv -- $LLR > /dev/null 2> $OUT/${TAG}_pmc_write.err
+# 4. the CNN step at the 200 k window: kernel stats, matrix-core counters, traffic
+CNN="python3 bench.py --primary cnn --reads 4000 --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cnn_stats -o run -- $CNN > $OUT/${TAG}_cnn_under_rocprof.json 2> $OUT/${TAG}_cnn_under_rocprof.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_cnn_pmc_sq -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_sq.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_cnn_pmc_fetch -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_cnn_pmc_write -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_write.err
+ls $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_cnn_stats
