@@ -418,7 +418,8 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
 
 // N1 for all minibatches (n1_select.h): sampled guess, then ONE verified full pass per statistic when the copied
 // bracket holds the rank (k_n1_finish), else the second pass; a missed window falls back to the aligned path.
-static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int minibatch, int n_mb, bool profile,
+template <class SIG>
+static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch, int n_mb, bool profile,
                      const int32_t *tails = nullptr) // tails: full_len when ADP_TAILS_NAN holds
 {
     hipStream_t st = h->stream;
@@ -452,40 +453,40 @@ static int launch_n1(adp_handle *h, const float *dsig, int n, int m, int T, int 
         HIPCHK(hipMemsetAsync(hvy, 0, (size_t)n_mb * N1H_WORDS * 4, st));
         { Scope s(h, !profile ? nullptr : "k_n1 sample passes");
         for (int mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
+            hipLaunchKernelGGL((k_n1_hist<0, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-            hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
+            hipLaunchKernelGGL((k_n1_hist<1, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
             hipLaunchKernelGGL(k_n1_fuse_setup, dim3((n_mb + 63) / 64), dim3(64), 0, st, mbs, fz, n_mb, mode);
         }
         // values shared by many of the samples to copy (quantised data): found in the sample, counted instead of copied
         // (a quarter of the sampled rows is plenty to see ties)
-        hipLaunchKernelGGL(k_n1_heavy_scan, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div, pdiv, tails);
+        hipLaunchKernelGGL(k_n1_heavy_scan<SIG>, dim3((sb + 3) / 4, n_mb), dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, hvy, row_step * 4, col_div, pdiv, tails);
         hipLaunchKernelGGL(k_n1_heavy_pick, pg, dim3(64), 0, st, mbs, fz, hvy, n_mb); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused");
-          hipLaunchKernelGGL(k_n1_fused, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy, tails); }
+          hipLaunchKernelGGL(k_n1_fused<SIG>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mbs, fz, fc, (float *)cb, hvy, tails); }
         { Scope s(h, !profile ? nullptr : "k_n1_fused_finish");
           hipLaunchKernelGGL(k_n1_fused_finish, pg, dim3(1024), 0, st, mbs, fz, fc, (const float *)cb, thr, (const uint32_t *)hvy); }
     }
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample
-        hipLaunchKernelGGL(k_n1_hist<0>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
+        hipLaunchKernelGGL((k_n1_hist<0, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
         hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
+        hipLaunchKernelGGL((k_n1_hist<1, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
         hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 1 over everything, verified
         { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<1> mad" : "k_n1_hist<1> med"));
-          hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS, cb, collect, 1, 8, tails); }
+          hipLaunchKernelGGL((k_n1_hist<1, SIG>), hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_ALWAYS, cb, collect, 1, 8, tails); }
         hipLaunchKernelGGL((k_n1_pick<1, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         hipLaunchKernelGGL(k_n1_finish, pg, dim3(1024), 0, st, mbs, cb, gc, gb, mode, thr);
         // fallback (runs only for minibatches whose guess missed)
-        hipLaunchKernelGGL(k_n1_hist<0>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
+        hipLaunchKernelGGL((k_n1_hist<0, SIG>), hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
         hipLaunchKernelGGL((k_n1_pick<0, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
-        hipLaunchKernelGGL(k_n1_hist<1>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
+        hipLaunchKernelGGL((k_n1_hist<1, SIG>), hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_BAD, cb, 0, 1, 8, tails);
         hipLaunchKernelGGL((k_n1_pick<1, N1_FALLBACK>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
         // pass 2 (only where the bracket did not settle it)
         { Scope s(h, !profile ? nullptr : (mode ? "k_n1_hist<2> mad" : "k_n1_hist<2> med"));
-          hipLaunchKernelGGL(k_n1_hist<2>, hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_NOT_DONE, cb, 0, 1, 8, tails); }
+          hipLaunchKernelGGL((k_n1_hist<2, SIG>), hg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, 1, N1_IF_NOT_DONE, cb, 0, 1, 8, tails); }
         hipLaunchKernelGGL((k_n1_pick<2, N1_FULL>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
     }
     return 0;
@@ -521,7 +522,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
         const int32_t *tails = (flags & ADP_TAILS_NAN) ? dlen : nullptr;
-        rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true, tails);
+        rc = launch_n1(h, SigF32{dsig}, n, m, T, minibatch, n_mb, true, tails);
         if (rc) return rc;
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
@@ -536,7 +537,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
                 HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope)
                 rng = h->rng0.as<int64_t>();
             }
-            hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+            hipLaunchKernelGGL(k_norm_pool<SigF32>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, SigF32{dsig}, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), rng,
                                dlen, (flags & ADP_TAILS_NAN) ? 1 : 0);
         }
@@ -548,7 +549,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             HIPCHK(hipEventRecord(h->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             { Scope s(h, "k_start_peak", h->stream2);
-              hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, h->stream2, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+              hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, h->stream2, SigF32{dsig}, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
             HIPCHK(hipEventRecord(h->ev_join, h->stream2));
             sp_forked = true;
         }
@@ -594,7 +595,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             if (sp_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
             else {
                 Scope s(h, "k_start_peak");
-                hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>());
+                hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{dsig}, dlen, n, m, h->cfg, h->sp.as<SpOut>());
             }
             hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
                                (const int32_t *)nullptr);
@@ -709,7 +710,7 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
         const int32_t *ln = dlen + s0;
         HIPCHK(hipMemsetAsync(h->any_none.p, 0, 4, st));
         { Scope s(h, "k_start_peak");
-          hipLaunchKernelGGL(k_start_peak, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, sg, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
+          hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{sg}, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
         hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
                            h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
         rc = launch_validate(h, sg, ln, n, m, 1, minibatch, false);
@@ -1023,9 +1024,9 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n * 8, st));
     HIPCHK(hipMemsetAsync(h->adapter_idx.p, 0, (size_t)n * 4, st));
     HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n * 8 * N1_NCNT, st));
-    rc = launch_n1(h, dsig, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
+    rc = launch_n1(h, SigF32{dsig}, n, m, h->T, 1, n, false); // per-read normalisation: every read is its own minibatch
     if (rc) return rc;
-    hipLaunchKernelGGL(k_norm_pool, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
+    hipLaunchKernelGGL(k_norm_pool<SigF32>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, SigF32{dsig}, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>());

@@ -56,6 +56,90 @@ static __device__ __forceinline__ float fdiv_shared(float a, float d, float y)
     return __builtin_fmaf(r, y, q0);
 }
 
+// ---------------------------------------------------------------- the resident signal matrix
+// The reference's minibatch layout is float32 pA [n, m], NaN from each read's end on (adapted/file_proc.py:143-190): SigF32.
+// SigI16 is the same matrix as the sequencer stores it -- raw int16 ADC samples [n, m] plus a per-read calibration,
+// pA = scale * (float32(adc) + offset) (pod5's calibrate_signal_array; both operations rounded to float32, never fused) --
+// turned into the float32 value in registers, bit-identical to adp_calibrate_i16's output, so that every streaming pass
+// moves 2 bytes per sample instead of 4.  Samples at or beyond min(full_len, m) read as NaN, like the padding they replace.
+// Kernels take the matrix type as a template parameter and go through a Row: row[i], row + k (a row that starts k samples
+// later), row.f4(q) / row.f4s(q) (samples 4q .. 4q+3 of a row whose start is 16-byte / 8-byte aligned; f4s = streaming
+// hint), row.f4u(i) (four samples from any position i).
+typedef float adp_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef short adp_s4 __attribute__((ext_vector_type(4)));
+typedef short adp_s4u __attribute__((ext_vector_type(4), aligned(2)));
+
+struct RowF32 {
+    const GLB float *p;
+    __device__ __forceinline__ float operator[](long long i) const { return p[i]; }
+    __device__ __forceinline__ RowF32 operator+(long long k) const { return RowF32{p + k}; }
+    __device__ __forceinline__ float4 f4(long long q) const { const adp_v4f v = reinterpret_cast<const GLB adp_v4f *>(p)[q]; return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ float4 f4s(long long q) const
+    {
+        const adp_v4f v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_v4f *>(p) + q);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ float4 f4u(long long i) const
+    {
+        const adp_f4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_f4u *>(p + i));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+    __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
+    __device__ __forceinline__ long long diff(const RowF32 &o) const { return p - o.p; }
+};
+
+struct RowI16 {
+    const GLB int16_t *p;
+    float sc, of;
+    int n; // samples that exist from p on (may be <= 0): the rest is the NaN padding
+    __device__ __forceinline__ float cal(short a) const { const float t = (float)a + of; return sc * t; }
+    __device__ __forceinline__ float operator[](long long i) const { return i < n ? cal(p[i]) : __builtin_nanf(""); }
+    __device__ __forceinline__ RowI16 operator+(long long k) const { return RowI16{p + k, sc, of, (int)(n - k)}; }
+    __device__ __forceinline__ float4 conv4(adp_s4 v, long long i) const
+    {
+        const float nanv = __builtin_nanf("");
+        float4 r = make_float4(cal(v.x), cal(v.y), cal(v.z), cal(v.w));
+        if (i + 3 >= n) { if (i >= n) r.x = nanv; if (i + 1 >= n) r.y = nanv; if (i + 2 >= n) r.z = nanv; r.w = nanv; }
+        return r;
+    }
+    __device__ __forceinline__ float4 f4(long long q) const { return conv4(reinterpret_cast<const GLB adp_s4 *>(p)[q], 4 * q); }
+    __device__ __forceinline__ float4 f4s(long long q) const { return conv4(__builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4 *>(p) + q), 4 * q); }
+    __device__ __forceinline__ float4 f4u(long long i) const
+    {
+        const adp_s4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4u *>(p + i));
+        const adp_s4 w = {v.x, v.y, v.z, v.w};
+        return conv4(w, i);
+    }
+    __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+    __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
+    __device__ __forceinline__ long long diff(const RowI16 &o) const { return p - o.p; }
+};
+
+struct SigF32 {
+    typedef RowF32 Row;
+    const float *base;
+    __device__ __forceinline__ Row row(long long r, int m) const { return Row{(const GLB float *)base + (size_t)r * m}; }
+    __device__ __forceinline__ bool vec_ok(int m) const { return (m & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0; }
+};
+struct SigI16 {
+    typedef RowI16 Row;
+    const int16_t *base;
+    const float *scale, *offset;
+    const int32_t *full_len;
+    __device__ __forceinline__ Row row(long long r, int m) const
+    {
+        const int fl = full_len[r];
+        return Row{(const GLB int16_t *)base + (size_t)r * m, scale[r], offset[r], fl < m ? (fl > 0 ? fl : 0) : m};
+    }
+    __device__ __forceinline__ bool vec_ok(int m) const { return (m & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 7) == 0; }
+};
+// plain float arrays (series, pooled values, copies) go through the same helpers as rows
+static __device__ __forceinline__ RowF32 as_row(const float *p) { return RowF32{(const GLB float *)p}; }
+static __device__ __forceinline__ RowF32 as_row(float *p) { return RowF32{(const GLB float *)p}; }
+static __device__ __forceinline__ RowF32 as_row(RowF32 r) { return r; }
+static __device__ __forceinline__ RowI16 as_row(RowI16 r) { return r; }
+
 static __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // order-preserving float32 <-> uint32 key

@@ -30,7 +30,8 @@ __device__ const double g_logcr_table[3 * LOGCR_N] = LOGCR_TABLE;
 // ranges != nullptr (CNN fallback C4): per-read pooled region [ranges[2r], min(ranges[2r+1], T, full_len))
 // tails_nan (ADP_TAILS_NAN): the row is NaN padding from full_len[r] on -- pooled blocks that reach into it are NaN without
 // being read
-__global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig, int m, int T, int off, int ds, int L, int Lp,
+template <class SIG>
+__global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
                                                    float *__restrict__ down, int32_t *__restrict__ nvalid,
                                                    const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len,
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
         L = (Lseg + ds - 1) / ds;
         if (L > Lp) L = Lp;
     }
-    const float *row = sig + (size_t)r * m + off;
+    const typename SIG::Row row = sig.row(r, m) + off;
     if (threadIdx.x == 0) s_nan = 0;
     int my_nan = 0;
     // pooled blocks worth computing: all of them, or only those that end before the padding starts
@@ -62,7 +63,7 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
         if (lv < Lseg) { if (lv < 0) lv = 0; L_ok = (int)(lv / ds); }
     }
     const int tile_n = NP_TILE * ds; // samples per tile (NP_TILE pooled outputs, 2 per thread)
-    const bool vec = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) && ((tile_n & 3) == 0);
+    const bool vec = row.vec_ok() && ((tile_n & 3) == 0);
     // every sample of the minibatch is divided by the same MAD: one IEEE division for its reciprocal, then three
     // operations per sample that return the bits of the IEEE quotient (fdiv_shared, common.h)
     const bool fast_div = fdiv_ok(mad);
@@ -80,11 +81,11 @@ __global__ void __launch_bounds__(256) k_norm_pool(const float *__restrict__ sig
         }
         __syncthreads();
         if (vec) {
-            const float4 *row4 = reinterpret_cast<const float4 *>(row + base);
+            const typename SIG::Row rowb = row + base;
             for (int q = threadIdx.x; q < tile_n / 4; q += 256) {
                 const int idx = base + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // np.pad(..., mode="constant") for a ragged tail
-                if (idx + 3 < Lseg) { v = ld_stream4(&row4[q]); v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
+                if (idx + 3 < Lseg) { v = rowb.f4s(q); v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
                 else {
                     if (idx < Lseg) v.x = norm1(row[idx]);
                     if (idx + 1 < Lseg) v.y = norm1(row[idx + 1]);

@@ -104,7 +104,8 @@ __global__ void k_n1_fuse_setup(MbState *__restrict__ mbs, N1Fused *__restrict__
 // The sample once more (same rows and columns as the sample passes): the keys of the points that the pass would copy,
 // with their multiplicities -- per block in LDS, then only the repeated ones (>= 4 in this block's share) to the
 // minibatch's table.
-__global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
+template <class SIG>
+__global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(SIG sig, int n_reads, int m, int T, int mbsize,
                                                                const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
                                                                uint32_t *__restrict__ hv, int row_step, int col_div, int pdiv,
                                                                const int32_t *__restrict__ full_len)
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(const float *__res
     const float D0 = f.wide_ok ? f.D0w : f.D0, D1 = f.wide_ok ? f.D1w : f.D1; // (the band the pass will use if keys turn out heavy)
     uint32_t nin = 0;
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
-        const float *row = sig + (size_t)r * m;
+        const typename SIG::Row row = sig.row(r, m);
         // (the pieces of the sample passes, n1_select.h)
         const int npc = col_div > 1 ? col_div : 1;
         const int Rg = col_div > 1 ? ((T / col_div) & ~3) : 0, Tp = col_div > 1 ? ((T / (col_div * pdiv)) & ~3) : T;
@@ -257,7 +258,8 @@ static __device__ __forceinline__ void n1f_account(float x, float med_s, float A
 }
 
 // grid = (blocks_per_minibatch, n_minibatch); block = N1_THREADS
-__global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
+template <class SIG>
+__global__ void __launch_bounds__(N1_THREADS) k_n1_fused(SIG sig, int n_reads, int m, int T, int mbsize,
                                                           const MbState *__restrict__ mbs, const N1Fused *__restrict__ fz,
                                                           unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf,
                                                           uint32_t *__restrict__ hv, const int32_t *__restrict__ full_len)
@@ -284,7 +286,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
     const int r1 = min(n_reads, r0 + mbsize);
     const float med_s = f.med_s, A0 = f.A0, A1 = f.A1, D0 = f.D0, D1 = f.D1;
     N1FAcc a; a.nvalid = 0; a.nbelow = 0; a.ninner = 0;
-    const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
+    const bool vec = sig.vec_ok(m);
     float *dstm = cbuf + (size_t)mb * N1_CB_CAP;
     float *dstb = dstm + N1F_MCAP;
 #define ACC(xx) n1f_account(xx, med_s, A0, A1, D0, D1, a, cbm, cbb, cnt2, nh, hkeys, hcnt)
@@ -310,20 +312,18 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
         __syncthreads();
     };
     for (int r = r0 + blockIdx.x; r < r1; r += gridDim.x) {
-        const float *row = sig + (size_t)r * m;
+        const typename SIG::Row row = sig.row(r, m);
         int Te = T; // ADP_TAILS_NAN: the NaN padding behind the read's end counts for nothing and is not read
         if (full_len) { const int fl = full_len[r]; Te = fl < T ? (fl > 0 ? fl : 0) : T; }
         if (vec) {
             const int T4 = Te >> 2;
-            const float4 *row4 = reinterpret_cast<const float4 *>(row);
             // the row in eight parts, the staging lists flushed after each: small lists leave LDS for 8 blocks per CU
             const int q4 = ((T4 + 7) / 8 + 2 * N1_THREADS - 1) / (2 * N1_THREADS) * (2 * N1_THREADS);
             for (int seg = 0; seg < T4; seg += q4) {
                 const int send = min(T4, seg + q4);
                 int i = seg + threadIdx.x;
                 for (; i + 3 * N1_THREADS < send; i += 4 * N1_THREADS) { // four loads in flight per lane (-3 % against two)
-                    float4 v0 = ld_stream4(&row4[i]), v1 = ld_stream4(&row4[i + N1_THREADS]), v2 = ld_stream4(&row4[i + 2 * N1_THREADS]),
-                           v3 = ld_stream4(&row4[i + 3 * N1_THREADS]);
+                    float4 v0 = row.f4s(i), v1 = row.f4s(i + N1_THREADS), v2 = row.f4s(i + 2 * N1_THREADS), v3 = row.f4s(i + 3 * N1_THREADS);
                     const float e[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
                     uint32_t fl = 0;
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
                     }
                 }
                 for (; i + N1_THREADS < send; i += 2 * N1_THREADS) { // two loads in flight per lane
-                    float4 v = ld_stream4(&row4[i]), w = ld_stream4(&row4[i + N1_THREADS]);
+                    float4 v = row.f4s(i), w = row.f4s(i + N1_THREADS);
                     const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
                     uint32_t fl = 0;
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(const float *__restrict
                         n1f_copy(x, med_s, D0, cbm, cbb, cnt2, nh, hkeys, hcnt);
                     }
                 }
-                for (; i < send; i += N1_THREADS) { float4 v = row4[i]; ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
+                for (; i < send; i += N1_THREADS) { float4 v = row.f4(i); ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
                 if (send == T4) for (int j = (T4 << 2) + threadIdx.x; j < Te; j += N1_THREADS) ACC(row[j]);
                 flush();
             }

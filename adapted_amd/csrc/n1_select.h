@@ -77,8 +77,8 @@ static __device__ __forceinline__ void n1_account(float x, int mode, float med, 
 }
 
 // grid = (blocks_per_minibatch, n_minibatch); block = N1_THREADS.  Rows r0 + j*row_step of the minibatch.
-template <int PASS>
-__global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict__ sig, int n_reads, int m, int T, int mbsize,
+template <int PASS, class SIG>
+__global__ void __launch_bounds__(N1_THREADS) k_n1_hist(SIG sig, int n_reads, int m, int T, int mbsize,
                                                          int mode, const MbState *__restrict__ mbs, uint32_t *__restrict__ ghist,
                                                          uint32_t *__restrict__ gbelow, unsigned long long *__restrict__ gcnt,
                                                          int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div, int pdiv = 8,
@@ -104,9 +104,9 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
     const float med = st.med;
     const uint32_t kbase = st.kbase;
     N1Acc a; a.below = 0; a.d_prev = 0xffffffffu; a.run = 0; a.nvalid = 0; a.nbelow = 0; a.below2 = 0; a.nbelow2 = 0;
-    const bool vec = ((m & 3) == 0) && ((reinterpret_cast<uintptr_t>(sig) & 15) == 0);
+    const bool vec = sig.vec_ok(m);
     for (long long r = r0 + (long long)blockIdx.x * row_step; r < r1; r += (long long)gridDim.x * row_step) {
-        const float *row = sig + (size_t)r * m;
+        const typename SIG::Row row = sig.row(r, m);
         // ADP_TAILS_NAN: everything from the read's end on is NaN padding, which counts for nothing here
         int Te = T;
         if (full_len) { const int fl = full_len[r]; Te = fl < T ? (fl > 0 ? fl : 0) : T; }
@@ -118,12 +118,11 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
             const int rot = (int)(((r - r0) / row_step) % pdiv);
             if (vec) { // all pieces of the row as one index space: (piece, float4 inside it)
                 const int p4 = Tp >> 2, tot4 = col_div * p4;
-                const float4 *row4 = reinterpret_cast<const float4 *>(row);
                 const int rg4 = Rg >> 2, off4 = (rot * Tp) >> 2;
                 for (int i = threadIdx.x; i < tot4; i += N1_THREADS) {
                     const int pc = i / p4, j = i - pc * p4;
                     if (4 * (pc * rg4 + off4 + j) >= Te) continue;
-                    float4 v = row4[pc * rg4 + off4 + j];
+                    float4 v = row.f4(pc * rg4 + off4 + j);
                     n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                     n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
@@ -139,9 +138,8 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(const float *__restrict_
             }
         } else if (vec) {
             const int T4 = Te >> 2;
-            const float4 *row4 = reinterpret_cast<const float4 *>(row);
             for (int i = threadIdx.x; i < T4; i += N1_THREADS) {
-                float4 v = row4[i];
+                float4 v = row.f4(i);
                 n1_account<PASS>(v.x, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                 n1_account<PASS>(v.y, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);
                 n1_account<PASS>(v.z, mode, med, kbase, hist, a, cklo, ckw, cb, cb_cnt);

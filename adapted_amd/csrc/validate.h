@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
     for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
         adp_row *row = rows + r;
         row_clear(row);
-        if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = nullptr; sc->n = 0; } }
+        if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = 0; sc->n = 0; } }
         if (in.mbs && in.mbs[r / in.mbsize].status != ADP_MB_OK) continue; // dropped minibatch: zero row
         const float *sig = in.sig + (size_t)r * in.m;
         const long long full_len = in.full_len[r];
@@ -847,7 +847,8 @@ struct SpOut {
     float start_peak_pa, next_greater_pa;
 };
 
-static __device__ __forceinline__ float sp_pooled(const float *row, int m, int ds, int j)
+template <class ROW>
+static __device__ __forceinline__ float sp_pooled(ROW row, int m, int ds, int j)
 {
     // mean-pool of the RAW signal, zero padded tail, numpy order
     const int b = j * ds;
@@ -858,9 +859,9 @@ static __device__ __forceinline__ float sp_pooled(const float *row, int m, int d
 // (lane-strided scalar loads of ds samples each keep the texture-address unit busy ~4x longer), then lane l pools
 // its ds samples from LDS in numpy's order.  Samples at or beyond m count as zero (np.pad).
 typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
-static __device__ __forceinline__ float sp_pooled_tile(const float *row_, int m, int ds, int j0, LDS float *tile)
+template <class ROW>
+static __device__ __forceinline__ float sp_pooled_tile(ROW row, int m, int ds, int j0, LDS float *tile)
 {
-    const GLB float *row = (const GLB float *)row_;
     const int ln = lane_id();
     const long long b0 = (long long)j0 * ds;
     const int nt = 64 * ds;
@@ -868,7 +869,7 @@ static __device__ __forceinline__ float sp_pooled_tile(const float *row_, int m,
     for (int q = ln * 4; q < nt; q += 256) {
         const long long i = b0 + q;
         float x0 = 0.f, x1 = 0.f, x2 = 0.f, x3 = 0.f;
-        if (i + 3 < m) { sp_f4u v = *reinterpret_cast<const GLB sp_f4u *>(row + i); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
+        if (i + 3 < m) { const float4 v = row.f4u(i); x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w; }
         else { if (i < m) x0 = row[i]; if (i + 1 < m) x1 = row[i + 1]; if (i + 2 < m) x2 = row[i + 2]; }
         tile[q] = x0; if (q + 1 < nt) tile[q + 1] = x1; if (q + 2 < nt) tile[q + 2] = x2; if (q + 3 < nt) tile[q + 3] = x3;
     }
@@ -878,14 +879,15 @@ static __device__ __forceinline__ float sp_pooled_tile(const float *row_, int m,
 }
 
 // detect_rna_start_peak (reference adapted/detect/start_peak.py:7-119); grid = n_reads waves; dynamic LDS = 64 * ds floats
-__global__ void __launch_bounds__(64) k_start_peak(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+template <class SIG>
+__global__ void __launch_bounds__(64) k_start_peak(SIG sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                    int m, adp_cfg cfg, SpOut *__restrict__ out)
 {
     extern __shared__ float sp_tile_raw[];
     LDS float *tile = (LDS float *)sp_tile_raw;
     const int r = blockIdx.x;
     const int ln = lane_id();
-    const float *row = sigs + (size_t)r * m;
+    const typename SIG::Row row = sigs.row(r, m);
     const int ds = cfg.sp_downscale_factor;
     const int off1 = cfg.sp_offset1, spmax = cfg.start_peak_max_idx, off2 = cfg.sp_offset2;
     const long long fl = full_len[r];

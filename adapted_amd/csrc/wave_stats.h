@@ -40,7 +40,7 @@ struct WaveScratch {
 #define WS_SEG_CAP 6144
 struct SegCache {
     float seg[WS_SEG_CAP];
-    const float *src; // global range currently mirrored: [src, src + n)
+    uintptr_t src;    // address of the global range currently mirrored: n samples from there
     int n;
 };
 
@@ -152,10 +152,12 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
         if (have) vkm1 = key2f(mn + d0);
     }
 }
-static __device__ __noinline__ void wave_select2_global(const float *__restrict__ x, int n, int k, int mode, float c,
+// x: a signal row (RowF32 / RowI16, common.h) or a plain float array in global memory
+template <class X>
+static __device__ __noinline__ void wave_select2_global(X x, int n, int k, int mode, float c,
                                                         LDS WaveScratch *ws, float &vk, float &vkm1)
 {
-    wave_select2_impl<const GLB float *>((const GLB float *)x, n, k, mode, c, ws, vk, vkm1);
+    wave_select2_impl<X>(x, n, k, mode, c, ws, vk, vkm1);
 }
 static __device__ __noinline__ void wave_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                                      float &vk, float &vkm1)
@@ -165,28 +167,32 @@ static __device__ __noinline__ void wave_select2_lds(const LDS float *x, int n, 
 
 // x_(k), x_(k-1) of xform(x[0..n)); with a SegCache the slice is mirrored into LDS first (reused while the
 // requested range stays inside the mirrored one)
-static __device__ void wave_select2(const float *x, int n, int k, int mode, float c, LDS WaveScratch *ws, float &vk,
+template <class X>
+static __device__ void wave_select2(X x, int n, int k, int mode, float c, LDS WaveScratch *ws, float &vk,
                                     float &vkm1, LDS SegCache *sc = nullptr)
 {
     if (sc && n <= WS_SEG_CAP) {
-        const float *src = sc->src;
+        const uintptr_t src = sc->src;
         const int cn = sc->n;
-        if (!(src && x >= src && x + n <= src + cn)) {
+        long long d = 0;
+        bool hit = false;
+        if (src && x.key() >= src) { d = (long long)(x.key() - src) / (long long)sizeof(*x.p); hit = d + n <= cn; }
+        if (!hit) {
             ws_sync();
             for (int i = lane_id(); i < n; i += 64) sc->seg[i] = x[i];
-            if (lane_id() == 0) { sc->src = x; sc->n = n; }
+            if (lane_id() == 0) { sc->src = x.key(); sc->n = n; }
             ws_sync();
-            src = x;
+            d = 0;
         }
-        wave_select2_lds(sc->seg + (x - src), n, k, mode, c, ws, vk, vkm1);
+        wave_select2_lds(sc->seg + d, n, k, mode, c, ws, vk, vkm1);
     } else {
-        wave_select2_global(x, n, k, mode, c, ws, vk, vkm1);
+        wave_select2_global<X>(x, n, k, mode, c, ws, vk, vkm1);
     }
 }
 
 // np.median(xform(x[0..n))) for a NaN-free float32 segment
-static __device__ __noinline__ float wave_median(const float *x, int n, int mode, float c, LDS WaveScratch *ws,
-                                                 LDS SegCache *sc = nullptr)
+template <class X>
+static __device__ __noinline__ float wave_median_t(X x, int n, int mode, float c, LDS WaveScratch *ws, LDS SegCache *sc = nullptr)
 {
     if (n <= 0) return __builtin_nanf("");
     float vk, vkm1;
@@ -197,8 +203,15 @@ static __device__ __noinline__ float wave_median(const float *x, int n, int mode
 
 // one np.percentile(x, q) value (linear method): virtual index (n-1)*q/100 in float64,
 // diff in float32, interpolation in float64 (numpy/lib/_function_base_impl.py _lerp)
-static __device__ __noinline__ double wave_percentile(const float *x, int n, double q100, LDS WaveScratch *ws,
-                                                      LDS SegCache *sc = nullptr)
+template <class X>
+static __device__ __forceinline__ float wave_median(X x, int n, int mode, float c, LDS WaveScratch *ws, LDS SegCache *sc = nullptr)
+{
+    const auto r = as_row(x); // (a plain float pointer becomes a RowF32)
+    return wave_median_t<decltype(as_row(x))>(r, n, mode, c, ws, sc);
+}
+
+template <class X>
+static __device__ __noinline__ double wave_percentile_t(X x, int n, double q100, LDS WaveScratch *ws, LDS SegCache *sc = nullptr)
 {
     double q = q100 / 100.0;
     double vi = (double)(n - 1) * q;
@@ -217,10 +230,18 @@ static __device__ __noinline__ double wave_percentile(const float *x, int n, dou
     return r;
 }
 
+template <class X>
+static __device__ __forceinline__ double wave_percentile(X x, int n, double q100, LDS WaveScratch *ws, LDS SegCache *sc = nullptr)
+{
+    const auto r = as_row(x);
+    return wave_percentile_t<decltype(as_row(x))>(r, n, q100, ws, sc);
+}
+
 // ---------------------------------------------------------------- numpy-ordered sums
 // numpy's pairwise recursion, iteratively: a node longer than 128 splits into (n2, len - n2) with
 // n2 = (len/2) rounded down to a multiple of 8.  Leaves are visited left to right.
-static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int len0, int mode, float c, LDS WaveScratch *ws, int &id)
+template <class X>
+static __device__ __noinline__ void ws_enum_leaves(X x, int off0, int len0, int mode, float c, LDS WaveScratch *ws, int &id)
 {
     int st_off[16], st_len[16];
     int sp = 0;
@@ -235,7 +256,7 @@ static __device__ __noinline__ void ws_enum_leaves(const float *x, int off0, int
             len = n2;                                           // descend left
         }
         if ((id & 63) == lane_id()) {
-            const GLB float *p = (const GLB float *)x + off;
+            const X p = x + off;
             ws->leaf[id] = pw_leaf_f32(len, [&](int i) { return ws_xform(p[i], mode, c); });
         }
         id++;
@@ -264,7 +285,8 @@ static __device__ __noinline__ float ws_eval_tree(int len0, const LDS WaveScratc
 }
 
 // np.add.reduce(xform(x[0..n))) in float32 with numpy's association
-static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, int n, int mode, float c, LDS WaveScratch *ws)
+template <class X>
+static __device__ __noinline__ float wave_np_sum_t(X x, int n, int mode, float c, LDS WaveScratch *ws)
 {
     const int ln = lane_id();
     float total = 0.0f;
@@ -276,14 +298,14 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
             // accumulator chains (16 samples); xor-shuffles fold the accumulators, then the 8 leaves (three levels of
             // the balanced tree); the 8 phase sums make the top three levels
             float ph[8];
-            const GLB float *p = (const GLB float *)x + s;
+            const X p = x + s;
 #pragma unroll
             for (int phs = 0; phs < 8; phs++) {
                 ws_sync();
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int e = (u * 64 + ln) * 4;
-                    const GLB float *q4 = p + phs * 1024 + e;
+                    const X q4 = p + (phs * 1024 + e);
                     float a0 = ws_xform(q4[0], mode, c), a1 = ws_xform(q4[1], mode, c), a2 = ws_xform(q4[2], mode, c), a3 = ws_xform(q4[3], mode, c);
                     LDS float *d = ws->stage + (e >> 7) * WS_LEAF_STRIDE + (e & 127);
                     d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
@@ -315,10 +337,19 @@ static __device__ __noinline__ float wave_np_sum(const float *__restrict__ x, in
     return total;
 }
 
-static __device__ float wave_np_mean(const float *x, int n, LDS WaveScratch *ws) { return wave_np_sum(x, n, 0, 0.0f, ws) / (float)n; }
+template <class X>
+static __device__ __forceinline__ float wave_np_sum(X x, int n, int mode, float c, LDS WaveScratch *ws)
+{
+    const auto r = as_row(x);
+    return wave_np_sum_t<decltype(as_row(x))>(r, n, mode, c, ws);
+}
+
+template <class X>
+static __device__ float wave_np_mean(X x, int n, LDS WaveScratch *ws) { return wave_np_sum(x, n, 0, 0.0f, ws) / (float)n; }
 
 // np.var: mean in float32, squared deviations in float32, sum / n
-static __device__ float wave_np_var(const float *x, int n, LDS WaveScratch *ws, float *mean_out)
+template <class X>
+static __device__ float wave_np_var(X x, int n, LDS WaveScratch *ws, float *mean_out)
 {
     float mu = wave_np_mean(x, n, ws);
     if (mean_out) *mean_out = mu;
