@@ -351,10 +351,11 @@ static void sync_ablate(hipStream_t st)
     }
 }
 
-static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
+template <class SIG>
+static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
                            bool gate_mb)
 {
-    ValidateIn in;
+    ValidateInT<SIG> in;
     in.sig = dsig; in.full_len = dlen; in.bounds = h->bounds.as<int64_t>(); in.topk_none = h->topk_none.as<int8_t>();
     in.kmax = kmax; in.n_reads = n; in.m = m; in.mbsize = mbsize;
     in.mbs = gate_mb ? h->mbs.as<MbState>() : nullptr;
@@ -363,32 +364,37 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
     // window, not MVS_CAP, bounds them), then the order statistics of all candidates in shared sweeps (cand_stats.h)
     // (below ~32 k samples of preload the slices are short enough for k_validate's own wave-per-read statistics, which then
     // cost less than the workgroup-per-read sweeps: 14 vs 51 ms per 32 000 reads at the default window)
-    const bool multi = kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite && h->m > 32768 &&
+    const bool multi = std::is_same<SIG, SigF32>::value && kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite && h->m > 32768 &&
                        h->cfg.pA_var_window <= MS_HIST && h->cfg.pA_mean_window <= MS_HIST;
     const int cap = multi ? h->vstride : MVS_CAP;
     if (multi && (h->series.ensure((size_t)n * 2 * cap * 4) || h->cstat.ensure((size_t)n * kmax * sizeof(CandStat)))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>(); in.series_cap = cap;
     in.cstat = multi ? h->cstat.as<CandStat>() : nullptr;
     if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
+        if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
             Scope s(h, "k_mvs_series_wave");
             auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
             const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 2 * (MS_CHUNK + 4)) * 4;
             static size_t lds_set = 0;
             if (lds > lds_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set = lds; }
-            hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
-                               h->series.as<float>(), cap, h->have_series.as<int8_t>());
-        } else {
-            Scope s(h, "k_mvs_series");
-            hipLaunchKernelGGL(k_mvs_series, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+            hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         }
+        }
+        if (!multi) {
+            Scope s(h, "k_mvs_series");
+            hipLaunchKernelGGL(k_mvs_series<SIG>, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                               h->series.as<float>(), cap, h->have_series.as<int8_t>());
+        }
+        if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
             static bool attr_set = false;
             if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared))); attr_set = true; }
             Scope s(h, "k_cand_stats");
-            hipLaunchKernelGGL(k_cand_stats, dim3(n), dim3(CS_THREADS), sizeof(CsShared), h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+            hipLaunchKernelGGL(k_cand_stats, dim3(n), dim3(CS_THREADS), sizeof(CsShared), h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
+        }
         }
     } else {
         (void)hipMemsetAsync(h->have_series.p, 0, (size_t)n, h->stream);
@@ -401,7 +407,7 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
         in.op_arena = h->op_arena.as<int32_t>(); in.op_used = h->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(h->op_arena.cap / 4);
         HIPCHK(hipMemsetAsync(h->op_used.p, 0, 4, h->stream));
         { Scope s(h, attempt ? nullptr : "k_validate");
-          hipLaunchKernelGGL(k_validate, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+          hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
         if (!h->cfg.detect_open_pores) { h->op_last_used = 0; break; }
         unsigned int used = 0;
         HIPCHK(hipMemcpyAsync(&used, h->op_used.p, 4, hipMemcpyDeviceToHost, h->stream));
@@ -411,7 +417,7 @@ static int launch_validate(adp_handle *h, const float *dsig, const int32_t *dlen
         if (h->op_arena.ensure((size_t)used * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     }
     { Scope s(h, "k_partition_stats");
-      hipLaunchKernelGGL(k_partition_stats, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
+      hipLaunchKernelGGL(k_partition_stats<SIG>, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
     return 0;
 }
@@ -589,7 +595,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (h->L > 0)
             hipLaunchKernelGGL(k_llr_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->adapter_idx.as<int32_t>(),
                                h->polya_idx.as<int32_t>(), n, h->ds, h->pos_off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>(), h->layout == ADP_LAYOUT_SINGLE_READ ? 1 : 0);
-        rc = launch_validate(h, dsig, dlen, n, m, 1, minibatch, true);
+        rc = launch_validate(h, SigF32{dsig}, dlen, n, m, 1, minibatch, true);
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
             if (sp_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
@@ -713,7 +719,7 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
           hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{sg}, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
         hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
                            h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
-        rc = launch_validate(h, sg, ln, n, m, 1, minibatch, false);
+        rc = launch_validate(h, SigF32{sg}, ln, n, m, 1, minibatch, false);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 1,
                            h->any_none.as<int32_t>());
@@ -741,7 +747,7 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
     HIPCHK(hipMemcpyAsync(h->bounds.p, bounds, (size_t)n_reads * (1 + k) * 8,
                           ((flags & ADP_IN_DEVICE) && !(flags & ADP_BOUNDS_HOST)) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->topk_none.p, (flags & ADP_TOPK_NONE) ? 1 : 0, (size_t)n_reads, st));
-    rc = launch_validate(h, dsig, dlen, n_reads, m, k, n_reads, false);
+    rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, k, n_reads, false);
     if (rc) return rc;
     rc = deliver_rows(h, n_reads, flags, rows_out);
     if (rc) return rc;
@@ -979,7 +985,7 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     if (rc) return rc;
     if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
-    rc = launch_validate(h, dsig, dlen, n_reads, m, kk, n_reads, false);
+    rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, kk, n_reads, false);
     if (rc) return rc;
     rc = deliver_rows(h, n_reads, flags, rows_out);
     if (rc) return rc;

@@ -221,11 +221,10 @@ static __device__ __forceinline__ uint32_t bs_flag4(float v0, float v1, float v2
 // numpy-ordered sum of xf(x[0..n)) fused with a per-sample side effect; all threads return the sum and the
 // block-reduced aux (SIDE_HIST: count below the window; SIDE_COLLECT: max key below the bucket, aux2 = count
 // of samples closer to the centre than the bracket)
-template <int SIDE>
-static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_, int n, int mode, float c, LDS BlockScratch *bs,
+template <int SIDE, class X>
+static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c, LDS BlockScratch *bs,
                                                    SideParam param)
 {
-    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     uint32_t aux = 0, aux2 = 0;
     float total = 0.0f; // meaningful in wave 0
@@ -238,20 +237,20 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
     const int nchunk = n / 8192;
     const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
-    auto slab_ptr = [&](int q) { return reinterpret_cast<const GLB f4u *>(x + (size_t)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024); };
+    auto slab_off = [&](int q) { return (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
     // software pipeline: the next slab's loads fly while this one is summed
-    f4u v[4], vn[4];
+    float4 v[4], vn[4];
     if (myslabs > 0) {
-        const GLB f4u *p = slab_ptr(0);
+        const long long p = slab_off(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
+        for (int u = 0; u < 4; u++) v[u] = x.f4u(p + (u * 64 + ln) * 4);
     }
     float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
     for (int q = 0; q < myslabs; q++) {
         if (q + 1 < myslabs) {
-            const GLB f4u *p = slab_ptr(q + 1);
+            const long long p = slab_off(q + 1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = __builtin_nontemporal_load(&p[u * 64 + ln]);
+            for (int u = 0; u < 4; u++) vn[u] = x.f4u(p + (u * 64 + ln) * 4);
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;
@@ -305,7 +304,7 @@ static __device__ __noinline__ SumAux block_np_sum(const float *__restrict__ x_,
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
         bs_tail_leaves(tail, bs);
         const int nleaf = bs->nleaf;
-        const GLB float *xt = x + s;
+        const X xt = x + s;
         for (int g0 = 0; g0 < nleaf; g0 += 32) {
             // stage 32 leaves: wave w loads leaves g0 + 8w .. g0 + 8w + 7 (coalesced, 2 loads per leaf)
             __syncthreads();
@@ -429,9 +428,9 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs,
 }
 
 // largest key below `key_lo` among x[0..n) (0 if none) -- all threads return it
-static __device__ __noinline__ uint32_t bs_max_key_below(const float *__restrict__ x_, int n, uint32_t key_lo, LDS BlockScratch *bs)
+template <class X>
+static __device__ __noinline__ uint32_t bs_max_key_below(X x, int n, uint32_t key_lo, LDS BlockScratch *bs)
 {
-    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid == 0) bs->below = 0;
@@ -450,9 +449,9 @@ static __device__ __noinline__ uint32_t bs_max_key_below(const float *__restrict
 // int16 ADC samples (a step of ~0.18 pA is wider than a bucket, so thousands of samples share one key).  One more pass
 // counts the bucket's samples by their exact key -- 4096 counters in the staging area -- and notes the largest key below
 // the bucket; the median follows from the counts, whatever the multiplicities.
-static __device__ __noinline__ float bs_median_dense_bucket(const float *__restrict__ x_, int n, LDS BlockScratch *bs, uint32_t key_lo, int rk)
+template <class X>
+static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS BlockScratch *bs, uint32_t key_lo, int rk)
 {
-    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     LDS uint32_t *sub = (LDS uint32_t *)bs->u.stage; // 4096 counters (16 KB of the 17 KB staging area)
     static_assert(sizeof(((BlockScratch *)0)->u.stage) >= 4096 * 4, "staging area too small for the key counters");
@@ -502,9 +501,9 @@ static __device__ __noinline__ float bs_median_dense_bucket(const float *__restr
 }
 
 // passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
-static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x_, int n, LDS BlockScratch *bs, float med, float sd)
+template <class X>
+static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratch *bs, float med, float sd)
 {
-    const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x;
     const int k1 = n / 2;
     LDS uint32_t *h18 = bs->hist;
@@ -577,7 +576,7 @@ static __device__ __noinline__ float bs_mad_two_pass(const float *__restrict__ x
         __syncthreads();
     } else if (miss || bs->ncollect > BS_BINS18) {
         __syncthreads();
-        if (tid < 64) { float m_ = wave_median(x_, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
+        if (tid < 64) { float m_ = wave_median(x, n, 1, med, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
         __syncthreads();
         mad = bs->bcast[1];
         __syncthreads();
@@ -617,7 +616,8 @@ static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_
 }
 
 // mean / std / median / MAD of x[0..n), n >= 1.  have_medmad: reuse med_in / mad_in (adapter partition).
-static __device__ SegStats block_segment_stats(const float *__restrict__ x, int n, LDS BlockScratch *bs, bool have_medmad,
+template <class X>
+static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs, bool have_medmad,
                                                float med_in, float mad_in)
 {
     const int tid = threadIdx.x;
@@ -799,7 +799,8 @@ struct PartReq {
 };
 
 // grid = n_reads blocks of 256 threads
-__global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(const float *__restrict__ sigs, int m, const PartReq *__restrict__ req,
+template <class SIG>
+__global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int m, const PartReq *__restrict__ req,
                                                                adp_row *__restrict__ rows)
 {
     __shared__ BlockScratch bs_;
@@ -809,7 +810,7 @@ __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(const float *
     if (!q.valid) return;
     if (threadIdx.x == 0) bs->tail_cached = -1;
     __syncthreads();
-    const float *sig = sigs + (size_t)r * m;
+    const typename SIG::Row sig = sigs.row(r, m);
     adp_row *row = rows + r;
     const int S = q.S;
     unsigned long long present = 0;

@@ -73,6 +73,7 @@ struct RowF32 {
     const GLB float *p;
     __device__ __forceinline__ float operator[](long long i) const { return p[i]; }
     __device__ __forceinline__ RowF32 operator+(long long k) const { return RowF32{p + k}; }
+    __device__ __forceinline__ RowF32 operator-(long long k) const { return RowF32{p - k}; }
     __device__ __forceinline__ float4 f4(long long q) const { const adp_v4f v = reinterpret_cast<const GLB adp_v4f *>(p)[q]; return make_float4(v.x, v.y, v.z, v.w); }
     __device__ __forceinline__ float4 f4s(long long q) const
     {
@@ -96,6 +97,7 @@ struct RowI16 {
     __device__ __forceinline__ float cal(short a) const { const float t = (float)a + of; return sc * t; }
     __device__ __forceinline__ float operator[](long long i) const { return i < n ? cal(p[i]) : __builtin_nanf(""); }
     __device__ __forceinline__ RowI16 operator+(long long k) const { return RowI16{p + k, sc, of, (int)(n - k)}; }
+    __device__ __forceinline__ RowI16 operator-(long long k) const { return RowI16{p - k, sc, of, (int)(n + k)}; }
     __device__ __forceinline__ float4 conv4(adp_s4 v, long long i) const
     {
         const float nanv = __builtin_nanf("");

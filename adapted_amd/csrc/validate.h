@@ -17,8 +17,9 @@
 #include "block_stats.h"
 #include "cand_stats.h"
 
-struct ValidateIn {
-    const float *sig;          // [n_reads, m]
+template <class SIG>
+struct ValidateInT {
+    SIG sig;                   // [n_reads, m] (float32 pA, or int16 ADC + calibration)
     const int32_t *full_len;   // [n_reads]
     const int64_t *bounds;     // [n_reads, 1 + kmax]: adapter_end, candidates (0 terminates)
     const int8_t *topk_none;   // [n_reads] 1 <=> polya_end_topk is None ; may be nullptr (all given)
@@ -55,10 +56,11 @@ struct RowW {
 // eight consecutive samples as two 16-byte accesses (gfx950 needs dword alignment only): with one LANE per read every
 // access of the wave touches 64 different rows, so the number of memory instructions is what the kernel costs
 typedef float bn_f4 __attribute__((ext_vector_type(4), aligned(4)));
-static __device__ __forceinline__ void bn_load8(float (&dst)[BN_BLK], const GLB float *a, int i, int n, int back)
+template <class X>
+static __device__ __forceinline__ void bn_load8(float (&dst)[BN_BLK], X a, int i, int n, int back)
 {
     if (i + BN_BLK <= n) {
-        const bn_f4 v0 = *reinterpret_cast<const GLB bn_f4 *>(a + i - back), v1 = *reinterpret_cast<const GLB bn_f4 *>(a + i - back + 4);
+        const float4 v0 = a.f4u(i - back), v1 = a.f4u(i - back + 4);
         dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
     } else {
 #pragma unroll
@@ -78,9 +80,9 @@ static __device__ __forceinline__ void bn_store8(GLB float *out, int o, const fl
 }
 
 // bottleneck.move_mean(a, window=w) for i >= w-1 (float32, NaN-free input) -- single lane
-static __device__ __noinline__ void bn_move_mean(const float *a_, int n, int w, float *out_)
+template <class X>
+static __device__ __noinline__ void bn_move_mean(X a, int n, int w, float *out_)
 {
-    const GLB float *a = (const GLB float *)a_;
     GLB float *out = (GLB float *)out_;
     float asum = 0.f;
     for (int i0 = 0; i0 < w; i0 += BN_BLK) {
@@ -111,9 +113,9 @@ static __device__ __noinline__ void bn_move_mean(const float *a_, int n, int w, 
 }
 
 // bottleneck.move_var(a, window=w, ddof=0) for i >= w-1 -- single lane
-static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, float *out_)
+template <class X>
+static __device__ __noinline__ void bn_move_var(X a, int n, int w, float *out_)
 {
-    const GLB float *a = (const GLB float *)a_;
     GLB float *out = (GLB float *)out_;
     float amean = 0.f, assqdm = 0.f;
     int count = 0;
@@ -167,10 +169,10 @@ static __device__ __noinline__ void bn_move_var(const float *a_, int n, int w, f
 // wait for memory once per chunk instead of once per few samples.  Same arithmetic as bn_move_var / bn_move_mean.
 #define MV_CHUNK 768
 #define MV_HIST (WS_STAGE_FLOATS - MV_CHUNK) // longest window this path serves
-static __device__ void wave_move_series(const float *x_, int n, int wv, int wm, bool do_var, bool do_mean, float *svar_, float *smean_,
+template <class X>
+static __device__ void wave_move_series(X x, int n, int wv, int wm, bool do_var, bool do_mean, float *svar_, float *smean_,
                                         LDS WaveScratch *ws)
 {
-    const GLB float *x = (const GLB float *)x_;
     GLB float *svar = (GLB float *)svar_;
     GLB float *smean = (GLB float *)smean_;
     const int ln = lane_id();
@@ -251,7 +253,8 @@ static __device__ void wave_move_series(const float *x_, int n, int wv, int wm, 
 }
 
 // calc_partition_stats -> (start, len, mean, std, med, mad)
-static __device__ void partition_stats(const float *sig, int S, long long start, long long end, RowW &rw, int c_start,
+template <class X>
+static __device__ void partition_stats(X sig, int S, long long start, long long end, RowW &rw, int c_start,
                                        int c_len, LDS WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
 {
     rw.set(c_start, (double)start);
@@ -262,7 +265,7 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
     float mean, sd, med, mad;
     if (n <= 0) { mean = sd = med = mad = __builtin_nanf(""); }
     else {
-        const float *x = sig + a;
+        const X x = sig + a;
         float var = wave_np_var(x, n, ws, &mean);
         sd = sqrtf(var);
         if (have_medmad) { med = med_in; mad = mad_in; }
@@ -277,7 +280,8 @@ static __device__ void partition_stats(const float *sig, int S, long long start,
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
 // shift_cache: the median shift across the adapter end is the same for every candidate of a read (value, flag)
-static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
+template <class X>
+static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
                                    double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
                                    const float *pre_mean, const float *pre_var, const CandStat *cst, float &shift_val, bool &shift_have)
 {
@@ -286,7 +290,7 @@ static __device__ __noinline__ MvsOut mvs_check(const float *sig, int S, long lo
     if ((long long)S < a_e + cfg.median_shift_window) return o;
     const int a = (int)(a_e < S ? a_e : S), b = (int)(p_e < S ? p_e : S);
     const int n = b - a;
-    const float *x = sig + a;
+    const X x = sig + a;
     const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
     if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) {
         o.exc = ADP_F_EXC_MOVE_WINDOW; return o;
@@ -344,7 +348,8 @@ struct MvsLoc { int ok, exc; long long idx; double mean, var, med, lrange, shift
 
 static __device__ __forceinline__ bool in_range_f32(float v, double lo, double hi) { return (float)lo <= v && v <= (float)hi; }
 
-static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S, long long loc, const adp_cfg &cfg, double pr0, double pr1,
+template <class X>
+static __device__ __noinline__ MvsLoc mvs_detect_at_loc(X sig, int S, long long loc, const adp_cfg &cfg, double pr0, double pr1,
                                                         LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
                                                         float med_before_loc)
 {
@@ -355,7 +360,7 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S,
     if ((long long)S < loc + cfg.search_window + tailw) return o; // not enough signal after loc (:216-231)
     if (loc < offset) return o;                                   // ... or before it (:234-247)
     const int n = offset + cfg.search_window;
-    const float *x = sig + (loc - offset);
+    const X x = sig + (loc - offset);
     if (wm < 1 || wv < 1) { o.exc = ADP_F_EXC_MOVE_WINDOW; return o; } // (windows longer than the slice cannot occur)
     __syncthreads();
     // the series hold the outputs from index window-1 on (the first window-1 are NaN in bottleneck: never in range)
@@ -384,7 +389,7 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S,
     const long long loc_ = loc > ix ? loc : ix;
     long long e1 = loc_ + cfg.polyA_window; if (e1 > S) e1 = S;
     long long e2 = loc_ + cfg.median_shift_window; if (e2 > S) e2 = S;
-    const float *y = sig + loc_;
+    const X y = sig + loc_;
     const float fmed = wave_median(y, (int)(e1 - loc_), 0, 0.f, ws, sc);
     o.med = (double)fmed;
     o.lrange = wave_percentile(y, (int)(e1 - loc_), 85.0, ws, sc) - wave_percentile(y, (int)(e1 - loc_), 15.0, ws, sc);
@@ -401,7 +406,8 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(const float *sig, int S,
 // lane of a wave.  They only depend on (adapter_end, first poly(A) candidate), which are known before
 // validation starts, so this kernel runs them for candidate 0 with one LANE per read (64 reads per wave).
 #define MVS_CAP 8192
-__global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
+template <class SIG>
+__global__ void __launch_bounds__(64) k_mvs_series(SIG sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                    int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
                                                    float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
@@ -422,7 +428,7 @@ __global__ void __launch_bounds__(64) k_mvs_series(const float *__restrict__ sig
     const bool wvar = !(p_e - a_e <= cfg.pA_var_window + 2), wmean = !(p_e - a_e <= cfg.pA_mean_window + 2);
     if ((wvar && (cfg.pA_var_window > n || cfg.pA_var_window < 1)) || (wmean && (cfg.pA_mean_window > n || cfg.pA_mean_window < 1))) return;
     if (n > cap) return;
-    const float *x = sigs + (size_t)r * m + a;
+    const typename SIG::Row x = sigs.row(r, m) + a;
     float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
     if (wvar) bn_move_var(x, n, cfg.pA_var_window, svar);
     if (wmean) bn_move_mean(x, n, cfg.pA_mean_window, smean);
@@ -611,7 +617,8 @@ static __device__ void row_exception(adp_row *row, int code)
 }
 
 // persistent grid: blockIdx.x = slot, block = 64 threads
-__global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, adp_row *__restrict__ rows,
+template <class SIG>
+__global__ void __launch_bounds__(64, 6) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
                                                  PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;
@@ -625,7 +632,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
         row_clear(row);
         if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = 0; sc->n = 0; } }
         if (in.mbs && in.mbs[r / in.mbsize].status != ADP_MB_OK) continue; // dropped minibatch: zero row
-        const float *sig = in.sig + (size_t)r * in.m;
+        const typename SIG::Row sig = in.sig.row(r, in.m);
         const long long full_len = in.full_len[r];
         const int S = (int)(full_len < in.m ? full_len : in.m);
         const int64_t *bd = in.bounds + (size_t)r * (1 + in.kmax);
@@ -714,7 +721,7 @@ __global__ void __launch_bounds__(64, 6) k_validate(ValidateIn in, adp_cfg cfg, 
         if (success && cfg.real_signal_check && !(g_ablate & 32)) {
             int a = (int)(a_s < S ? a_s : S), b = (int)(a_e < S ? a_e : S);
             int n = b - a; if (n < 0) n = 0;
-            const float *x = sig + a;
+            const typename SIG::Row x = sig + a;
             bool ok = false;
             if (n >= 2 * cfg.mean_window) {
                 float ms = wave_np_mean(x, cfg.mean_window, ws);
