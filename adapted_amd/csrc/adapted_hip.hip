@@ -498,18 +498,12 @@ static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch
     return 0;
 }
 
-static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int minibatch, int flags,
-                        adp_row *rows_out, int32_t *mb_status, int upto)
+// the LLR path over a resident signal matrix: float32 pA (SigF32) or int16 ADC + calibration (SigI16)
+template <class SIG>
+static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int minibatch, int flags,
+                          adp_row *rows_out, int32_t *mb_status, int upto)
 {
-    if (!h || !signals || !full_len || n < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
-    if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
-    if (h->layout == ADP_LAYOUT_SINGLE_READ && minibatch != 1) { g_err = "the single-read layout normalises every read on its own: minibatch must be 1"; return ADP_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
-    h->prof.clear();
-    h->ev_used = 0;
-    const float *dsig; const int32_t *dlen;
-    int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
-    if (rc) return rc;
+    int rc = 0;
     const int n_mb = (n + minibatch - 1) / minibatch;
     h->last_n = n; h->last_nmb = n_mb;
     if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 8) || h->gcnt.ensure((size_t)n_mb * 8 * N1_NCNT)) {
@@ -528,7 +522,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
     } else {
         const int32_t *tails = (flags & ADP_TAILS_NAN) ? dlen : nullptr;
-        rc = launch_n1(h, SigF32{dsig}, n, m, T, minibatch, n_mb, true, tails);
+        rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true, tails);
         if (rc) return rc;
         if (upto >= 2) {
             Scope s(h, "k_norm_pool");
@@ -543,7 +537,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
                 HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope)
                 rng = h->rng0.as<int64_t>();
             }
-            hipLaunchKernelGGL(k_norm_pool<SigF32>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, SigF32{dsig}, m, T, h->off, h->ds, h->L, h->Lp,
+            hipLaunchKernelGGL(k_norm_pool<SIG>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), rng,
                                dlen, (flags & ADP_TAILS_NAN) ? 1 : 0);
         }
@@ -555,7 +549,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
             HIPCHK(hipEventRecord(h->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
             { Scope s(h, "k_start_peak", h->stream2);
-              hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, h->stream2, SigF32{dsig}, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
+              hipLaunchKernelGGL(k_start_peak<SIG>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, h->stream2, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>()); }
             HIPCHK(hipEventRecord(h->ev_join, h->stream2));
             sp_forked = true;
         }
@@ -595,13 +589,13 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
         if (h->L > 0)
             hipLaunchKernelGGL(k_llr_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->adapter_idx.as<int32_t>(),
                                h->polya_idx.as<int32_t>(), n, h->ds, h->pos_off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>(), h->layout == ADP_LAYOUT_SINGLE_READ ? 1 : 0);
-        rc = launch_validate(h, SigF32{dsig}, dlen, n, m, 1, minibatch, true);
+        rc = launch_validate(h, dsig, dlen, n, m, 1, minibatch, true);
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
             if (sp_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
             else {
                 Scope s(h, "k_start_peak");
-                hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{dsig}, dlen, n, m, h->cfg, h->sp.as<SpOut>());
+                hipLaunchKernelGGL(k_start_peak<SIG>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>());
             }
             hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
                                (const int32_t *)nullptr);
@@ -617,6 +611,21 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));
     return ADP_OK;
+}
+
+static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full_len, int n, int m, int minibatch, int flags,
+                        adp_row *rows_out, int32_t *mb_status, int upto)
+{
+    if (!h || !signals || !full_len || n < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    if (h->layout == ADP_LAYOUT_SINGLE_READ && minibatch != 1) { g_err = "the single-read layout normalises every read on its own: minibatch must be 1"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear();
+    h->ev_used = 0;
+    const float *dsig; const int32_t *dlen;
+    int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
+    if (rc) return rc;
+    return llr_pipeline_t(h, SigF32{dsig}, dlen, n, m, minibatch, flags, rows_out, mb_status, upto);
 }
 
 extern "C" {
@@ -637,6 +646,21 @@ int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len,
                    adp_row *rows_out, int32_t *mb_status)
 {
     return llr_pipeline(h, signals, full_len, n_reads, m, minibatch, flags, rows_out, mb_status, 8);
+}
+
+int adp_detect_llr_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len, const float *scale, const float *offset, int n_reads,
+                       int m, int minibatch, int flags, adp_row *rows_out, int32_t *mb_status)
+{
+    if (!h || !raw || !full_len || !scale || !offset || n_reads < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    if (!(flags & ADP_IN_DEVICE)) { g_err = "adp_detect_llr_i16 takes device pointers (ADP_IN_DEVICE)"; return ADP_ERR_INVALID; }
+    if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
+    if (h->layout == ADP_LAYOUT_SINGLE_READ) { g_err = "the single-read layout takes float32 input"; return ADP_ERR_UNSUPPORTED; }
+    if (m & 3) { g_err = "int16 rows need m % 4 == 0 (8-byte aligned rows)"; return ADP_ERR_UNSUPPORTED; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear();
+    h->ev_used = 0;
+    // (samples at or beyond min(full_len, m) read as NaN: the padding is implied, so the passes always stop at a read's end)
+    return llr_pipeline_t(h, SigI16{raw, scale, offset, full_len}, full_len, n_reads, m, minibatch, flags | ADP_TAILS_NAN, rows_out, mb_status, 8);
 }
 
 __global__ void k_debug_log(const double *in, double *out, int n)

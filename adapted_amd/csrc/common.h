@@ -85,6 +85,11 @@ struct RowF32 {
         const adp_f4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_f4u *>(p + i));
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    __device__ __forceinline__ float4 f4uc(long long i) const // (the same through the caches: data that is read again soon)
+    {
+        const adp_f4u v = *reinterpret_cast<const GLB adp_f4u *>(p + i);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
     __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
     __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
     __device__ __forceinline__ long long diff(const RowF32 &o) const { return p - o.p; }
@@ -110,6 +115,12 @@ struct RowI16 {
     __device__ __forceinline__ float4 f4u(long long i) const
     {
         const adp_s4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4u *>(p + i));
+        const adp_s4 w = {v.x, v.y, v.z, v.w};
+        return conv4(w, i);
+    }
+    __device__ __forceinline__ float4 f4uc(long long i) const
+    {
+        const adp_s4u v = *reinterpret_cast<const GLB adp_s4u *>(p + i);
         const adp_s4 w = {v.x, v.y, v.z, v.w};
         return conv4(w, i);
     }

@@ -60,7 +60,7 @@ template <class X>
 static __device__ __forceinline__ void bn_load8(float (&dst)[BN_BLK], X a, int i, int n, int back)
 {
     if (i + BN_BLK <= n) {
-        const float4 v0 = a.f4u(i - back), v1 = a.f4u(i - back + 4);
+        const float4 v0 = a.f4uc(i - back), v1 = a.f4uc(i - back + 4);
         dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
     } else {
 #pragma unroll

@@ -152,7 +152,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
            "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
-           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena"]
+           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena", "adp_detect_llr_i16"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -423,6 +423,24 @@ class Engine:
         self._check(self.lib.adp_detect_llr(self._h, sp, lp, int(n), self.m, int(minibatch), flags, rp,
                                             mbs.ctypes.data_as(C.c_void_p)))
         del keep
+        return self.attach_open_pores(rows), mbs
+
+    def detect_llr_rows_i16(self, raw_dev: int, len_dev: int, scale_dev: int, offset_dev: int, n: int, minibatch: int,
+                            with_start_peak: bool = False, rows_dev: Optional[int] = None):
+        """adp_detect_llr over RAW int16 samples resident on the device (per-read calibration applied in registers):
+        -> (rows or None when rows_dev is given, mb_status)"""
+        flags = ADP_IN_DEVICE | (ADP_WITH_START_PEAK if with_start_peak else 0)
+        n_mb = (n + minibatch - 1) // minibatch
+        mbs = np.zeros(n_mb, dtype=np.int32)
+        if rows_dev is not None:
+            flags |= ADP_OUT_DEVICE
+            rows, rp = None, C.c_void_p(rows_dev)
+        else:
+            rows = np.zeros(n, dtype=ROW_DTYPE)
+            rp = rows.ctypes.data_as(C.c_void_p)
+        self._check(self.lib.adp_detect_llr_i16(self._h, C.c_void_p(int(raw_dev)), C.c_void_p(int(len_dev)), C.c_void_p(int(scale_dev)),
+                                                C.c_void_p(int(offset_dev)), int(n), self.m, int(minibatch), flags, rp,
+                                                mbs.ctypes.data_as(C.c_void_p)))
         return self.attach_open_pores(rows), mbs
 
     def detect_start_peak_rows(self, signals, full_lens, n: int, minibatch: int, device_ptrs: bool = False):

@@ -175,6 +175,16 @@ int adp_synchronize(adp_handle *h);
 int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                    int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
 
+/* The same over RAW samples (an EXTENSION of the boundary: the reference's operators take calibrated
+ * float32): raw = DEVICE int16 [n_reads, m] as the sequencer stores them, scale / offset = DEVICE float32 [n_reads] (pod5's
+ * per-read calibration), full_len = DEVICE int32 [n_reads]; flags must hold ADP_IN_DEVICE.  Every kernel that touches the
+ * signal forms pA = scale * (float32(adc) + offset) in registers (both operations rounded to float32, never fused --
+ * bit-identical to adp_calibrate_i16's output) and treats samples at or beyond min(full_len, m) as the NaN padding of
+ * adapted/file_proc.py:170-174, so rows are identical to adp_calibrate_i16 + adp_detect_llr while every streaming pass
+ * moves 2 bytes per sample instead of 4.  m must be a multiple of 4. */
+int adp_detect_llr_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len, const float *scale, const float *offset,
+                       int n_reads, int m, int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
+
 /* Start-peak primary + validation. */
 int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads,
                           int m, int minibatch, int flags, adp_row *rows_out);

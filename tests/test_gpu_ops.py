@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from golden_cases import CASES
-from util import GOLD, load_case, row_diffs
+from util import GOLD, load_case, make_spc, row_diffs
 
 pytestmark = pytest.mark.gpu
 
@@ -452,3 +452,47 @@ def test_cli_two_ranks_equal_one_rank(tmp_path, primary):
         assert one.keys() == two.keys() and len(one) >= 1
         for k in one:
             assert one[k] == two[k], (tag, k)
+
+
+@pytest.mark.parametrize("max_obs_trace,n,overrides", [(None, 96, {}), (200000, 48, {}), (60000, 64, {"mvs_polya.mvs_detect_overwrite": True}),
+                                                        (None, 64, {"med_shift.detect_med_shift": True, "mvs_polya.pA_var_window": 101})])
+def test_int16_native_rows_equal_the_calibrated_float32_path(max_obs_trace, n, overrides):
+    """adp_detect_llr_i16: every kernel that touches the signal reads the RAW int16 samples and forms pA = scale * (float32(adc) +
+    offset) in registers; samples behind a read's end count as the NaN padding.  Rows byte-identical to adp_calibrate_i16 +
+    adp_detect_llr on the same reads (per-read calibrations, lengths from 1012 samples to beyond the window, open-pore blips
+    above 16 entries, two minibatches), with the start-peak columns."""
+    from adapted_amd import lib, synth
+
+    spc = make_spc(dict(chem="RNA004", primary="llr", max_obs_trace=max_obs_trace, override=overrides))
+    m = spc.sig_preload_size
+    rng = np.random.default_rng(n)
+    lens = np.array([m + 300 if i % 3 == 0 else max(1012, synth.pareto_length(9, i, lo=2000, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    lens[1], lens[2] = 1012, m
+    sig, lens = synth.synth_batch(61, 0, n, m, lens)
+    for j in range(24):
+        sig[4, 120 + 40 * j: 123 + 40 * j] = 260.0  # more open pores than a row holds
+    scale = rng.uniform(0.15, 0.21, n).astype(np.float32)
+    offset = rng.integers(-30, 10, n).astype(np.float32)
+    raw = np.clip(np.round(np.nan_to_num(sig) / scale[:, None] - offset[:, None]), -32768, 32767).astype(np.int16)
+    raw[np.isnan(sig)] = rng.integers(-3000, 3000, int(np.isnan(sig).sum())).astype(np.int16)  # garbage behind the reads' ends
+    eng = lib.Engine(spc, n, m, device=0)
+    d_raw, d_len, d_cal, d_f32 = eng.dev_alloc(n * m * 2), eng.dev_alloc(n * 4), eng.dev_alloc(2 * n * 4), eng.dev_alloc(n * m * 4)
+    eng.h2d(d_raw, raw)
+    eng.h2d(d_len, lens)
+    eng.h2d(d_cal, np.concatenate([scale, offset]))
+    mb = n // 2
+    eng.calibrate_i16(d_raw, d_len, d_cal, d_cal + n * 4, n, d_f32)
+    want, mbs_w = eng.detect_llr_rows(d_f32, d_len, n, mb, with_start_peak=True, device_ptrs=True, tails_nan=True)
+    got, mbs_g = eng.detect_llr_rows_i16(d_raw, d_len, d_cal, d_cal + n * 4, n, mb, with_start_peak=True)
+    assert (mbs_w == 0).all() and (mbs_g == mbs_w).all()
+    res_w, res_g = lib.rows_to_results(want, "llr"), lib.rows_to_results(got, "llr")
+    plain = lambda d: {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in d.items()}
+    bad = [(i, d) for i, (g, w) in enumerate(zip(res_g, res_w)) for d in row_diffs(g, plain(w.__dict__))]
+    assert not bad, bad[:8]
+    a, b = want.copy(), got.copy()
+    a["open_pores_more"] = 0; b["open_pores_more"] = 0  # (registry tokens differ between the two calls)
+    assert a.tobytes() == b.tobytes()
+    assert sum(r.success for r in res_g) > n // 4
+    for p in (d_raw, d_len, d_cal, d_f32):
+        eng.dev_free(p)
+    eng.close()
