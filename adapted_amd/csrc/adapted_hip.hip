@@ -178,6 +178,20 @@ __global__ void __launch_bounds__(256) k_expand_ragged(const SRC *__restrict__ p
     }
 }
 
+// the same for raw samples that STAY raw (adp_detect_llr_i16 reads them): int16 [n, m], zeros behind each read
+__global__ void __launch_bounds__(256) k_expand_ragged_raw(const int16_t *__restrict__ packed, const int64_t *__restrict__ offs,
+                                                           const int32_t *__restrict__ full_len, int m, int16_t *__restrict__ out)
+{
+    const int r = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= m) return;
+    const int len = full_len[r] < m ? (full_len[r] > 0 ? full_len[r] : 0) : m;
+    const int16_t *src = packed + offs[r] + i0;
+    int16_t *dst = out + (size_t)r * m + i0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (i0 + j < m) dst[j] = (i0 + j < len) ? src[j] : (int16_t)0;
+}
+
 extern "C" {
 
 int adp_abi_version(void) { return ADP_ABI_VERSION; }
@@ -1168,6 +1182,16 @@ int adp_expand_ragged(adp_handle *h, const void *packed, int is_int16, const int
     else
         hipLaunchKernelGGL(k_expand_ragged<float>, grid, dim3(256), 0, h->stream, (const float *)packed, offsets, full_len,
                            (const float *)nullptr, (const float *)nullptr, m, signals_out);
+    HIPCHK(hipGetLastError());
+    return ADP_OK;
+}
+
+int adp_expand_ragged_i16(adp_handle *h, const int16_t *packed, const int64_t *offsets, const int32_t *full_len, int n_reads, int m,
+                          int16_t *raw_out)
+{
+    if (!h || !packed || !offsets || !full_len || !raw_out || n_reads < 1 || m < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_expand_ragged_raw, dim3((m + 1023) / 1024, n_reads), dim3(256), 0, h->stream, packed, offsets, full_len, m, raw_out);
     HIPCHK(hipGetLastError());
     return ADP_OK;
 }

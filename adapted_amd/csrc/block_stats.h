@@ -243,14 +243,14 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     if (myslabs > 0) {
         const long long p = slab_off(0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = x.f4u(p + (u * 64 + ln) * 4);
+        for (int u = 0; u < 4; u++) v[u] = x.f4u_in(p + (u * 64 + ln) * 4);
     }
     float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
     for (int q = 0; q < myslabs; q++) {
         if (q + 1 < myslabs) {
             const long long p = slab_off(q + 1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = x.f4u(p + (u * 64 + ln) * 4);
+            for (int u = 0; u < 4; u++) vn[u] = x.f4u_in(p + (u * 64 + ln) * 4);
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;
@@ -463,7 +463,7 @@ static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS Bloc
     for (int base = 0; base < n; base += BS_THREADS * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = (i < n) ? x[i] : 0.f; }
+        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int i = base + u * BS_THREADS + tid;
@@ -518,7 +518,7 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
     for (int base = 0; base < n; base += BS_THREADS * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = (i < n) ? x[i] : 0.f; }
+        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             int i = base + u * BS_THREADS + tid;
@@ -546,7 +546,7 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
         for (int base = 0; base < n; base += BS_THREADS * 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = (i < n) ? x[i] : 0.f; }
+            for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 int i = base + u * BS_THREADS + tid;

@@ -72,6 +72,8 @@ typedef short adp_s4u __attribute__((ext_vector_type(4), aligned(2)));
 struct RowF32 {
     const GLB float *p;
     __device__ __forceinline__ float operator[](long long i) const { return p[i]; }
+    // x[i] where ok, else dflt (a masked load: the compiler keeps several of them in flight)
+    __device__ __forceinline__ float at_or(long long i, bool ok, float dflt) const { return ok ? p[i] : dflt; }
     __device__ __forceinline__ RowF32 operator+(long long k) const { return RowF32{p + k}; }
     __device__ __forceinline__ RowF32 operator-(long long k) const { return RowF32{p - k}; }
     __device__ __forceinline__ float4 f4(long long q) const { const adp_v4f v = reinterpret_cast<const GLB adp_v4f *>(p)[q]; return make_float4(v.x, v.y, v.z, v.w); }
@@ -85,6 +87,10 @@ struct RowF32 {
         const adp_f4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_f4u *>(p + i));
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    // *_in: the caller guarantees that the four samples exist (no padding among them): nothing to check for either row type
+    __device__ __forceinline__ float4 f4_in(long long q) const { return f4(q); }
+    __device__ __forceinline__ float4 f4s_in(long long q) const { return f4s(q); }
+    __device__ __forceinline__ float4 f4u_in(long long i) const { return f4u(i); }
     __device__ __forceinline__ float4 f4uc(long long i) const // (the same through the caches: data that is read again soon)
     {
         const adp_f4u v = *reinterpret_cast<const GLB adp_f4u *>(p + i);
@@ -100,7 +106,13 @@ struct RowI16 {
     float sc, of;
     int n; // samples that exist from p on (may be <= 0): the rest is the NaN padding
     __device__ __forceinline__ float cal(short a) const { const float t = (float)a + of; return sc * t; }
-    __device__ __forceinline__ float operator[](long long i) const { return i < n ? cal(p[i]) : __builtin_nanf(""); }
+    // (the load is unconditional -- a position behind the read's end is still inside the matrix, or at most 6 bytes behind its
+    // last row for the vector forms, which the allocations cover -- so that the compiler keeps independent loads in flight
+    // instead of branching around each)
+    __device__ __forceinline__ float operator[](long long i) const { const float v = cal(p[i]); return i < n ? v : __builtin_nanf(""); }
+    // (here ONE unconditional load -- element 0 stands in when !ok -- and a select: a conditional load followed by the
+    // conversion makes the compiler branch around each load and wait for it, eight round trips instead of one)
+    __device__ __forceinline__ float at_or(long long i, bool ok, float dflt) const { const float v = (*this)[ok ? i : 0]; return ok ? v : dflt; }
     __device__ __forceinline__ RowI16 operator+(long long k) const { return RowI16{p + k, sc, of, (int)(n - k)}; }
     __device__ __forceinline__ RowI16 operator-(long long k) const { return RowI16{p - k, sc, of, (int)(n + k)}; }
     __device__ __forceinline__ float4 conv4(adp_s4 v, long long i) const
@@ -123,6 +135,15 @@ struct RowI16 {
         const adp_s4u v = *reinterpret_cast<const GLB adp_s4u *>(p + i);
         const adp_s4 w = {v.x, v.y, v.z, v.w};
         return conv4(w, i);
+    }
+    __device__ __forceinline__ float4 cal4(adp_s4 v) const { return make_float4(cal(v.x), cal(v.y), cal(v.z), cal(v.w)); }
+    __device__ __forceinline__ float4 f4_in(long long q) const { return cal4(reinterpret_cast<const GLB adp_s4 *>(p)[q]); }
+    __device__ __forceinline__ float4 f4s_in(long long q) const { return cal4(__builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4 *>(p) + q)); }
+    __device__ __forceinline__ float4 f4u_in(long long i) const
+    {
+        const adp_s4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4u *>(p + i));
+        const adp_s4 w = {v.x, v.y, v.z, v.w};
+        return cal4(w);
     }
     __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
     __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
@@ -148,6 +169,14 @@ struct SigI16 {
     __device__ __forceinline__ bool vec_ok(int m) const { return (m & 3) == 0 && (reinterpret_cast<uintptr_t>(base) & 7) == 0; }
 };
 // plain float arrays (series, pooled values, copies) go through the same helpers as rows
+// x[i] if ok, else some valid element's value or 0 (the caller does not use it): the load pattern each row type is fastest with
+static __device__ __forceinline__ float ld_if(const RowF32 &x, long long i, bool ok) { return ok ? x.p[i] : 0.f; }
+static __device__ __forceinline__ float ld_if(const RowI16 &x, long long i, bool ok) { return x[ok ? i : 0]; }
+static __device__ __forceinline__ float ld_if(const LDS float *x, long long i, bool ok) { return ok ? x[i] : 0.f; }
+// x[i] if ok, else x[0]
+static __device__ __forceinline__ float ld_or_first(const RowF32 &x, long long i, bool ok) { return ok ? x.p[i] : x.p[0]; }
+static __device__ __forceinline__ float ld_or_first(const RowI16 &x, long long i, bool ok) { return x[ok ? i : 0]; }
+static __device__ __forceinline__ float ld_or_first(const LDS float *x, long long i, bool ok) { return ok ? x[i] : x[0]; }
 static __device__ __forceinline__ RowF32 as_row(const float *p) { return RowF32{(const GLB float *)p}; }
 static __device__ __forceinline__ RowF32 as_row(float *p) { return RowF32{(const GLB float *)p}; }
 static __device__ __forceinline__ RowF32 as_row(RowF32 r) { return r; }

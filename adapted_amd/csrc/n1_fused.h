@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(SIG sig, int n_reads, i
                 const int send = min(T4, seg + q4);
                 int i = seg + threadIdx.x;
                 for (; i + 3 * N1_THREADS < send; i += 4 * N1_THREADS) { // four loads in flight per lane (-3 % against two)
-                    float4 v0 = row.f4s(i), v1 = row.f4s(i + N1_THREADS), v2 = row.f4s(i + 2 * N1_THREADS), v3 = row.f4s(i + 3 * N1_THREADS);
+                    float4 v0 = row.f4s_in(i), v1 = row.f4s_in(i + N1_THREADS), v2 = row.f4s_in(i + 2 * N1_THREADS), v3 = row.f4s_in(i + 3 * N1_THREADS);
                     const float e[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
                     uint32_t fl = 0;
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(SIG sig, int n_reads, i
                     }
                 }
                 for (; i + N1_THREADS < send; i += 2 * N1_THREADS) { // two loads in flight per lane
-                    float4 v = row.f4s(i), w = row.f4s(i + N1_THREADS);
+                    float4 v = row.f4s_in(i), w = row.f4s_in(i + N1_THREADS);
                     const float e[8] = {v.x, v.y, v.z, v.w, w.x, w.y, w.z, w.w};
                     uint32_t fl = 0;
 #pragma unroll
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(SIG sig, int n_reads, i
                         n1f_copy(x, med_s, D0, cbm, cbb, cnt2, nh, hkeys, hcnt);
                     }
                 }
-                for (; i < send; i += N1_THREADS) { float4 v = row.f4(i); ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
+                for (; i < send; i += N1_THREADS) { float4 v = row.f4_in(i); ACC(v.x); ACC(v.y); ACC(v.z); ACC(v.w); }
                 if (send == T4) for (int j = (T4 << 2) + threadIdx.x; j < Te; j += N1_THREADS) ACC(row[j]);
                 flush();
             }

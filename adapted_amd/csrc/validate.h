@@ -12,6 +12,7 @@
 // mean / variance series of one poly(A) candidate.  All branches are per-read decisions and
 // therefore wave-uniform.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "wave_stats.h"
 #include "block_stats.h"
@@ -64,7 +65,7 @@ static __device__ __forceinline__ void bn_load8(float (&dst)[BN_BLK], X a, int i
         dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w; dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < BN_BLK; j++) dst[j] = (i + j < n) ? a[i + j - back] : 0.f;
+        for (int j = 0; j < BN_BLK; j++) dst[j] = a.at_or(i + j - back, i + j < n, 0.f);
     }
 }
 static __device__ __forceinline__ void bn_store8(GLB float *out, int o, const float (&res)[BN_BLK], int i, int n)
@@ -88,7 +89,7 @@ static __device__ __noinline__ void bn_move_mean(X a, int n, int w, float *out_)
     for (int i0 = 0; i0 < w; i0 += BN_BLK) {
         float v[BN_BLK];
 #pragma unroll
-        for (int j = 0; j < BN_BLK; j++) v[j] = (i0 + j < w) ? a[i0 + j] : 0.f;
+        for (int j = 0; j < BN_BLK; j++) v[j] = a.at_or(i0 + j, i0 + j < w, 0.f);
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) if (i0 + j < w) asum += v[j];
     }
@@ -122,7 +123,7 @@ static __device__ __noinline__ void bn_move_var(X a, int n, int w, float *out_)
     for (int i0 = 0; i0 < w; i0 += BN_BLK) {
         float v[BN_BLK];
 #pragma unroll
-        for (int j = 0; j < BN_BLK; j++) v[j] = (i0 + j < w) ? a[i0 + j] : 0.f;
+        for (int j = 0; j < BN_BLK; j++) v[j] = a.at_or(i0 + j, i0 + j < w, 0.f);
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) {
             if (i0 + j < w) {
@@ -160,6 +161,35 @@ static __device__ __noinline__ void bn_move_var(X a, int n, int w, float *out_)
         bn_store8(out, i0 - w + 1, res, i0, n);
 #pragma unroll
         for (int j = 0; j < BN_BLK; j++) { cn[j] = nn[j]; co[j] = no[j]; }
+    }
+}
+
+// The same two recurrences element by element, for k_validate's rare long-window path over int16 rows: the register
+// budget of anything k_validate can reach counts against its 6 waves per SIMD, and the eight-sample pipelines above need
+// 103 registers once each sample is also converted.  Same operations, same order.
+template <class X>
+static __device__ __noinline__ void bn_move_slim(X a, int n, int w, float *out_, bool var)
+{
+    GLB float *out = (GLB float *)out_;
+    float amean = 0.f, assqdm = 0.f, asum = 0.f;
+    int count = 0;
+    for (int i = 0; i < w; i++) {
+        const float ai = a[i];
+        if (var) { count++; const float delta = ai - amean; amean += delta / (float)count; assqdm += delta * (ai - amean); }
+        else asum += ai;
+    }
+    const float inv = (float)(1.0 / (double)w);
+    if (var) { if (assqdm < 0) assqdm = 0; out[0] = assqdm / (float)count; }
+    else out[0] = asum / (float)w;
+    for (int i = w; i < n; i++) {
+        float ai = a[i], aold = a[i - w];
+        if (var) {
+            const float delta = ai - aold;
+            aold -= amean; amean += delta * inv; ai -= amean;
+            assqdm += (ai + aold) * delta;
+            if (assqdm < 0) assqdm = 0;
+            out[i - w + 1] = assqdm * inv;
+        } else { asum += ai - aold; out[i - w + 1] = asum * inv; }
     }
 }
 
@@ -307,8 +337,13 @@ static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, lon
         if (cfg.pA_var_window <= MV_HIST && cfg.pA_mean_window <= MV_HIST) {
             wave_move_series(x, n, cfg.pA_var_window, cfg.pA_mean_window, wvar, wmean, scr_var, scr_mean, ws);
         } else {
-            if (lane_id() == 0 && wvar) bn_move_var(x, n, cfg.pA_var_window, scr_var);
-            if (lane_id() == 1 && wmean) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+            if constexpr (std::is_same<X, RowI16>::value) {
+                if (lane_id() == 0 && wvar) bn_move_slim(x, n, cfg.pA_var_window, scr_var, true);
+                if (lane_id() == 1 && wmean) bn_move_slim(x, n, cfg.pA_mean_window, scr_mean, false);
+            } else {
+                if (lane_id() == 0 && wvar) bn_move_var(x, n, cfg.pA_var_window, scr_var);
+                if (lane_id() == 1 && wmean) bn_move_mean(x, n, cfg.pA_mean_window, scr_mean);
+            }
         }
         __threadfence_block();
     }
@@ -366,8 +401,13 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(X sig, int S, long long 
     // the series hold the outputs from index window-1 on (the first window-1 are NaN in bottleneck: never in range)
     if (wv <= MV_HIST && wm <= MV_HIST) wave_move_series(x, n, wv, wm, true, true, scr_var, scr_mean, ws);
     else {
-        if (lane_id() == 0) bn_move_var(x, n, wv, scr_var);
-        if (lane_id() == 1) bn_move_mean(x, n, wm, scr_mean);
+        if constexpr (std::is_same<X, RowI16>::value) {
+            if (lane_id() == 0) bn_move_slim(x, n, wv, scr_var, true);
+            if (lane_id() == 1) bn_move_slim(x, n, wm, scr_mean, false);
+        } else {
+            if (lane_id() == 0) bn_move_var(x, n, wv, scr_var);
+            if (lane_id() == 1) bn_move_mean(x, n, wm, scr_mean);
+        }
     }
     __threadfence_block();
     __syncthreads();
@@ -618,7 +658,7 @@ static __device__ void row_exception(adp_row *row, int code)
 
 // persistent grid: blockIdx.x = slot, block = 64 threads
 template <class SIG>
-__global__ void __launch_bounds__(64, 6) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
+__global__ void __launch_bounds__(64, 6) __attribute__((amdgpu_waves_per_eu(6, 6))) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
                                                  PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;
@@ -859,7 +899,7 @@ static __device__ __forceinline__ float sp_pooled(ROW row, int m, int ds, int j)
 {
     // mean-pool of the RAW signal, zero padded tail, numpy order
     const int b = j * ds;
-    return pw_leaf_f32(ds, [&](int k) { int i = b + k; return i < m ? row[i] : 0.0f; }) / (float)ds;
+    return pw_leaf_f32(ds, [&](int k) { int i = b + k; return row.at_or(i, i < m, 0.0f); }) / (float)ds;
 }
 
 // 64 pooled values j0 .. j0 + 63 at once: the 64 * ds raw samples are staged in LDS with coalesced 16-byte loads
@@ -907,7 +947,7 @@ __global__ void __launch_bounds__(64) k_start_peak(SIG sigs, const int32_t *__re
     for (int base = 0; base < end_idx && base < m && op == 0x7fffffff; base += 512) { // 8 tiles per round trip to memory
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = base + u * 64 + ln; v[u] = (i < end_idx && i < m) ? row[i] : -__builtin_inff(); }
+        for (int u = 0; u < 8; u++) { const int i = base + u * 64 + ln; v[u] = row.at_or(i, i < end_idx && i < m, -__builtin_inff()); }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const unsigned long long mk = __ballot(v[u] > thr);

@@ -67,7 +67,7 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
     for (int base = 0; base < n; base += 512) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : x[0]; }
+        for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = ld_or_first(x, i, i < n); }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const float xf = ws_xform(v[u], mode, c);
@@ -91,7 +91,7 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
         for (int base = 0; base < n; base += 512) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = (i < n) ? x[i] : 0.0f; }
+            for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int i = base + u * 64 + ln;

@@ -152,7 +152,7 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
            "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
-           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena", "adp_detect_llr_i16"]
+           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena", "adp_detect_llr_i16", "adp_expand_ragged_i16"]
 
 
 class MinibatchDropped(RuntimeError):
@@ -334,6 +334,11 @@ class Engine:
         self._check(self.lib.adp_expand_ragged(self._h, C.c_void_p(packed_dev), int(bool(is_int16)), C.c_void_p(offs_dev),
                                                C.c_void_p(len_dev), C.c_void_p(scale_dev or None), C.c_void_p(offset_dev or None),
                                                int(n), self.m, C.c_void_p(out_dev)))
+
+    def expand_ragged_i16(self, packed_dev: int, offs_dev: int, len_dev: int, n: int, out_dev: int):
+        """packed raw int16 reads -> raw int16 [n, m] on the device (what detect_llr_rows_i16 reads); asynchronous"""
+        self._check(self.lib.adp_expand_ragged_i16(self._h, C.c_void_p(packed_dev), C.c_void_p(offs_dev), C.c_void_p(len_dev), int(n), self.m,
+                                                   C.c_void_p(out_dev)))
 
     def host_alloc(self, shape, dtype) -> np.ndarray:
         """page-locked host array (staging for h2d_async); release with host_free(arr)"""

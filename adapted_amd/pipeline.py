@@ -45,8 +45,15 @@ class HostPipeline:
         self.ragged = bool(ragged)
         self.eng = lib.Engine(spc, self.N, self.m, device=self.device)
         self.slots = []
+        # int16 input + LLR primary: the kernels read the raw samples themselves (adp_detect_llr_i16) -- no float32 matrix is made
+        self.native_i16 = self.i16 and primary == "llr" and self.m % 4 == 0
         # the float32 minibatch made on the device (calibrated and / or laid out from packed reads); one: detect is serial
-        self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4) if (self.i16 or self.ragged) else None
+        # (native int16 + packed reads: the raw int16 matrix instead)
+        self.dsig16 = None
+        if self.native_i16:
+            self.dsig16 = self.eng.dev_alloc(self.N * self.m * 2) if self.ragged else None
+        elif self.i16 or self.ragged:
+            self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4)
         for _ in range(min(16, max(2, n_slots))):
             sig = self.eng.host_alloc((self.N * self.m,) if self.ragged else (self.N, self.m), np.int16 if self.i16 else np.float32)
             lens = self.eng.host_alloc((self.N,), np.int32)
@@ -99,6 +106,11 @@ class HostPipeline:
         s = self.slots[j]
         self.eng.copy_wait(j)  # this slot's copies only: the next slot's may still be in flight
         dsig, dlen = s["ds"], s["dl"]
+        if self.native_i16:
+            if self.ragged:
+                self.eng.expand_ragged_i16(dsig, s["do"], dlen, n, self.dsig16)
+                dsig = self.dsig16
+            return self.eng.detect_llr_rows_i16(dsig, dlen, s["dcal"], s["dcal"] + self.N * 4, n, self.mb, with_start_peak=self.with_start_peak)
         if self.ragged:  # packed reads (-> calibrated) -> float32 [n, m], NaN beyond each read
             if self.i16:
                 self.eng.expand_ragged(dsig, True, s["do"], dlen, n, self.dsig16, s["dcal"], s["dcal"] + self.N * 4)

@@ -297,6 +297,26 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         for s0 in range(0, R, 1000):
             sig_t[s0:s0 + 1000].div_(w.adc_step).round_().mul_(w.adc_step)
         torch.cuda.synchronize()
+    raw_t = cal_t = None
+    i16_check = None
+    if getattr(w, "int16", False):
+        # the same reads as the sequencer stores them: int16 ADC codes + a per-read calibration (pA = scale * (adc + offset));
+        # the float32 matrix is dropped, every kernel reads the raw samples (adp_detect_llr_i16)
+        sc, of = 0.17, -12.0
+        raw_t = torch.empty((R, m), dtype=torch.int16, device=dev)
+        for s0 in range(0, R, 500):
+            raw_t[s0:s0 + 500] = torch.clamp(torch.round(torch.nan_to_num(sig_t[s0:s0 + 500]) / sc - of), -32768, 32767).to(torch.int16)
+        cal_t = torch.cat([torch.full((R,), sc, dtype=torch.float32, device=dev), torch.full((R,), of, dtype=torch.float32, device=dev)])
+        torch.cuda.synchronize()
+        # parity of the first minibatch: raw path against adp_calibrate_i16 + the float32 path
+        eng.calibrate_i16(raw_t.data_ptr(), len_t.data_ptr(), cal_t.data_ptr(), cal_t.data_ptr() + R * 4, mb, sig_t.data_ptr())
+        a, _ = eng.detect_llr_rows(sig_t.data_ptr(), len_t.data_ptr(), mb, mb, with_start_peak=not w.no_start_peak, device_ptrs=True, tails_nan=True)
+        b, _ = eng.detect_llr_rows_i16(raw_t.data_ptr(), len_t.data_ptr(), cal_t.data_ptr(), cal_t.data_ptr() + R * 4, mb, mb,
+                                       with_start_peak=not w.no_start_peak)
+        a["open_pores_more"] = 0; b["open_pores_more"] = 0
+        i16_check = bool(a.tobytes() == b.tobytes())
+        sig_t = None
+        torch.cuda.empty_cache()
     gathered = None
     if world > 1 and rank == 0:
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
@@ -310,6 +330,11 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             rows = cnn_mod.detect_rows_device(engines[k], sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs,
                                               lens_host[s0:s0 + Rs], None, spc, minibatch=mb)
             engines[k].h2d(rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize, rows)
+            return
+        if raw_t is not None:
+            engines[k].detect_llr_rows_i16(raw_t.data_ptr() + s0 * m * 2, len_t.data_ptr() + s0 * 4, cal_t.data_ptr() + s0 * 4,
+                                           cal_t.data_ptr() + (R + s0) * 4, Rs, mb, with_start_peak=not w.no_start_peak,
+                                           rows_dev=rows_t.data_ptr() + s0 * lib.ROW_DTYPE.itemsize)
             return
         engines[k].detect_llr_rows(sig_t.data_ptr() + s0 * m * 4, len_t.data_ptr() + s0 * 4, Rs, mb,
                                    with_start_peak=not w.no_start_peak, device_ptrs=True,
@@ -385,7 +410,8 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         dom = max(kavg, key=kavg.get)
         # 4 bytes per PRELOADED sample, each read once; a launch covers the Rs reads of one engine
         mean_samples = float(np.minimum(lens_host, m).mean())
-        b_alg = 4.0 * mean_samples * Rs
+        bps = 2.0 if raw_t is not None else 4.0  # bytes per preloaded sample as it lies in HBM
+        b_alg = bps * mean_samples * Rs
         achieved = b_alg / (kavg[dom] * 1e-3) / 1e9
         step_s = dt / w.steps
         out = {
@@ -405,7 +431,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                      if traffic and dom in traffic and w.lens == "full" and w.primary == "llr" else None),
                          "traffic_source": (traffic["_file"] + " (rocprofv3 --pmc, FETCH_SIZE doubled per MI355X_MICROARCH.md)") if traffic else None,
                          "kernel_ms": kavg[dom], "algorithmic_bytes_per_launch": b_alg,
-                         "whole_path_frac": (4.0 * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS},
+                         "whole_path_frac": (bps * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "kernel_ms_sum": sum(kavg.values()),
         }
@@ -422,6 +448,10 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                "whole_path_frac": CNN_FLOP_PER_POS * L1 * R / step_s / 1e12 / F32_MFMA_PEAK_TF,
                                "whole_path_hbm_frac": (4.0 * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS,
                                "slowest_kernel": dom, "slowest_kernel_ms": kavg[dom]}
+        if raw_t is not None:
+            out["config"]["workload"] = out["config"]["workload"].replace("RNA004 LLR", "RNA004 LLR over RAW int16 ADC samples + per-read calibration (2 B per sample in HBM; extension of the float32 boundary)")
+            out["config"]["rows_of_first_minibatch_equal_float32_path"] = i16_check
+            out["dtype"] = "int16 samples calibrated to f32 in registers, f32 statistics, f64 cumulative sums + LLR trace"
         if w.lens != "full":
             out["config"]["lens"] = "%s: mean %.0f samples of m = %d preloaded (%.0f %% of the matrix is NaN padding)" % (
                 w.lens, mean_samples, m, 100.0 * (1.0 - mean_samples / m))
@@ -433,7 +463,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                       "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
                                       "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7]),
                                       "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23])}
-        if world == 1 and w.cpu_sample > 0 and w.primary == "llr" and w.lens == "full" and w.adc_step == 0:
+        if world == 1 and w.cpu_sample > 0 and w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and raw_t is None:
             n_s = min(w.cpu_sample, R)
             n_all = min(w.cpu_sample_all, R // max(cpu_procs, 1)) if cpu_procs > 1 else 0
             out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows, lens_host, cpu_pool, cpu_procs if n_all > 0 else 0,
@@ -442,7 +472,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             out["cpu_baseline"] = None
     for e in engines:
         e.close()
-    del sig_t, rows_t, rows_bufs, len_t
+    del sig_t, rows_t, rows_bufs, len_t, raw_t, cal_t
     state.clear()
     torch.cuda.empty_cache()
     return out
@@ -516,7 +546,8 @@ def main():
                          "(pinned staging, H2D overlapped with detect) and print the PCIe-inclusive rate -- never the headline value")
     ap.add_argument("--group", type=int, default=4, help="with --host-pipeline: minibatches per staging slot / detect call")
     ap.add_argument("--fill-threads", type=int, default=1, help="with --host-pipeline: host threads copying a slot's reads (the stand-in reader)")
-    ap.add_argument("--int16", action="store_true", help="with --host-pipeline: stream raw int16 ADC samples and calibrate on the device")
+    ap.add_argument("--int16", action="store_true", help="the resident workload as RAW int16 ADC samples + per-read calibration (every kernel reads them "
+                                                         "natively: adp_detect_llr_i16); with --host-pipeline: stream raw int16 samples from host memory")
     args = ap.parse_args()
 
     world_env = int(os.environ.get("WORLD_SIZE", "0"))
@@ -530,7 +561,7 @@ def main():
     if args.reads is None:
         args.reads = 96000 if args.primary == "llr" else (4000 if args.max_obs_trace > 32000 else 32000)
     default_run = (args.primary == "llr" and args.lens == "full" and args.adc_step == 0 and args.host_pipeline == 0 and
-                   args.max_obs_trace == 200000 and not args.no_start_peak)
+                   args.max_obs_trace == 200000 and not args.no_start_peak and not args.int16)
 
     # the all-cores CPU baseline runs in worker processes: start them before this process initialises the GPU
     cpu_pool, cpu_procs = None, 0
@@ -567,7 +598,8 @@ def main():
         sec = {}
         for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=4000, steps=4, warmup=1)),
                          ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
-                         ("pareto", dict(lens="pareto", steps=4, warmup=1))):
+                         ("pareto", dict(lens="pareto", steps=4, warmup=1)),
+                         ("int16", dict(int16=True, steps=4, warmup=1))):
             w = argparse.Namespace(**vars(args))
             w.cpu_sample = 0
             for k, v in kw.items():

@@ -263,6 +263,10 @@ int adp_calibrate_i16(adp_handle *h, const int16_t *raw, const int32_t *full_len
 int adp_expand_ragged(adp_handle *h, const void *packed, int is_int16, const int64_t *offsets, const int32_t *full_len,
                       const float *scale, const float *offset, int n_reads, int m, float *signals_out);
 
+/* Packed raw samples -> the raw int16 [n, m] matrix adp_detect_llr_i16 reads (zeros behind each read; DEVICE pointers). */
+int adp_expand_ragged_i16(adp_handle *h, const int16_t *packed, const int64_t *offsets, const int32_t *full_len, int n_reads, int m,
+                          int16_t *raw_out);
+
 /* Streaming input (adapted_amd/pipeline.py): page-locked host staging memory, and a host-to-device copy on the handle's
  * COPY stream (neither the compute stream nor its side stream), so that the copy of the next minibatch overlaps the
  * detect call of the current one.  adp_copy_mark(slot) marks the copies issued so far (slot in [0, 16));
