@@ -1,6 +1,6 @@
 """Differential soak (development aid, GPU box): random minibatches -- heavy-tailed lengths, values on an ADC grid or not,
 several presets and windows -- through the HIP path and the CPU oracle; prints the number of differing fields.
-    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big | candidates | cnn | predict]
+    python tests/soak_vs_oracle.py [n_rounds] [start_peak | big | candidates | cnn | predict | int16]
 cnn: the whole CNN path (prepare -> hand-written conv stack -> predict -> candidate validation, incl. the shared-sweep
 statistics of cand_stats.h at windows beyond 32 k samples -> short-read fallback), the oracle validating the device's
 predictions; predict: cnn_predict on random scores quantised to a coarse grid (ties, plateaus, reads below the mask level)
@@ -70,6 +70,54 @@ def soak_cnn(rounds):
     return 1 if bad_total else 0
 
 
+def soak_int16(rounds):
+    """adp_detect_llr_i16 (kernels reading raw int16 + per-read calibration) against adp_calibrate_i16 + adp_detect_llr:
+    rows must be byte-identical (no oracle involved: the float32 path is pinned elsewhere)"""
+    rng = np.random.default_rng(31)
+    bad_total = 0
+    for it in range(rounds):
+        chem = ["RNA004", "RNA002"][it % 2]
+        spc = get_chemistry_specific_config(chem)
+        spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+        spc.core.max_obs_trace = int(rng.choice([4000, 16000, 25000, 60000, 200000]))
+        spc.mvs_polya.mvs_detect_overwrite = bool(it % 3 == 2)
+        spc.med_shift.detect_med_shift = bool(it % 2)
+        if it % 4 == 3:
+            spc.mvs_polya.pA_var_window = int(rng.choice([50, 101, 400]))   # (400: beyond the LDS series path)
+            spc.mvs_polya.pA_mean_window = int(rng.choice([10, 23, 350]))
+            spc.mvs_polya.search_window = 900
+        spc.update_primary_method()
+        spc.update_sig_preload_size()
+        m = spc.sig_preload_size
+        if m % 4:
+            continue
+        n = 64 if m > 100000 else 160
+        lo = spc.core.min_obs_adapter + 2 * spc.core.downscale_factor + 8
+        lens = np.array([m + 7 if rng.random() < 0.4 else max(lo, synth.pareto_length(it, i, lo=3000, hi=4 * m)) for i in range(n)], dtype=np.int32)
+        sig, lens = synth.synth_batch(500 + it, 0, n, m, lens)
+        scale = rng.uniform(0.1, 0.25, n).astype(np.float32)
+        offset = rng.integers(-200, 50, n).astype(np.float32)
+        raw = np.clip(np.round(np.nan_to_num(sig) / scale[:, None] - offset[:, None]), -32768, 32767).astype(np.int16)
+        eng = lib.Engine(spc, n, m, device=0)
+        d_raw, d_len, d_cal, d_f32 = eng.dev_alloc(n * m * 2), eng.dev_alloc(n * 4), eng.dev_alloc(2 * n * 4), eng.dev_alloc(n * m * 4)
+        eng.h2d(d_raw, raw); eng.h2d(d_len, lens); eng.h2d(d_cal, np.concatenate([scale, offset]))
+        mb = n // 2
+        eng.calibrate_i16(d_raw, d_len, d_cal, d_cal + n * 4, n, d_f32)
+        a, ma = eng.detect_llr_rows(d_f32, d_len, n, mb, with_start_peak=True, device_ptrs=True, tails_nan=bool(it % 2))
+        b, mbs = eng.detect_llr_rows_i16(d_raw, d_len, d_cal, d_cal + n * 4, n, mb, with_start_peak=True)
+        a["open_pores_more"] = 0; b["open_pores_more"] = 0
+        bad = int((a.view(np.uint8).reshape(n, -1) != b.view(np.uint8).reshape(n, -1)).any(axis=1).sum()) + int((ma != mbs).sum())
+        print("int16 round %d %s T=%d m=%d overwrite=%d windows=(%d,%d) pass=%d/%d differing rows: %d" % (
+            it, chem, spc.core.max_obs_trace, m, spc.mvs_polya.mvs_detect_overwrite, spc.mvs_polya.pA_var_window, spc.mvs_polya.pA_mean_window,
+            int(b["success"].sum()), n, bad), flush=True)
+        bad_total += bad
+        for p_ in (d_raw, d_len, d_cal, d_f32):
+            eng.dev_free(p_)
+        eng.close()
+    print("TOTAL differing rows:", bad_total)
+    return 1 if bad_total else 0
+
+
 def soak_predict(rounds):
     import torch
     from test_gpu_cnn import _ref_predict
@@ -105,6 +153,8 @@ def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     if len(sys.argv) > 2 and sys.argv[2] == "cnn":
         return soak_cnn(rounds)
+    if len(sys.argv) > 2 and sys.argv[2] == "int16":
+        return soak_int16(rounds)
     if len(sys.argv) > 2 and sys.argv[2] == "predict":
         import torch
 
