@@ -952,7 +952,8 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
     int NT = 4; { long long best = -1; for (int nt = 4; nt >= 2; nt--) { const long long pb = 64 * nt, cover = (L1 + pb - 1) / pb * pb; if (best < 0 || cover < best) { best = cover; NT = nt; } } }
     const int PB = 64 * NT, tiles = (L1 + PB - 1) / PB, Lpad = tiles * PB + 8;
     size_t per_read = (size_t)CNN_C * Lpad * 4;
-    size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each if (cap_reads < 1) cap_reads = 1;
+    size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
+    if (cap_reads < 1) cap_reads = 1;
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
     if (h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
         for (int k = 0; k < 2; k++) {

@@ -133,8 +133,14 @@ def cnn_score(batch_of_prepared_signals, model, engine=None):
     if engine is None:
         if len(model.state_dict()) == 0:
             raise ValueError("Model weights were not loaded")
+        x = batch_of_prepared_signals
+        # in slices of <= 2 GiB of 64-channel activations: MIOpen returns wrong scores for a batch beyond 4 GiB
+        per_read = 64 * 4 * ((int(x.shape[-1]) - 1) // 3 + 1)
+        step = max(1, (2 << 30) // per_read)
         with torch.no_grad():
-            return model(batch_of_prepared_signals)
+            if x.shape[0] <= step:
+                return model(x)
+            return torch.cat([model(x[s0:s0 + step]) for s0 in range(0, x.shape[0], step)], dim=0)
     x = batch_of_prepared_signals.contiguous()
     n, _, Lc = x.shape
     Lo = 3 * ((Lc - 1) // 3 + 1) - 2

@@ -42,6 +42,12 @@ for name, fn in (("hip", lambda: eng.cnn_forward(x.data_ptr(), n, Lc, out.data_p
         fn()
         print("   ", eng.kernel_times())
         eng.set_profiling(False)
+# (compared in slices of 64 reads: MIOpen's own result is WRONG for a batch whose activations pass 4 GiB -- 1000 reads of the
+# 200k window: |whole - sliced| ~ 20 on reads 0-299 and 700-999 -- which the library's own chunking avoids)
+worst = scale = 0.0
 with torch.no_grad():
-    ref = model(x)
-print("max |hip - torch| =", float((ref - out).abs().max()), "of scale", float(ref.abs().max()))
+    for s0 in range(0, n, 64):
+        ref = model(x[s0:s0 + 64])
+        worst = max(worst, float((ref - out[s0:s0 + 64]).abs().max()))
+        scale = max(scale, float(ref.abs().max()))
+print("max |hip - torch (64 reads at a time)| =", worst, "of scale", scale)
