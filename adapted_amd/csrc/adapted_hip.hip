@@ -21,6 +21,7 @@ __device__ unsigned long long g_dbg[24] = {0};
 #include "validate.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
+#include "trace_api.h"
 #include "wave_stats.h"
 
 static thread_local std::string g_err;
@@ -76,6 +77,7 @@ struct adp_handle {
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
     DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used;
+    DevBuf tr_buf, tr_meta; // adp_c_llr_trace: staging of host arrays
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
@@ -233,7 +235,7 @@ int adp_destroy(adp_handle *h)
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -685,6 +687,73 @@ __global__ void k_debug_log(const double *in, double *out, int n)
     const LDS double *lt = (const LDS double *)lt_;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = log_cr_impl(in[i], lt, [](double u) { return log(u); });
+}
+
+// c_llr_trace / c_llr_trace_gains / _gains for a batch of float64 signals (trace_api.h)
+int adp_c_llr_trace(adp_handle *h, const double *raw, const int32_t *len, const int32_t *start, const int32_t *end, int n_reads,
+                    int L, const adp_trace_args *args, int flags, double *gain_out, double *c_io, double *c2_io)
+{
+    if (!h || !len || !start || !end || !args || !gain_out || n_reads < 1 || L < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
+    const bool from_sums = (flags & ADP_TRACE_FROM_SUMS) != 0, in_dev = (flags & ADP_IN_DEVICE) != 0, out_dev = (flags & ADP_OUT_DEVICE) != 0;
+    if (from_sums ? (!c_io || !c2_io) : !raw) { g_err = "bad argument: no input signal / sums"; return ADP_ERR_INVALID; }
+    if (!from_sums && ((c_io == nullptr) != (c2_io == nullptr))) { g_err = "bad argument: c and c2 go together"; return ADP_ERR_INVALID; }
+    const adp_trace_args &a = *args;
+    if (a.stride < 1 || a.min_obs < 0 || a.border_trim < 0) { g_err = "stride must be >= 1, offsets >= 0"; return ADP_ERR_INVALID; }
+    if (a.polya_early_stopping > 0) {
+        if (a.adapter_early_stop_stride < 1 || a.polya_early_stop_stride < 1 || a.adapter_early_stop_window < 0 || a.polya_early_stop_window < 0) { g_err = "early-stop windows / strides out of range"; return ADP_ERR_INVALID; }
+        if (a.adapter_early_stop_stride % a.stride || a.polya_early_stop_stride % a.stride) { g_err = "early-stop stride is not a multiple of stride (the reference asserts, _c_llr.pyx:137-138)"; return ADP_ERR_INVALID; }
+    } else if (a.adapter_early_stopping > 0) {
+        if (a.adapter_early_stop_stride < 1 || a.adapter_early_stop_window < 0) { g_err = "early-stop window / stride out of range"; return ADP_ERR_INVALID; }
+        if (a.adapter_early_stop_stride % a.stride) { g_err = "early-stop stride is not a multiple of stride (the reference asserts, _c_llr.pyx:102)"; return ADP_ERR_INVALID; }
+    }
+    for (int r = 0; r < n_reads; r++)
+        if (len[r] < 0 || len[r] > L || start[r] < 0 || start[r] > end[r] || end[r] > len[r]) { g_err = "need 0 <= start <= end <= len <= L for every read"; return ADP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->prof.clear(); h->ev_used = 0;
+    const size_t row = (size_t)L * 8, mat = row * n_reads;
+    // device staging: [raw | c | c2 | gain] as far as the caller's arrays are host memory
+    const int need = (in_dev ? 0 : (from_sums ? 2 : 1)) + ((!from_sums && (!c_io || !out_dev)) ? 2 : 0) + (out_dev ? 0 : 1);
+    if (need && h->tr_buf.ensure(mat * need)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    if (h->tr_meta.ensure((size_t)n_reads * 12)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    double *pool = h->tr_buf.as<double>();
+    auto take = [&]() { double *p = pool; pool += (size_t)L * n_reads; return p; };
+    int32_t *dlen = h->tr_meta.as<int32_t>(), *dstart = dlen + n_reads, *dend = dstart + n_reads;
+    HIPCHK(hipMemcpyAsync(dlen, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dstart, start, (size_t)n_reads * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dend, end, (size_t)n_reads * 4, hipMemcpyHostToDevice, h->stream));
+    const double *dc, *dc2;
+    double *dc_w = nullptr, *dc2_w = nullptr;
+    if (from_sums) {
+        if (in_dev) { dc = c_io; dc2 = c2_io; }
+        else {
+            double *t0 = take(), *t1 = take();
+            HIPCHK(hipMemcpyAsync(t0, c_io, mat, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(t1, c2_io, mat, hipMemcpyHostToDevice, h->stream));
+            dc = t0; dc2 = t1;
+        }
+    } else {
+        const double *draw = raw;
+        if (!in_dev) { double *t = take(); HIPCHK(hipMemcpyAsync(t, raw, mat, hipMemcpyHostToDevice, h->stream)); draw = t; }
+        if (c_io && out_dev) { dc_w = c_io; dc2_w = c2_io; } else { dc_w = take(); dc2_w = take(); }
+        { Scope s(h, "k_trace_cumsum");
+          hipLaunchKernelGGL(k_trace_cumsum, dim3(n_reads), dim3(64), 0, h->stream, draw, dlen, L, n_reads, dc_w, dc2_w); }
+        dc = dc_w; dc2 = dc2_w;
+    }
+    double *dg = out_dev ? gain_out : take();
+    TraceArgs ta = {a.min_obs, a.border_trim, a.stride, a.adapter_early_stopping, a.adapter_early_stop_window, a.adapter_early_stop_stride,
+                    a.polya_early_stopping, a.polya_early_stop_window, a.polya_early_stop_stride};
+    { Scope s(h, "k_trace_gains");
+      hipLaunchKernelGGL(k_trace_gains, dim3(n_reads), dim3(64), 0, h->stream, dc, dc2, dlen, dstart, dend, L, ta, dg); }
+    HIPCHK(hipGetLastError());
+    if (!out_dev) {
+        HIPCHK(hipMemcpyAsync(gain_out, dg, mat, hipMemcpyDeviceToHost, h->stream));
+        if (!from_sums && c_io) {
+            HIPCHK(hipMemcpyAsync(c_io, dc_w, mat, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(c2_io, dc2_w, mat, hipMemcpyDeviceToHost, h->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
 }
 
 int adp_debug_log(adp_handle *h, const double *host_in, double *host_out, int n)

@@ -152,7 +152,18 @@ EXPORTS = ["adp_abi_version", "adp_sizeof_cfg", "adp_sizeof_row", "adp_last_erro
            "adp_memcpy_h2d", "adp_memcpy_d2h", "adp_set_profiling", "adp_kernel_times", "adp_debug_fetch",
            "adp_debug_llr_upto", "adp_debug_log", "adp_cnn_topk", "adp_host_alloc", "adp_host_free", "adp_memcpy_h2d_async",
            "adp_copy_mark", "adp_copy_wait", "adp_debug_divcheck", "adp_calibrate_i16", "adp_expand_ragged", "adp_set_layout",
-           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena", "adp_detect_llr_i16", "adp_expand_ragged_i16"]
+           "adp_cnn_set_weights", "adp_cnn_forward", "adp_cnn_predict", "adp_detect_cnn", "adp_open_pores_arena", "adp_detect_llr_i16", "adp_expand_ragged_i16",
+           "adp_c_llr_trace"]
+
+
+class AdpTraceArgs(C.Structure):
+    """struct adp_trace_args (include/adapted_hip.h): the keyword arguments of the reference's c_llr_trace"""
+    _fields_ = [(k, C.c_int32) for k in ("min_obs", "border_trim", "stride", "adapter_early_stopping", "adapter_early_stop_window",
+                                         "adapter_early_stop_stride", "polya_early_stopping", "polya_early_stop_window",
+                                         "polya_early_stop_stride")]
+
+
+ADP_TRACE_FROM_SUMS = 64
 
 
 class MinibatchDropped(RuntimeError):
@@ -480,6 +491,34 @@ class Engine:
                                                      flags, rows.ctypes.data_as(C.c_void_p)))
         del keep
         return self.attach_open_pores(rows)
+
+    def c_llr_trace(self, raw, lens, starts, ends, args: "AdpTraceArgs", sums=None, return_c_c2: bool = False):
+        """adp_c_llr_trace: the reference's `c_llr_trace` (`c_llr_trace_gains` with ``sums=(c, c2)``) for a batch -- raw float64
+        [n, L], per-read lens / starts / ends -> gains float64 [n, L] (and c, c2)"""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        ends = np.ascontiguousarray(ends, dtype=np.int32)
+        flags = 0
+        if sums is not None:
+            c = np.ascontiguousarray(sums[0], dtype=np.float64)
+            c2 = np.ascontiguousarray(sums[1], dtype=np.float64)
+            n, L = c.shape
+            rawp = None
+            flags |= ADP_TRACE_FROM_SUMS
+        else:
+            raw = np.ascontiguousarray(raw, dtype=np.float64)
+            n, L = raw.shape
+            rawp = raw.ctypes.data_as(C.c_void_p)
+            c = np.zeros((n, L)) if return_c_c2 else None
+            c2 = np.zeros((n, L)) if return_c_c2 else None
+        if not (lens.size == starts.size == ends.size == n):
+            raise ValueError("lens / starts / ends need one entry per read")
+        g = np.zeros((n, L))
+        self._check(self.lib.adp_c_llr_trace(self._h, rawp, lens.ctypes.data_as(C.c_void_p), starts.ctypes.data_as(C.c_void_p),
+                                             ends.ctypes.data_as(C.c_void_p), int(n), int(L), C.byref(args), flags,
+                                             g.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p) if c is not None else None,
+                                             c2.ctypes.data_as(C.c_void_p) if c2 is not None else None))
+        return (g, c, c2) if return_c_c2 else g
 
     def cnn_topk(self, scores_ptr: int, adapter_pos_ptr: int, polya_pos_ptr: int, n: int, Lo: int, k: int):
         """the k > 1 part of C3 behind given arg-maxes (tests): (cand int32 [n, k], n_peaks int32 [n]); device pointers in"""

@@ -277,6 +277,28 @@ int adp_memcpy_h2d_async(adp_handle *h, void *dst, const void *src_pinned, uint6
 int adp_copy_mark(adp_handle *h, int slot);
 int adp_copy_wait(adp_handle *h, int slot);
 
+/* The reference's native module (adapted/detect/_c_llr.pyx, imported at adapted/detect/llr.py:18) as a batched call:
+ * `c_llr_trace(raw_signal, start, end, min_obs, border_trim, stride, adapter_early_stopping, adapter_early_stop_window,
+ * adapter_early_stop_stride, polya_early_stopping, polya_early_stop_window, polya_early_stop_stride, return_c_c2)` (:202-236)
+ * for n_reads float64 signals -- raw [n_reads, L], read r valid in [0, len[r]) -- with `_gains` (:67-88) and both early-stopping
+ * forms (`_gains_w_early_stop` :91-122, `_gains_w_polya_early_stop` :125-173) behind the same dispatch (:190-197).
+ *   gain_out [n_reads, L]   zeros outside the computed points, as np.zeros_like(c)
+ *   c_io, c2_io [n_reads, L] np.cumsum(raw), np.cumsum(raw * raw): outputs (may be NULL), or -- with ADP_TRACE_FROM_SUMS, the
+ *                           form of `c_llr_trace_gains` (:176-199) and `_gains` -- the INPUTS (raw is ignored, may be NULL)
+ *   len, start, end         HOST int32 [n_reads] (checked here: 0 <= start <= end <= len <= L)
+ *   flags                   ADP_IN_DEVICE: raw (or the sums) are device pointers; ADP_OUT_DEVICE: gain_out (and the sums when
+ *                           they are outputs) are device pointers
+ * Returns ADP_ERR_INVALID where the reference asserts (an early-stop stride that is not a multiple of `stride`) or would
+ * index outside its arrays.  The product path does not go through here (adp_detect_llr has its own fused passes). */
+typedef struct adp_trace_args {
+    int32_t min_obs, border_trim, stride;
+    int32_t adapter_early_stopping, adapter_early_stop_window, adapter_early_stop_stride;
+    int32_t polya_early_stopping, polya_early_stop_window, polya_early_stop_stride;
+} adp_trace_args;
+#define ADP_TRACE_FROM_SUMS 64
+int adp_c_llr_trace(adp_handle *h, const double *raw, const int32_t *len, const int32_t *start, const int32_t *end, int n_reads,
+                    int L, const adp_trace_args *args, int flags, double *gain_out, double *c_io, double *c2_io);
+
 /* Per-kernel timing of the LAST detect call, measured with HIP events on the handle's stream.
  * Enable with adp_set_profiling(h, 1).  names_out: up to cap pointers to static strings. */
 int adp_set_profiling(adp_handle *h, int on);

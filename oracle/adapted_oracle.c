@@ -435,6 +435,60 @@ void orc_gains(long start, long end, const double *c, const double *c2, long n,
     }
 }
 
+/* ------------------------------------------------------------------ the _c_llr module as an API (SURVEY 8(b) "Native", 8(f) rank 4)
+ * c_llr_trace / c_llr_trace_gains / _gains with stride and both early-stopping forms, reference adapted/detect/_c_llr.pyx:67-236.
+ * np.cumsum of float64 (first element taken as is), np.multiply(raw, raw) rounded before it is added. */
+void orc_cumsum_f64(const double *raw, long n, double *c, double *c2)
+{
+    double a = 0, b = 0;
+    for (long i = 0; i < n; i++) {
+        double v = raw[i], q = v * v;
+        if (i == 0) { a = v; b = q; } else { a += v; b += q; }
+        c[i] = a; c2[i] = b;
+    }
+}
+
+/* np.diff(g[lo:i:stride]).mean(), Python slice rules for a negative lo (_c_llr.pyx:115, :160, :165); NaN for < 2 elements */
+static double diff_mean(const double *g, long n, long lo, long i, long stride, double *tmp)
+{
+    if (lo < 0) { lo += n; if (lo < 0) lo = 0; }
+    long cnt = 0;
+    if (i > lo) cnt = (i - lo + stride - 1) / stride;
+    if (cnt < 2) return NAN; /* mean of an empty array */
+    for (long k = 0; k + 1 < cnt; k++) tmp[k] = g[lo + (k + 1) * stride] - g[lo + k * stride];
+    return orc_np_sum_f64(tmp, cnt - 1) / (double)(cnt - 1);
+}
+
+/* -> 0, or -1 when the reference's assert (early-stop stride % stride == 0) fails.  tmp: >= n doubles of scratch. */
+int orc_c_llr_trace_gains(const double *c, const double *c2, long n, long start, long end, long min_obs, long border_trim,
+                          long stride, long a_es, long a_w, long a_s, long p_es, long p_w, long p_s, double *g, double *tmp)
+{
+    for (long i = 0; i < n; i++) g[i] = 0.0;
+    if (p_es > 0) { if (a_s % stride || p_s % stride) return -1; }
+    else if (a_es > 0) { if (a_s % stride) return -1; }
+    const long s0 = start + min_obs;
+    const double vs = (double)(end - start) * log(var_c(start, end, c, c2));
+    int adapter_found = 0;
+    for (long i = s0; i < end - border_trim; i += stride) {
+        if (p_es > 0) {
+            if (!adapter_found && i >= s0 + a_w && (i - s0) % a_s == 0) {
+                if (diff_mean(g, n, i - a_w, i, stride, tmp) < 0) adapter_found = 1;
+            }
+            if (adapter_found) {
+                if (diff_mean(g, n, i - p_w, i, stride, tmp) > 0) break;
+            }
+        } else if (a_es > 0) {
+            if (i >= s0 + a_w && (i - s0) % a_s == 0) {
+                if (diff_mean(g, n, i - a_w, i, stride, tmp) < 0) break;
+            }
+        }
+        double h = (double)(i - start) * log(var_c(start, i, c, c2));
+        double t = (double)(end - i) * log(var_c(i, end, c, c2));
+        g[i] = vs - (h + t);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ scipy find_peaks */
 
 typedef struct {

@@ -287,6 +287,34 @@ def norm_params(batch, T, thresh):
     return rc, out
 
 
+def c_llr_trace(raw_signal, start, end, min_obs, border_trim, stride=1, adapter_early_stopping=0, adapter_early_stop_window=500,
+                adapter_early_stop_stride=100, polya_early_stopping=0, polya_early_stop_window=50, polya_early_stop_stride=10,
+                return_c_c2=0, sums=None):
+    """adapted/detect/_c_llr.pyx:202-236 (and :176-199 with ``sums=(c, c2)``), restated in oracle/adapted_oracle.c"""
+    L = lib()
+    if sums is None:
+        raw = np.ascontiguousarray(raw_signal, dtype=np.float64)
+        n = raw.size
+        c = np.zeros(n)
+        c2 = np.zeros(n)
+        L.orc_cumsum_f64(raw.ctypes.data_as(C.c_void_p), C.c_long(n), c.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p))
+    else:
+        c = np.ascontiguousarray(sums[0], dtype=np.float64)
+        c2 = np.ascontiguousarray(sums[1], dtype=np.float64)
+        n = c.size
+    g = np.zeros(n)
+    tmp = np.zeros(max(n, 1))
+    L.orc_c_llr_trace_gains.restype = C.c_int
+    rc = L.orc_c_llr_trace_gains(c.ctypes.data_as(C.c_void_p), c2.ctypes.data_as(C.c_void_p), C.c_long(n), C.c_long(start), C.c_long(end),
+                                 C.c_long(min_obs), C.c_long(border_trim), C.c_long(stride), C.c_long(adapter_early_stopping),
+                                 C.c_long(adapter_early_stop_window), C.c_long(adapter_early_stop_stride), C.c_long(polya_early_stopping),
+                                 C.c_long(polya_early_stop_window), C.c_long(polya_early_stop_stride),
+                                 g.ctypes.data_as(C.c_void_p), tmp.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise AssertionError("early-stop stride is not a multiple of stride")
+    return (g, c, c2) if return_c_c2 else g
+
+
 def find_peaks(x, distance=None, prominence=None, width=None, rel_height=0.5, cap=None):
     L = lib()
     x = np.ascontiguousarray(x, dtype=np.float64)
