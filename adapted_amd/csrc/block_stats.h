@@ -238,19 +238,29 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     const int nchunk = n / 8192;
     const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
     auto slab_off = [&](int q) { return (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
-    // software pipeline: the next slab's loads fly while this one is summed
-    float4 v[4], vn[4];
-    if (myslabs > 0) {
-        const long long p = slab_off(0);
+    // software pipeline: the loads of the next PF slabs fly (as raw samples) while this one is summed
+    constexpr int PF = X::PREFETCH;
+    typename X::Raw4 pf[PF][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = x.f4u_in(p + (u * 64 + ln) * 4);
-    }
+    for (int d = 0; d < PF; d++)
+        if (d < myslabs) {
+            const long long p = slab_off(d);
+#pragma unroll
+            for (int u = 0; u < 4; u++) pf[d][u] = x.raw4u_in(p + (u * 64 + ln) * 4);
+        }
     float slabsum = 0.0f; // lane j (< 8): sum of slab j of the current chunk
     for (int q = 0; q < myslabs; q++) {
-        if (q + 1 < myslabs) {
-            const long long p = slab_off(q + 1);
+        float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) vn[u] = x.f4u_in(p + (u * 64 + ln) * 4);
+        for (int u = 0; u < 4; u++) v[u] = x.cook4(pf[0][u]);
+#pragma unroll
+        for (int d = 0; d + 1 < PF; d++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) pf[d][u] = pf[d + 1][u];
+        if (q + PF < myslabs) {
+            const long long p = slab_off(q + PF);
+#pragma unroll
+            for (int u = 0; u < 4; u++) pf[PF - 1][u] = x.raw4u_in(p + (u * 64 + ln) * 4);
         }
         ws_sync(); // this wave's previous chain reads of its staging rows are done
         uint32_t flags = 0;
@@ -291,8 +301,6 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
             const int ch = w + 4 * (q >> 3);
             if (ln == 0) bs->chunk_sum[ch & (BS_MAXCHUNK - 1)] = cs;
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = vn[u];
     }
     __syncthreads();
     if (tid == 0) for (int ch = 0; ch < nchunk; ch++) total += bs->chunk_sum[ch]; // numpy adds the chunk sums in sequence

@@ -96,6 +96,12 @@ struct RowF32 {
         const adp_f4u v = *reinterpret_cast<const GLB adp_f4u *>(p + i);
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    // raw4u_in / cook4: the load and the conversion of f4u_in apart, for software pipelines that keep the RAW samples in flight
+    // (PREFETCH = how many such steps a streaming loop keeps ahead: the same bytes in flight for either row type)
+    typedef float4 Raw4;
+    static constexpr int PREFETCH = 1;
+    __device__ __forceinline__ Raw4 raw4u_in(long long i) const { return f4u(i); }
+    __device__ __forceinline__ float4 cook4(const Raw4 &v) const { return v; }
     __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
     __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
     __device__ __forceinline__ long long diff(const RowF32 &o) const { return p - o.p; }
@@ -145,6 +151,15 @@ struct RowI16 {
         const adp_s4 w = {v.x, v.y, v.z, v.w};
         return cal4(w);
     }
+    typedef adp_s4 Raw4;
+    static constexpr int PREFETCH = 2; // (3 with 4 workgroups per CU for the registers: slower, 29.5 vs 26.4 ms -- the kernel wants its 5 waves per SIMD)
+    __device__ __forceinline__ Raw4 raw4u_in(long long i) const
+    {
+        const adp_s4u v = __builtin_nontemporal_load(reinterpret_cast<const GLB adp_s4u *>(p + i));
+        const adp_s4 w = {v.x, v.y, v.z, v.w};
+        return w;
+    }
+    __device__ __forceinline__ float4 cook4(const Raw4 &v) const { return cal4(v); }
     __device__ __forceinline__ bool vec_ok() const { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
     __device__ __forceinline__ uintptr_t key() const { return reinterpret_cast<uintptr_t>(p); }
     __device__ __forceinline__ long long diff(const RowI16 &o) const { return p - o.p; }
