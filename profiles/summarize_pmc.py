@@ -11,7 +11,11 @@ usage: summarize_pmc.py <fetch pass: counter_collection.csv | results.db> <write
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import kname  # noqa: E402
 
 
 def per_kernel_max(path):
@@ -22,11 +26,11 @@ def per_kernel_max(path):
 
         rows = sqlite3.connect(path).execute("select kernel_name, value from counters_collection")
         for name, value in rows:
-            k = name.split("(")[0].replace("void ", "")
+            k = kname(name)
             best[k] = max(best[k], float(value))
         return best
     for row in csv.DictReader(open(path)):
-        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+        k = kname(row["Kernel_Name"])
         best[k] = max(best[k], float(row["Counter_Value"]))
     return best
 
@@ -39,9 +43,9 @@ def stats(db, out):
         w = csv.writer(fh)
         w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
         for name, calls, tot, avg, pct in rows:
-            w.writerow([name.split("(")[0].replace("void ", ""), calls, "%.3f" % tot, "%.3f" % avg, "%.4f" % pct])
+            w.writerow([kname(name), calls, "%.3f" % tot, "%.3f" % avg, "%.4f" % pct])
     for r in rows[:14]:
-        print("%-24s calls %3d  avg %10.1f us  %5.1f %%" % (r[0].split("(")[0].replace("void ", ""), r[1], r[3], r[4]))
+        print("%-24s calls %3d  avg %10.1f us  %5.1f %%" % (kname(r[0]), r[1], r[3], r[4]))
 
 
 def main():

@@ -14,7 +14,11 @@ Derived (MI355X_MICROARCH.md, rocprofv3 PMC slots: SQ_WAVE_CYCLES / SQ_WAIT_* / 
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import kname  # noqa: E402
 
 
 def main():
@@ -22,7 +26,7 @@ def main():
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in files:
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = kname(row["Kernel_Name"])
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     res = {}
     for k, cs in acc.items():

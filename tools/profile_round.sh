@@ -22,4 +22,19 @@ rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cnn_stats -o run -- $CNN > $OUT/
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_cnn_pmc_sq -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_sq.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_cnn_pmc_fetch -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_cnn_pmc_write -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_write.err
-ls $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_cnn_stats
+# 5. the int16-native path (raw ADC samples in HBM): the same traffic pass, to set beside the float32 one
+I16="python3 bench.py --int16 --steps 2 --warmup 1 --no-secondary --cpu-sample 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_i16_pmc_fetch -o run --output-format csv -- $I16 > /dev/null 2> $OUT/${TAG}_i16_pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_i16_pmc_write -o run --output-format csv -- $I16 > /dev/null 2> $OUT/${TAG}_i16_pmc_write.err
+# 6. summaries (the raw traces stay on the box: only these come back)
+S=$OUT/${TAG}_summary
+mkdir -p $S
+python3 profiles/summarize_phases.py $OUT/${TAG}_stats/run_results.db $S/kernel_stats_by_workload.csv > $S/kernel_stats_by_workload.txt
+python3 profiles/summarize_pmc.py $OUT/${TAG}_pmc_fetch/run_counter_collection.csv $OUT/${TAG}_pmc_write/run_counter_collection.csv 96000 200000 $S/traffic.json > $S/traffic.txt
+python3 profiles/summarize_pmc.py $OUT/${TAG}_i16_pmc_fetch/run_counter_collection.csv $OUT/${TAG}_i16_pmc_write/run_counter_collection.csv 96000 200000 $S/traffic_int16.json > $S/traffic_int16.txt
+python3 profiles/summarize_pmc.py --stats $OUT/${TAG}_cnn_stats/run_results.db $S/cnn200k_kernel_stats.csv > $S/cnn200k_kernel_stats.txt
+python3 profiles/summarize_pmc.py $OUT/${TAG}_cnn_pmc_fetch/run_counter_collection.csv $OUT/${TAG}_cnn_pmc_write/run_counter_collection.csv 4000 200000 $S/cnn200k_traffic.json > $S/cnn200k_traffic.txt
+python3 profiles/summarize_sq.py $OUT/${TAG}_cnn_pmc_sq/run_counter_collection.csv $S/sq_counters_cnn200k.json > $S/sq_counters_cnn200k.txt
+cp $OUT/${TAG}_bench.json $OUT/${TAG}_bench_under_rocprof.json $OUT/${TAG}_cnn_under_rocprof.json $S/
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_cnn_stats $OUT/${TAG}_cnn_pmc_sq $OUT/${TAG}_cnn_pmc_fetch $OUT/${TAG}_cnn_pmc_write $OUT/${TAG}_i16_pmc_fetch $OUT/${TAG}_i16_pmc_write
+ls $S
