@@ -391,7 +391,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
         if (multi) {
             Scope s(h, "k_mvs_series_wave");
             auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
-            const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 2 * (MS_CHUNK + 4)) * 4;
+            const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 4 * (MS_CHUNK + 4)) * 4; // (two out halves per wave)
             static size_t lds_set = 0;
             if (lds > lds_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set = lds; }
             hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,

@@ -485,7 +485,11 @@ __global__ void __launch_bounds__(64) k_mvs_series(SIG sigs, const int32_t *__re
 // longest chain, not by throughput (the same time for 1000 and 4000 reads).  History at the 200 k window, per 4000 reads:
 // one lane per read straight from global memory (k_mvs_series) 38 ms -- the chains waited on scattered loads; one chain per
 // WAVE from LDS 23 ms -- eight waves per SIMD, one lane in 64 working, bound by instruction issue; MS_G chains per wave with
-// the chunk loads waited for one by one 23 ms; with the next chunk's loads in flight during the chains 13 ms.
+// the chunk loads waited for one by one 23 ms; with the next chunk's loads in flight during the chains 12.9 ms; round 2,
+// late: the loads made unconditional (the compiler had put their wait BEFORE the chains, where two paths joined), the stores
+// a chunk late (one counter for loads and stores), the variance steps hand-scheduled (ms_var4), the LDS reads a group
+// ahead, the ring writes unconditional: 10.9 ms.  Ablation (ADP_ABLATE-style switches, since removed): chains 7 ms --
+// 45 instructions per four steps at the 4-cycle issue rate of a single wave --, LDS copies and loop 3, loads + stores 1.4.
 #define MS_CHUNK 64
 #define MS_HIST 320   // longest window served
 #define MS_G 16       // reads per wave (= chains advanced by one vector instruction)
@@ -493,6 +497,76 @@ __global__ void __launch_bounds__(64) k_mvs_series(SIG sigs, const int32_t *__re
 // ring of RB floats per read (RB = a power of two >= window + MS_CHUNK): sample i of the slice lives at ring[i & (RB - 1)];
 // rows are RB + 4 floats apart (4 x odd: the 16-byte accesses of the 16 chain lanes fall into different bank groups)
 static __device__ __forceinline__ int ms_ring(int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; }
+
+// Four sliding steps of bottleneck's move_var (same operations, same order as bn_move_var) as ONE hand-scheduled block.
+// One wave per SIMD runs these chains, and a vector instruction that needs its predecessor's result issues ~8 cycles behind
+// it instead of 4: the compiler's order (step after step, nearly every instruction waiting for the one before, plus packed
+// subtractions that cost more moves than they save: 68 instructions, ~480 cycles per four steps) made the kernel 2.3x slower
+// than the carried dependencies require.  Here the four steps are interleaved so that (nearly) no instruction follows its
+// producer directly; only the two carried chains remain: the mean (one add per step) and the sum of squares (add, compare,
+// select per step -- `if (assqdm < 0) assqdm = 0` keeps a NaN, so no v_max).  The compare writes vcc; gfx950 wants two
+// wait states before a v_cndmask reads it: two other instructions stand between them everywhere but at the end (s_nop 1).
+//   per step: delta = ai - aold; aold -= amean; amean += delta * inv; ai -= amean; assqdm += (ai + aold) * delta;
+//             if (assqdm < 0) assqdm = 0; out = assqdm * inv
+// registers: D_j delta_j, later out_j; E_j delta_j * inv, later the mean after step j; P_j aold_j - mean, later the clamped
+// sum after step j; Q_j ai_j - mean, the product, the unclamped sum.
+static __device__ __forceinline__ void ms_var4(const float (&a)[4], const float (&o)[4], float inv, float &amean, float &assqdm, float (&res)[4])
+{
+    float d0, d1, d2, d3, e0, e1, e2, e3, p0, p1, p2, p3, q0, q1, q2, q3;
+    asm("v_sub_f32_e32 %[d0], %[a0], %[o0]\n\t"
+        "v_sub_f32_e32 %[d1], %[a1], %[o1]\n\t"
+        "v_mul_f32_e32 %[e0], %[d0], %[inv]\n\t"
+        "v_sub_f32_e32 %[d2], %[a2], %[o2]\n\t"
+        "v_sub_f32_e32 %[p0], %[o0], %[m]\n\t"
+        "v_add_f32_e32 %[e0], %[m], %[e0]\n\t"
+        "v_mul_f32_e32 %[e1], %[d1], %[inv]\n\t"
+        "v_sub_f32_e32 %[q0], %[a0], %[e0]\n\t"
+        "v_sub_f32_e32 %[d3], %[a3], %[o3]\n\t"
+        "v_add_f32_e32 %[q0], %[q0], %[p0]\n\t"
+        "v_add_f32_e32 %[e1], %[e0], %[e1]\n\t"
+        "v_mul_f32_e32 %[q0], %[q0], %[d0]\n\t"
+        "v_sub_f32_e32 %[p1], %[o1], %[e0]\n\t"
+        "v_add_f32_e32 %[q0], %[s], %[q0]\n\t"
+        "v_sub_f32_e32 %[q1], %[a1], %[e1]\n\t"
+        "v_cmp_ngt_f32_e32 vcc, 0, %[q0]\n\t"
+        "v_mul_f32_e32 %[e2], %[d2], %[inv]\n\t"
+        "v_add_f32_e32 %[q1], %[q1], %[p1]\n\t"
+        "v_cndmask_b32_e32 %[p0], 0, %[q0], vcc\n\t"
+        "v_mul_f32_e32 %[q1], %[q1], %[d1]\n\t"
+        "v_add_f32_e32 %[e2], %[e1], %[e2]\n\t"
+        "v_add_f32_e32 %[q1], %[p0], %[q1]\n\t"
+        "v_mul_f32_e32 %[e3], %[d3], %[inv]\n\t"
+        "v_cmp_ngt_f32_e32 vcc, 0, %[q1]\n\t"
+        "v_sub_f32_e32 %[q2], %[a2], %[e2]\n\t"
+        "v_sub_f32_e32 %[p2], %[o2], %[e1]\n\t"
+        "v_cndmask_b32_e32 %[p1], 0, %[q1], vcc\n\t"
+        "v_add_f32_e32 %[e3], %[e2], %[e3]\n\t"
+        "v_add_f32_e32 %[q2], %[q2], %[p2]\n\t"
+        "v_mul_f32_e32 %[d0], %[p0], %[inv]\n\t"
+        "v_mul_f32_e32 %[q2], %[q2], %[d2]\n\t"
+        "v_sub_f32_e32 %[q3], %[a3], %[e3]\n\t"
+        "v_add_f32_e32 %[q2], %[p1], %[q2]\n\t"
+        "v_sub_f32_e32 %[p3], %[o3], %[e2]\n\t"
+        "v_cmp_ngt_f32_e32 vcc, 0, %[q2]\n\t"
+        "v_add_f32_e32 %[q3], %[q3], %[p3]\n\t"
+        "v_mul_f32_e32 %[d1], %[p1], %[inv]\n\t"
+        "v_cndmask_b32_e32 %[p2], 0, %[q2], vcc\n\t"
+        "v_mul_f32_e32 %[q3], %[q3], %[d3]\n\t"
+        "v_mul_f32_e32 %[d2], %[p2], %[inv]\n\t"
+        "v_add_f32_e32 %[q3], %[p2], %[q3]\n\t"
+        "v_cmp_ngt_f32_e32 vcc, 0, %[q3]\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_e32 %[p3], 0, %[q3], vcc\n\t"
+        "v_mul_f32_e32 %[d3], %[p3], %[inv]"
+        : [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2), [e3] "=&v"(e3),
+          [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [q0] "=&v"(q0), [q1] "=&v"(q1), [q2] "=&v"(q2), [q3] "=&v"(q3)
+        : [a0] "v"(a[0]), [a1] "v"(a[1]), [a2] "v"(a[2]), [a3] "v"(a[3]), [o0] "v"(o[0]), [o1] "v"(o[1]), [o2] "v"(o[2]), [o3] "v"(o[3]),
+          [inv] "v"(inv), [m] "v"(amean), [s] "v"(assqdm)
+        : "vcc");
+    res[0] = d0; res[1] = d1; res[2] = d2; res[3] = d3;
+    amean = e3;
+    assqdm = p3;
+}
 
 template <bool VAR>
 static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LDS int32_t *a_of, const LDS int32_t *n_of,
@@ -511,7 +585,6 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
     int count = 0;
     const float inv = (float)(1.0 / (double)w);
     LDS float *mybuf = buf + g * S;
-    LDS float *myout = out + g * SO;
     const bool vec = (w & 3) == 0;
     // lengths and slice starts of the wave's reads in registers (wave-uniform values)
     int nq[MS_G];
@@ -522,19 +595,37 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
         xq[q] = (const GLB float *)sigs + (size_t)(r0 + q < n_reads ? r0 + q : r0) * m + a_of[q];
     }
     // the samples of the NEXT chunk are requested before the chains of the current one run (one load per read, all in
-    // flight together; waiting for them one by one cost 8 us per chunk) and land in LDS after it
+    // flight together; waiting for them one by one cost 8 us per chunk) and land in LDS after it.  The loads are
+    // UNCONDITIONAL (index clamped into the slice; what lies behind a slice's end is not copied to LDS): behind a
+    // condition the compiler joins the two paths right after the load -- s_waitcnt vmcnt(0) BEFORE the chains, i.e. a full
+    // memory round trip (2.5 us, 16 streams with a page each) per chunk of 1.6 us of arithmetic
     float pre[MS_G];
     auto fetch = [&](int i0) {
 #pragma unroll
-        for (int q = 0; q < MS_G; q++) { const int i = i0 + ln; pre[q] = (i < nq[q]) ? xq[q][i] : 0.f; }
+        for (int q = 0; q < MS_G; q++) { const int i = i0 + ln, last = nq[q] > 0 ? nq[q] - 1 : 0; pre[q] = xq[q][i < last ? i : last]; }
+    };
+    // out[q][i - i0] is read q's series value at index i - w + 1 (defined from i = w - 1 on): coalesced stores per read,
+    // issued a chunk LATE, from the other half of the out buffer, right behind the next chunk's loads: gfx950 counts loads
+    // and stores in one counter (vmcnt), and the wait for a chunk's samples at the top of the loop would otherwise also wait
+    // for the stores issued just before it -- a memory round trip per chunk
+    auto store_chunk = [&](int i0, const LDS float *o) {
+#pragma unroll
+        for (int q = 0; q < MS_G; q++) {
+            GLB float *sp = (GLB float *)series + (size_t)(r0 + q < n_reads ? r0 + q : r0) * 2 * cap + (VAR ? cap : 0);
+            const int i = i0 + ln;
+            if (i < nq[q] && i >= w - 1) sp[i - w + 1] = o[q * SO + ln];
+        }
     };
     fetch(0);
-    for (int i0 = 0; i0 < nmax; i0 += MS_CHUNK) {
+    int par = 0;
+    for (int i0 = 0; i0 < nmax; i0 += MS_CHUNK, par ^= 1) {
         ws_sync();
 #pragma unroll
-        for (int q = 0; q < MS_G; q++) { const int i = i0 + ln; if (i < nq[q]) buf[q * S + (i & MASK)] = pre[q]; }
+        for (int q = 0; q < MS_G; q++) buf[q * S + ((i0 + ln) & MASK)] = pre[q]; // (behind a slice's end: cells no chain reads)
         ws_sync();
-        if (i0 + MS_CHUNK < nmax) fetch(i0 + MS_CHUNK);
+        fetch(i0 + MS_CHUNK); // (also behind the last chunk: clamped indices, values not used -- no second path to join)
+        if (i0 > 0) store_chunk(i0 - MS_CHUNK, out + (par ^ 1) * MS_G * SO);
+        LDS float *myout = out + par * MS_G * SO + g * SO;
         if (chain && i0 < n) {
             const int hi = min(n, i0 + MS_CHUNK);
             int i = i0;
@@ -561,24 +652,25 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
                     myout[i - i0] = assqdm * inv;
                 } else { asum += ai - aold; myout[i - i0] = asum * inv; }
             }
-            for (; i + 4 <= hi; i += 4) { // four sliding steps on 16-byte LDS accesses
-                const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
-                const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - w) & MASK]);
-                const float an[4] = {a4.x, a4.y, a4.z, a4.w}, ao[4] = {o4.x, o4.y, o4.z, o4.w};
-                float res[4];
+            // four sliding steps on 16-byte LDS accesses; the NEXT group's samples are requested before this group's
+            // arithmetic (ms_var4 wants all eight values at its first instructions: an LDS round trip per group otherwise)
+            if (i + 4 <= hi) {
+                adp_v4f a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
+                adp_v4f o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - w) & MASK]);
+                for (; i + 4 <= hi; i += 4) {
+                    const float an[4] = {a4n.x, a4n.y, a4n.z, a4n.w}, ao[4] = {o4n.x, o4n.y, o4n.z, o4n.w};
+                    const int inx = (i + 8 <= hi) ? i + 4 : i; // (the last group reads its own samples again: no second path)
+                    a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[inx & MASK]);
+                    o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(inx - w) & MASK]);
+                    float res[4];
+                    if (VAR) ms_var4(an, ao, inv, amean, assqdm, res);
+                    else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (VAR) {
-                        float ai = an[j], aold = ao[j];
-                        const float delta = ai - aold;
-                        aold -= amean; amean += delta * inv; ai -= amean;
-                        assqdm += (ai + aold) * delta;
-                        if (assqdm < 0) assqdm = 0;
-                        res[j] = assqdm * inv;
-                    } else { asum += an[j] - ao[j]; res[j] = asum * inv; }
+                        for (int j = 0; j < 4; j++) { asum += an[j] - ao[j]; res[j] = asum * inv; }
+                    }
+                    const adp_v4f r4 = {res[0], res[1], res[2], res[3]};
+                    *reinterpret_cast<LDS adp_v4f *>(&myout[i - i0]) = r4;
                 }
-                const adp_v4f r4 = {res[0], res[1], res[2], res[3]};
-                *reinterpret_cast<LDS adp_v4f *>(&myout[i - i0]) = r4;
             }
             for (; i < hi; i++) {
                 float ai = mybuf[i & MASK], aold = mybuf[(i - w) & MASK];
@@ -591,15 +683,9 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
                 } else { asum += ai - aold; myout[i - i0] = asum * inv; }
             }
         }
-        ws_sync();
-        // out[q][i - i0] is read q's series value at index i - w + 1 (defined from i = w - 1 on): coalesced per read
-#pragma unroll
-        for (int q = 0; q < MS_G; q++) {
-            GLB float *sp = (GLB float *)series + (size_t)(r0 + q < n_reads ? r0 + q : r0) * 2 * cap + (VAR ? cap : 0);
-            const int i = i0 + ln;
-            if (i < nq[q] && i >= w - 1) sp[i - w + 1] = out[q * SO + ln];
-        }
     }
+    ws_sync();
+    if (nmax > 0) store_chunk((nmax - 1) / MS_CHUNK * MS_CHUNK, out + (par ^ 1) * MS_G * SO);
 }
 
 // grid = ceil(n_reads / MS_G); block = 128 (wave 0: MS_G moving variances, wave 1: MS_G moving means); dynamic LDS
@@ -637,7 +723,7 @@ __global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict
     __syncthreads();
     const int Sv = ms_ring(cfg.pA_var_window) + 4, Sm = ms_ring(cfg.pA_mean_window) + 4;
     LDS float *base = (LDS float *)ms_raw;
-    LDS float *buf_v = base, *out_v = buf_v + MS_G * Sv, *buf_m = out_v + MS_G * (MS_CHUNK + 4), *out_m = buf_m + MS_G * Sm;
+    LDS float *buf_v = base, *out_v = buf_v + MS_G * Sv, *buf_m = out_v + 2 * MS_G * (MS_CHUNK + 4), *out_m = buf_m + MS_G * Sm; // (out: two halves)
     if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_var_window, series, cap, buf_v, out_v);
     else ms_chains<false>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_mean_window, series, cap, buf_m, out_m);
 }
