@@ -308,7 +308,16 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     __syncthreads();
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
-        for (int i = tid; i < tail; i += BS_THREADS) bs_side<SIDE>(x[s + i], param, bs, aux, aux2);
+        { // the side effects of the ragged part: eight loads in flight per thread (one by one, each waited for its own round trip)
+            const X xs = x + s;
+            for (int base = 0; base < tail; base += BS_THREADS * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; v[u] = ld_if(xs, i, i < tail); }
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (base + u * BS_THREADS + tid < tail) bs_side<SIDE>(v[u], param, bs, aux, aux2);
+            }
+        }
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
         bs_tail_leaves(tail, bs);
         const int nleaf = bs->nleaf;
@@ -317,14 +326,25 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
             // stage 32 leaves: wave w loads leaves g0 + 8w .. g0 + 8w + 7 (coalesced, 2 loads per leaf)
             __syncthreads();
             const int w = tid >> 6, ln = tid & 63;
+            // (all sixteen loads of the wave's eight leaves first -- clamped indices, no conditions --, then the LDS writes:
+            // load, wait, write per leaf cost sixteen memory round trips per group of 32 leaves)
+            float va[8], vb[8];
+            int lens[8];
+#pragma unroll
             for (int q = 0; q < 8; q++) {
-                int l = g0 + w * 8 + q;
-                if (l < nleaf) {
-                    int off = bs->leaf_off[l], len = bs->leaf_len[l];
-                    LDS float *dst = bs->u.stage + (w * 8 + q) * BS_LEAF_STRIDE;
-                    if (ln < len) dst[ln] = bs_x2(xt[off + ln], mode, c);
-                    if (ln + 64 < len) dst[ln + 64] = bs_x2(xt[off + ln + 64], mode, c);
-                }
+                const int l = g0 + w * 8 + q;
+                const bool have = l < nleaf;
+                const int off = have ? bs->leaf_off[l] : 0, len = have ? bs->leaf_len[l] : 0;
+                const int last = len > 0 ? len - 1 : 0;
+                lens[q] = len;
+                va[q] = xt[off + (ln < last ? ln : last)];
+                vb[q] = xt[off + (ln + 64 < last ? ln + 64 : last)];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                LDS float *dst = bs->u.stage + (w * 8 + q) * BS_LEAF_STRIDE;
+                if (ln < lens[q]) dst[ln] = bs_x2(va[q], mode, c);
+                if (ln + 64 < lens[q]) dst[ln + 64] = bs_x2(vb[q], mode, c);
             }
             __syncthreads();
             // thread (leaf = tid >> 3, j = tid & 7): accumulator chain j of numpy's 8-accumulator leaf
