@@ -462,90 +462,123 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
             //    56 maxima per step (lanes 4..59), their neighbours by shuffle.  A maximum without any is kept
             //    at once; the others form the work list of step 3.
             int nund = 0;
-            for (int base = 0; base < npk; base += 56) {
-                const int k = base - 4 + ln;
-                const bool valid = k >= 0 && k < npk;
-                const int p = valid ? pk[k] : (k < 0 ? -0x40000000 : 0x40000000);
-                const double v = valid ? tv_get(tv, p) : 0.0;
-                // forward neighbours k+j by shuffle; the backward relation of k to k-j is the forward one seen from
-                // k-j with the comparison reversed (the sanitised values hold no NaN), so it travels as one bit
-                uint32_t mask = 0, lower = 0; // lower bit j-1: k+j lies within 9 samples and is LOWER than k
+            // (four steps' positions, then their four trace values, are requested together: a step is two dependent round
+            // trips to memory -- the list entry, then the trace value it points at -- and a read has up to 180 steps)
+            for (int base4 = 0; base4 < npk; base4 += 56 * 4) {
+                int pp[4];
+                double vv[4];
 #pragma unroll
-                for (int j = 1; j <= 4; j++) {
-                    const int pf = __shfl_down(p, j); const double vf = __shfl_down(v, j);
-                    const bool within = pf - p <= 9;
-                    if (within && vf >= v) mask |= 1u << (j - 1);
-                    if (within && !(vf >= v)) lower |= 1u << (j - 1);
+                for (int u = 0; u < 4; u++) {
+                    const int k = base4 + 56 * u - 4 + ln;
+                    const bool valid = k >= 0 && k < npk;
+                    pp[u] = valid ? pk[k] : (k < 0 ? -0x40000000 : 0x40000000);
                 }
 #pragma unroll
-                for (int j = 1; j <= 4; j++) {
-                    const uint32_t lb = (uint32_t)__shfl_up((int)lower, j);
-                    if (lb >> (j - 1) & 1u) mask |= 1u << (4 + j - 1); // k-j is within 9 and k is lower than it
+                for (int u = 0; u < 4; u++) {
+                    const int k = base4 + 56 * u - 4 + ln;
+                    const bool valid = k >= 0 && k < npk;
+                    vv[u] = valid ? tv_get(tv, pp[u]) : 0.0;
                 }
-                const bool out = valid && ln >= 4 && ln < 60;
-                if (out) {
-                    const uint32_t sl = (uint32_t)(k + 4);
-                    __hip_atomic_fetch_or(&stw[sl >> 4], (mask ? PST_UNDECIDED : PST_KEPT) << ((sl & 15u) * 2u), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int base = base4 + 56 * u;
+                    if (base >= npk) break;
+                    const int k = base - 4 + ln;
+                    const bool valid = k >= 0 && k < npk;
+                    const int p = pp[u];
+                    const double v = vv[u];
+                    // forward neighbours k+j by shuffle; the backward relation of k to k-j is the forward one seen from
+                    // k-j with the comparison reversed (the sanitised values hold no NaN), so it travels as one bit
+                    uint32_t mask = 0, lower = 0; // lower bit j-1: k+j lies within 9 samples and is LOWER than k
+#pragma unroll
+                    for (int j = 1; j <= 4; j++) {
+                        const int pf = __shfl_down(p, j); const double vf = __shfl_down(v, j);
+                        const bool within = pf - p <= 9;
+                        if (within && vf >= v) mask |= 1u << (j - 1);
+                        if (within && !(vf >= v)) lower |= 1u << (j - 1);
+                    }
+#pragma unroll
+                    for (int j = 1; j <= 4; j++) {
+                        const uint32_t lb = (uint32_t)__shfl_up((int)lower, j);
+                        if (lb >> (j - 1) & 1u) mask |= 1u << (4 + j - 1); // k-j is within 9 and k is lower than it
+                    }
+                    const bool out = valid && ln >= 4 && ln < 60;
+                    if (out) {
+                        const uint32_t sl = (uint32_t)(k + 4);
+                        __hip_atomic_fetch_or(&stw[sl >> 4], (mask ? PST_UNDECIDED : PST_KEPT) << ((sl & 15u) * 2u), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    const bool und = out && mask;
+                    const unsigned long long m = __ballot(und);
+                    if (und) mk[nund + __popcll(m & ((1ull << ln) - 1ull))] = ((uint32_t)k << 8) | mask;
+                    nund += __popcll(m);
                 }
-                const bool und = out && mask;
-                const unsigned long long m = __ballot(und);
-                if (und) mk[nund + __popcll(m & ((1ull << ln) - 1ull))] = ((uint32_t)k << 8) | mask;
-                nund += __popcll(m);
             }
             __syncthreads();
             // 3. fixed point of "kept iff no kept higher-priority neighbour"
             if (g_ablate & 512) nund = 0;
             while (nund > 0) {
                 int w = 0;
-                for (int base = 0; base < nund; base += 64) {
-                    const int idx = base + ln;
-                    uint32_t e = 0;
-                    bool pending = false;
-                    if (idx < nund) {
-                        e = mk[idx];
-                        const uint32_t k = e >> 8;
-                        // states of the ordinals k-4 .. k+4 = slots k .. k+8
-                        const unsigned long long W =
-                            (((unsigned long long)stw[(k >> 4) + 1] << 32) | stw[k >> 4]) >> ((k & 15u) * 2u);
-                        bool kept_nb = false;
-                        uint32_t b = e & 255u;
-                        while (b) {
-                            const int o = __ffs(b) - 1; b &= b - 1;
-                            const int f = o < 4 ? 5 + o : 7 - o; // k+1..k+4 -> fields 5..8 ; k-1..k-4 -> fields 3..0
-                            const uint32_t sn = (uint32_t)(W >> (2 * f)) & 3u;
-                            if (sn == PST_KEPT) kept_nb = true;
-                            else if (sn == PST_UNDECIDED) pending = true;
+                for (int base4 = 0; base4 < nund; base4 += 256) { // (four list loads in flight; the rewritten list stays
+                    uint32_t ee[4];                                 //  below what has been read)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int idx = base4 + 64 * u + ln; ee[u] = (idx < nund) ? mk[idx] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int base = base4 + 64 * u;
+                        if (base >= nund) break;
+                        const int idx = base + ln;
+                        const uint32_t e = ee[u];
+                        bool pending = false;
+                        if (idx < nund) {
+                            const uint32_t k = e >> 8;
+                            // states of the ordinals k-4 .. k+4 = slots k .. k+8
+                            const unsigned long long W =
+                                (((unsigned long long)stw[(k >> 4) + 1] << 32) | stw[k >> 4]) >> ((k & 15u) * 2u);
+                            bool kept_nb = false;
+                            uint32_t b = e & 255u;
+                            while (b) {
+                                const int o = __ffs(b) - 1; b &= b - 1;
+                                const int f = o < 4 ? 5 + o : 7 - o; // k+1..k+4 -> fields 5..8 ; k-1..k-4 -> fields 3..0
+                                const uint32_t sn = (uint32_t)(W >> (2 * f)) & 3u;
+                                if (sn == PST_KEPT) kept_nb = true;
+                                else if (sn == PST_UNDECIDED) pending = true;
+                            }
+                            const uint32_t sl = k + 4u;
+                            if (kept_nb) {
+                                __hip_atomic_fetch_and(&stw[sl >> 4], ~(2u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                pending = false;
+                            } else if (!pending) {
+                                __hip_atomic_fetch_and(&stw[sl >> 4], ~(1u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
                         }
-                        const uint32_t sl = k + 4u;
-                        if (kept_nb) {
-                            __hip_atomic_fetch_and(&stw[sl >> 4], ~(2u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            pending = false;
-                        } else if (!pending) {
-                            __hip_atomic_fetch_and(&stw[sl >> 4], ~(1u << ((sl & 15u) * 2u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                        const unsigned long long m = __ballot(pending);
+                        if (pending) mk[w + __popcll(m & ((1ull << ln) - 1ull))] = e;
+                        w += __popcll(m);
+                        __syncthreads();
                     }
-                    const unsigned long long m = __ballot(pending);
-                    if (pending) mk[w + __popcll(m & ((1ull << ln) - 1ull))] = e;
-                    w += __popcll(m);
-                    __syncthreads();
                 }
                 nund = w;
             }
             __syncthreads();
             // kept maxima, in index order, compacted in place
             int nkept = 0;
-            for (int base = 0; base < npk; base += 64) {
-                const int k = base + ln;
-                int pp = -1; bool kp = false;
-                if (k < npk) {
-                    pp = pk[k];
-                    const uint32_t sl = (uint32_t)(k + 4);
-                    kp = ((stw[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == PST_KEPT;
+            for (int base4 = 0; base4 < npk; base4 += 256) { // (four loads in flight; the stores land at or below what was read)
+                int pq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int k = base4 + 64 * u + ln; pq[u] = (k < npk) ? pk[k] : -1; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = base4 + 64 * u + ln;
+                    bool kp = false;
+                    if (k < npk) {
+                        const uint32_t sl = (uint32_t)(k + 4);
+                        kp = ((stw[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == PST_KEPT;
+                    }
+                    const unsigned long long m = __ballot(kp);
+                    if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = pq[u];
+                    nkept += __popcll(m);
                 }
-                const unsigned long long m = __ballot(kp);
-                if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = pp;
-                nkept += __popcll(m);
             }
             __syncthreads();
             // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
