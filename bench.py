@@ -537,7 +537,7 @@ def main():
     ap.add_argument("--primary", choices=["llr", "cnn"], default="llr",
                     help="llr: BASELINE configs[1] (default, the headline); cnn: configs[2] (hand-written conv head)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary workloads (configs[2] at the 200 k and the default window, configs[4]'s Pareto lengths) that a "
+                    help="skip the secondary workloads (configs[2] at the 200 k and the default window, configs[4]'s Pareto lengths, int16 input, two streams) that a "
                          "default 1-GPU run attaches to its JSON line")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
@@ -596,10 +596,15 @@ def main():
     if rank == 0 and world == 1 and default_run and not args.no_secondary:
         # the other single-GPU configurations of BASELINE.json, driver-run with the headline (each its own roofline)
         sec = {}
-        for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=4000, steps=4, warmup=1)),
+        # (cnn_200k at 8000 reads per step: the moving-window series of the candidate validation is a sequential float32
+        # recurrence per read, ~11 ms per call whatever the number of reads; two_streams: the headline with two engines per
+        # GPU, each on its own HIP stream with half of the minibatches -- the ALU-bound gains of one overlap the streaming
+        # passes of the other; the headline itself stays on one stream so that a launch has the GPU to itself for the roofline)
+        for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=8000, steps=3, warmup=1)),
                          ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
                          ("pareto", dict(lens="pareto", steps=4, warmup=1)),
-                         ("int16", dict(int16=True, steps=4, warmup=1))):
+                         ("int16", dict(int16=True, steps=4, warmup=1)),
+                         ("two_streams", dict(streams=2, steps=4, warmup=1))):
             w = argparse.Namespace(**vars(args))
             w.cpu_sample = 0
             for k, v in kw.items():
