@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict
             if (ok && (p_e - a_e <= cfg.pA_var_window + 2 || p_e - a_e <= cfg.pA_mean_window + 2)) ok = false;
             if (ok && (cfg.pA_var_window > n || cfg.pA_var_window < 1 || cfg.pA_mean_window > n || cfg.pA_mean_window < 1)) ok = false;
             if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
-            if (!ok) n = 0;
+            if (!ok) { n = 0; a = 0; } // (a = 0: the unconditional prefetch of an unused read stays inside its row)
             have[r] = ok ? 1 : 0;
         }
         a_of[ln] = a; n_of[ln] = n;

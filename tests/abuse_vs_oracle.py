@@ -58,8 +58,50 @@ def main():
             print("%-40s status %s pass %d/%d differing fields: %d" % (name, list(mbs), sum(g.success for g in got), n, bad), flush=True)
             total += bad
         eng.close()
+    total += abuse_cnn()
     print("TOTAL differing:", total)
     return 1 if total else 0
+
+
+def abuse_cnn():
+    """the same hostile values through the CNN path at a 60 k window (the wave-per-16-reads series kernel with its
+    hand-scheduled variance steps, the shared-sweep candidate statistics): conv stack + predict on the device, the rows
+    against the oracle's validation of the same predictions"""
+    from adapted_amd.detect import cnn
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.core.max_obs_trace = 60000
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m, n = spc.sig_preload_size, 64
+    base, lens = synth.synth_batch(78, 0, n, m, np.full(n, m, dtype=np.int32))
+    f = np.float32
+    cases = {}
+    a = base.copy(); a[3, 15000] = np.inf; a[9, 30000] = -np.inf; a[12, 7000] = np.inf; a[12, 7400] = -np.inf; cases["cnn: infinities"] = a
+    a = base.copy(); a[5, 20000:20100] = f(3e30); a[6, 9000:9050] = f(-2e30); cases["cnn: huge values"] = a
+    a = base.copy() * f(1e-30); cases["cnn: tiny magnitudes"] = a
+    a = -base.copy(); cases["cnn: negative signal"] = a
+    a = base.copy(); a[7, 8000:39000] = f(95.0); a[8, :] = f(100.0); cases["cnn: constant stretches and a constant read"] = a
+    a = base.copy(); a[10, 16000:16100] = np.nan; a[11, 5000:5050] = np.nan; cases["cnn: NaN holes inside reads"] = a
+    a = np.round(base.copy()); cases["cnn: integers"] = a.astype(np.float32)
+    total = 0
+    for name, sig in cases.items():
+        eng = lib.Engine(spc, n, m, device=0)
+        cnn.ensure_weights(eng, None, spc)
+        _, bounds = eng.detect_cnn_rows(sig, lens, n, n)
+        got = lib.rows_to_results(cnn.detect_rows(eng, sig, lens, None, spc), "cnn")
+        want = oracle.detect_cnn_from_preds(sig, lens, bounds, spc)
+        bad = 0
+        for i, (g, w) in enumerate(zip(got, want)):
+            d = row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")})
+            if d:
+                print("   read %d: %s" % (i, d[:8]), flush=True)
+            bad += len(d)
+        print("%-46s pass %d/%d all-candidates %d differing fields: %d" % (name, sum(g.success for g in got), n,
+              int((bounds[:, 1:] != 0).all(axis=1).sum()), bad), flush=True)
+        total += bad
+        eng.close()
+    return total
 
 
 if __name__ == "__main__":
