@@ -367,6 +367,17 @@ static void sync_ablate(hipStream_t st)
     }
 }
 
+template <int THREADS, int L0, int LN>
+static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
+{
+    typedef CsSharedT<L0, LN> Sh;
+    static bool attr_set = false; // (per instantiation)
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats<THREADS, L0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); attr_set = true; }
+    hipLaunchKernelGGL((k_cand_stats<THREADS, L0, LN>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                       (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
+    return 0;
+}
+
 template <class SIG>
 static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
                            bool gate_mb)
@@ -378,9 +389,8 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     in.scratch = h->vscratch.as<float>(); in.scratch_stride = h->vstride;
     // several candidates per read (the CNN path): moving-window series up to the LARGEST candidate for every read (the
     // window, not MVS_CAP, bounds them), then the order statistics of all candidates in shared sweeps (cand_stats.h)
-    // (below ~32 k samples of preload the slices are short enough for k_validate's own wave-per-read statistics, which then
-    // cost less than the workgroup-per-read sweeps: 14 vs 51 ms per 32 000 reads at the default window)
-    const bool multi = std::is_same<SIG, SigF32>::value && kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite && h->m > 32768 &&
+    // (two shapes of k_cand_stats: big workgroups and wide levels beyond a 32 k preload, small ones below: cand_stats.h)
+    const bool multi = std::is_same<SIG, SigF32>::value && kmax > 1 && h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite &&
                        h->cfg.pA_var_window <= MS_HIST && h->cfg.pA_mean_window <= MS_HIST;
     const int cap = multi ? h->vstride : MVS_CAP;
     if (multi && (h->series.ensure((size_t)n * 2 * cap * 4) || h->cstat.ensure((size_t)n * kmax * sizeof(CandStat)))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
@@ -405,11 +415,10 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
         }
         if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
-            static bool attr_set = false;
-            if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CsShared))); attr_set = true; }
             Scope s(h, "k_cand_stats");
-            hipLaunchKernelGGL(k_cand_stats, dim3(n), dim3(CS_THREADS), sizeof(CsShared), h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
-                               (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
+            int rc = h->m > 32768 ? launch_cand_stats<1024, 12, 8>(h, dsig.base, dlen, n, m, kmax, cap)
+                                  : launch_cand_stats<256, 8, 6>(h, dsig.base, dlen, n, m, kmax, cap);
+            if (rc) return rc;
         }
         }
     } else {

@@ -14,27 +14,33 @@
 //     an element is routed through small LDS tables to the histogram of the queries whose resolved bits it shares;
 //   * x_(k-1) (even-count medians, percentile interpolation) is simply another query.
 //
-// A 1024-thread workgroup per read; four sweeps over each of the three arrays (min / max, then 12 + 8 + 8 bits; a fifth for
-// spans beyond 28 bits) whatever the number of candidates.  Selection is exact; the float32 / float64 arithmetic on the
+// A workgroup per read; four sweeps over each of the three arrays (min / max, then 12 + 8 + 8 bits; a fifth for spans beyond
+// 28 bits; the small shape: 8 + 6 + 6 + 6 + 6) whatever the number of candidates.  Selection is exact; the float32 / float64 arithmetic on the
 // selected values is that of wave_median / wave_percentile (wave_stats.h).
 #pragma once
 #include "common.h"
 
-#define CS_THREADS 1024
+// Two shapes of the same kernel (template parameters THREADS, L0, LN = bits of the key span resolved by the first / by a later
+// level): 1024 threads with 12 + 8 bits for the long slices of wide windows, where the sweeps over the arrays are the cost
+// and levels must be few; 256 threads with 8 + 6 bits for the short slices of the default window, where the work per
+// level that grows with the bins (clearing, slot maps, rank scans) and the barriers of a big workgroup are the cost
+// (per 32 000 reads at the 16 k window: 1024 / 12 / 8 54 ms, 256 / 12 / 8 62, 256 / 8 / 6 9.1 with the fifth level wide
+// key spans need; k_validate's own wave-per-read statistics: 12.3).
 #define CS_MAXQ 64
 #define CS_GROUP 10 // candidates per round (6 queries each on the slice itself)
-#define CS_L0_BITS 12
-#define CS_LN_BITS 8
 #define CS_UNROLL 8 // elements a thread requests before it looks at the first (memory-level parallelism of the sweeps)
 
 struct CandStat { float fvar, fmean, fmed; int32_t ready; double q85, q15; };
 
 struct CsQuery { int len, k, slot, krem, bin, before; uint32_t prefix; float val; };
 
-struct CsShared {
-    uint32_t hist[CS_MAXQ << CS_LN_BITS];
-    uint8_t map0[1 << CS_L0_BITS];
-    uint8_t mapn[2][CS_MAXQ << CS_LN_BITS];
+template <int L0, int LN>
+struct CsSharedT {
+    static_assert((1 << L0) <= (CS_MAXQ << LN), "the first level uses the histogram words of all slots");
+    uint32_t hist[CS_MAXQ << LN];
+    static constexpr int NLEV = 1 + (32 - L0 + LN - 1) / LN; // levels that resolve any 32-bit key span (4 for 12 + 8, 5 for 8 + 6)
+    uint8_t map0[1 << L0];
+    uint8_t mapn[NLEV - 2][CS_MAXQ << LN]; // slot routing behind the levels 1 .. NLEV - 2
     CsQuery q[CS_MAXQ];
     int seglen[CS_MAXQ];
     int nseg, nq, nslots;
@@ -47,8 +53,10 @@ struct CsShared {
 
 // x_(k) of x[0 .. len) for every query sh->q[0 .. nq) (0 <= k < len <= n_max); NaN when the prefix holds one.
 // All threads of the block call it; results in sh->q[i].val.
-static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsShared *sh)
+template <int THREADS, int L0, int LN>
+static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsSharedT<L0, LN> *sh)
 {
+    constexpr int CS_THREADS = THREADS, CS_L0_BITS = L0, CS_LN_BITS = LN;
     const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
     const int nq = sh->nq;
@@ -96,12 +104,17 @@ static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsShare
     const int nan_first = sh->nan_first;
     for (int i = tid; i < nq; i += CS_THREADS) { sh->q[i].slot = 0; sh->q[i].krem = sh->q[i].k; sh->q[i].prefix = 0; }
     int rb = span ? 32 - __clz(span) : 0;
-    int s0 = 0, s1 = 0, s2 = 0, w1 = 0, w2 = 0; // shifts / widths of the levels already resolved (the routing below)
+    constexpr int NLEV = CsSharedT<L0, LN>::NLEV;
+    int sft[NLEV], wid[NLEV]; // shifts / widths of the levels already resolved (the routing below)
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) sft[l] = wid[l] = 0;
     int nslots = 1;
-    for (int level = 0; rb > 0 && level < 4; level++) {
+#pragma unroll
+    for (int level = 0; level < NLEV; level++) {
+        if (rb <= 0) break;
         const int w = level == 0 ? (rb < CS_L0_BITS ? rb : CS_L0_BITS) : (rb < CS_LN_BITS ? rb : CS_LN_BITS);
         const int shift = rb - w;
-        if (level == 0) s0 = shift; else if (level == 1) { s1 = shift; w1 = w; } else if (level == 2) { s2 = shift; w2 = w; }
+        sft[level] = shift; wid[level] = w;
         for (int i = tid; i < (nslots << w); i += CS_THREADS) sh->hist[i] = 0;
         __syncthreads();
         int lo = 0;
@@ -117,9 +130,16 @@ static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsShare
                     if (v != v) continue;
                     const uint32_t d = f2key(v) - mn;
                     uint32_t slot = 0;
-                    if (level >= 1) { slot = sh->map0[d >> s0]; if (slot == 0xffu) continue; }
-                    if (level >= 2) { slot = sh->mapn[0][(slot << w1) | ((d >> s1) & ((1u << w1) - 1u))]; if (slot == 0xffu) continue; }
-                    if (level >= 3) { slot = sh->mapn[1][(slot << w2) | ((d >> s2) & ((1u << w2) - 1u))]; if (slot == 0xffu) continue; }
+                    if (level >= 1) { slot = sh->map0[d >> sft[0]]; if (slot == 0xffu) continue; }
+                    bool dead = false;
+#pragma unroll
+                    for (int l = 1; l < NLEV - 1; l++) {
+                        if (l < level && !dead) {
+                            slot = sh->mapn[l - 1][(slot << wid[l]) | ((d >> sft[l]) & ((1u << wid[l]) - 1u))];
+                            dead = slot == 0xffu;
+                        }
+                    }
+                    if (dead) continue;
                     __hip_atomic_fetch_add(&sh->hist[(slot << w) | ((d >> shift) & ((1u << w) - 1u))], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -196,15 +216,17 @@ static __device__ __forceinline__ double cs_pct_value(float vk, float vkm1, int 
     return r;
 }
 
-// grid = n reads; block = CS_THREADS; dynamic LDS = sizeof(CsShared).  series: [n, 2, cap] moving mean, moving variance of
+// grid = n reads; block = THREADS; dynamic LDS = sizeof(CsSharedT<L0, LN>).  series: [n, 2, cap] moving mean, moving variance of
 // signal[adapter_end : largest candidate) (k_mvs_series); out: [n, kmax], ready = 1 where the five statistics are filled in
 // (k_validate computes the others itself: slices shorter than a window, reads whose series were not prepared).
-__global__ void __launch_bounds__(CS_THREADS) k_cand_stats(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads, int m,
+template <int THREADS, int L0, int LN>
+__global__ void __launch_bounds__(THREADS) k_cand_stats(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads, int m,
                                                            const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
                                                            const float *__restrict__ series, int cap, const int8_t *__restrict__ have,
                                                            CandStat *__restrict__ out)
 {
     extern __shared__ unsigned char cs_raw[];
+    typedef CsSharedT<L0, LN> CsShared;
     LDS CsShared *sh = (LDS CsShared *)cs_raw;
     const int r = blockIdx.x, tid = threadIdx.x;
     CandStat *o = out + (size_t)r * kmax;
@@ -248,7 +270,7 @@ __global__ void __launch_bounds__(CS_THREADS) k_cand_stats(const float *__restri
             sh->nq = nq;
         }
         __syncthreads();
-        cs_multi_select(x, sh);
+        cs_multi_select<THREADS, L0, LN>(x, sh);
         if (tid < nc * 6) { const int c = tid / 6, t = tid % 6; const int qi = sh->c_qx[c][t]; sh->c_x[c][t] = (sh->c_n[c] > 0 && qi >= 0) ? sh->q[qi].val : 0.f; }
         __syncthreads();
         for (int which = 0; which < 2; which++) { // the moving variance, then the moving mean: median of the prefix n - w + 1
@@ -267,7 +289,7 @@ __global__ void __launch_bounds__(CS_THREADS) k_cand_stats(const float *__restri
                 sh->nq = nq;
             }
             __syncthreads();
-            cs_multi_select(which == 0 ? svar : smean, sh);
+            cs_multi_select<THREADS, L0, LN>(which == 0 ? svar : smean, sh);
             if (tid < nc * 2) {
                 const int c = tid / 2, t = tid % 2;
                 const int qi = which == 0 ? sh->c_qv[c][t] : sh->c_qm[c][t];
