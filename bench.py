@@ -355,6 +355,8 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             # and waited for before the next one starts (and before the clock stops)
             if state["pending"] is not None:
                 state["pending"].wait()
+                if backend == "nccl":  # (an RCCL wait orders torch's stream, not the host: the buffer that gather read is
+                    torch.cuda.current_stream().synchronize()  # written again by the library's own stream one step from now)
             cur = state["rows"]
             state["pending"] = dist.gather(cur if backend == "nccl" else cur.cpu(), gathered, dst=0, async_op=True)
             state["i"] += 1
