@@ -123,6 +123,43 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+def hip_runtimes() -> List[str]:
+    """paths of every HIP runtime (libamdhip64) mapped into this process -- one entry is the healthy state"""
+    seen = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for ln in fh:
+                path = ln.split(None, 5)[-1].strip() if ln.count("/") else ""
+                if "libamdhip64" in os.path.basename(path) and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _share_torch_runtime():
+    """One process, ONE HIP runtime, whatever the import order.  PyTorch-ROCm wheels bundle a libamdhip64.so whose SONAME
+    (libamdhip64.so.7) is also what libadapted_hip.so asks for: loaded after torch, this library binds to torch's copy by
+    itself; loaded BEFORE torch it would bind to /opt/rocm's and a later `import torch` would map a second runtime beside it
+    (two runtimes = two device contexts: RCCL, events and allocations of one are invisible to the other).  So when no
+    runtime is mapped yet and a torch wheel with a bundled runtime is installed, map that copy first (by path, without
+    importing torch); the dynamic loader then resolves both this library and a later torch to it.
+    ADAPTED_HIP_RUNTIME=system keeps /opt/rocm's runtime (fine for processes that never import torch)."""
+    if os.environ.get("ADAPTED_HIP_RUNTIME", "auto") == "system" or hip_runtimes():
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- no torch, or an unusual install: the system runtime it is
+        pass
+
+
 def load():
     """Load (building if needed) libadapted_hip.so.  Raises HipLibraryError if impossible."""
     global _LIB
@@ -130,14 +167,14 @@ def load():
         return _LIB
     try:
         path = os.environ.get("ADAPTED_HIP_LIB") or _build.build()  # (override: a developer's experimental build)
-        # PyTorch-ROCm wheels carry their own HIP runtime; when both runtimes end up in one process, torch's has to claim
-        # the GPU first or it finds none afterwards.  If torch is already imported, let it do so now.
-        _torch = sys.modules.get("torch")
-        if _torch is not None and getattr(_torch, "cuda", None) is not None and _torch.cuda.is_available():
-            _torch.cuda.init()
+        _share_torch_runtime()
         lib = C.CDLL(path)
     except Exception as e:  # no CPU fallback by design
         raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
+    if len(hip_runtimes()) > 1:
+        raise HipLibraryError("two HIP runtimes are mapped into this process (%s): import torch before loading another "
+                              "library that links /opt/rocm's libamdhip64, or set ADAPTED_HIP_RUNTIME consistently"
+                              % ", ".join(hip_runtimes()))
     if lib.adp_sizeof_cfg() != C.sizeof(AdpCfg) or lib.adp_sizeof_row() != ROW_DTYPE.itemsize:
         raise HipLibraryError("ABI mismatch between adapted_amd/lib.py and libadapted_hip.so")
     lib.adp_last_error.restype = C.c_char_p

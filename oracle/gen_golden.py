@@ -4,6 +4,7 @@ vectors can be regenerated, never shipped to or run on the GPU box.
 
     /opt/conda/bin/python3.9 oracle/gen_golden.py llr        # LLR + start-peak cases, primitives
     /usr/local/bin/python3   oracle/gen_golden.py cnn        # CNN cases (needs torch)
+    /usr/local/bin/python3   oracle/gen_golden.py cnn rna004_cnn_200k   # just the named case(s)
 
 Inputs are regenerated from seeds by adapted_amd/synth.py (host twin of the device
 generator), so only the reference's OUTPUTS are stored.
@@ -296,14 +297,17 @@ def main():
                 gen_csv(results, lens, name)
         gen_start_peak_table()
     elif what == "cnn":
-        export_weights()
+        if not only:
+            export_weights()
         for name, case in CASES.items():
-            if case["primary"] != "cnn":
+            if case["primary"] != "cnn" or (only and name not in only):
                 continue
             results, spc, sig, lens = run_case(name, case)
             print(name, "ok", sum(r.success for r in results), "/", len(results))
             gen_csv(results, lens, name)
     import numpy, scipy
+    if only:
+        return
     with open(os.path.join(GOLD, "PROVENANCE_%s.txt" % what), "w") as fh:
         fh.write("generated by oracle/gen_golden.py %s\npython %s\nnumpy %s scipy %s\nreference ADAPTed v0.2.4 at /root/reference\n"
                  % (what, sys.version.split()[0], numpy.__version__, scipy.__version__))

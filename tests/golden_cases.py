@@ -60,6 +60,10 @@ CASES = {
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
+    # configs[2] at the north-star window (T = 200000, m = 201500, Lc = 20050): the CNN head pinned where the bench runs it;
+    # lengths include reads short enough (< 2 * max_obs_adapter) to enter the LLR fallback (combined.py:251-301)
+    "rna004_cnn_200k": dict(chem="RNA004", primary="cnn", max_obs_trace=200000, seed=27,
+                            first=2000, n=12, lens="mixed200cnn", minibatch=12, dump=[0, 2]),
 }
 
 
@@ -92,6 +96,8 @@ def resolve_lens(spec, n, m):
         return [m] * n
     if spec == "mixed200":
         pat = ["m", "m+5000", 150000, "m", 60000, "m", 9000, "m", 1012, "m"]
+    elif spec == "mixed200cnn":
+        pat = ["m", "m+5000", 150000, 9000, 60000, "m", 12000, "m", 1012, 11000, "m", 7500]
     elif spec == "mixed002":  # RNA002: min_obs_adapter=2000, ds=20 -> need >= 2020 samples
         pat = ["m", "m+5000", 30000, "m", 8000, 2025, 3000, "m", 2400, 12345]
     else:

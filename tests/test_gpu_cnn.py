@@ -12,22 +12,24 @@ from util import load_case, load_stages, row_diffs
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def setup():
+# both windows the reference was run at: the preset's (m = 17 500) and configs[2]'s (m = 201 500, Lc = 20 050: 12 reads incl.
+# ones short enough for the LLR fallback, one that raises) -- tests/golden/rna004_cnn_{default,200k}.*
+@pytest.fixture(scope="module", params=["rna004_cnn_default", "rna004_cnn_200k"])
+def setup(request):
     import torch
 
     from adapted_amd.detect import cnn
     from adapted_amd.detect.combined import get_engine
 
-    case, spc, sig, lens, want = load_case("rna004_cnn_default")
+    case, spc, sig, lens, want = load_case(request.param)
     model = cnn.load_cnn_model(spc.cnn_boundaries.model_name, device=0)
     eng = get_engine(spc, sig.shape[0], sig.shape[1], 0)
-    return dict(case=case, spc=spc, sig=sig, lens=lens, want=want, model=model, eng=eng, cnn=cnn, torch=torch)
+    return dict(name=request.param, case=case, spc=spc, sig=sig, lens=lens, want=want, model=model, eng=eng, cnn=cnn, torch=torch)
 
 
 def test_prepare_scores_preds(setup):
     s = setup
-    st = load_stages("rna004_cnn_default")
+    st = load_stages(s["name"])
     cnn, spc = s["cnn"], s["spc"]
     x = cnn.prepare_data(s["sig"], spc.core, spc=spc, engine=s["eng"])
     xc = x.cpu().numpy()

@@ -87,15 +87,19 @@ def test_mad_zero_raises(oracle_mod):
         oracle_mod.detect_llr(sig, np.full(4, spc.sig_preload_size, dtype=np.int32), spc)
 
 
-def test_cnn_oracle_vs_golden(oracle_mod):
+CNN_CASES = [k for k, c in CASES.items() if c["primary"] == "cnn"]  # the default window and configs[2]'s 200 k window
+
+
+@pytest.mark.parametrize("name", CNN_CASES)
+def test_cnn_oracle_vs_golden(oracle_mod, name):
     """C1 bit-exact, C2 (numpy conv) within 1e-4, C3 indices identical, rows (V1 with k candidates
     + C4 fallback) bit-exact given the reference's predictions."""
     import os
 
     from util import GOLD
 
-    case, spc, sig, lens, want = load_case("rna004_cnn_default")
-    st = load_stages("rna004_cnn_default")
+    case, spc, sig, lens, want = load_case(name)
+    st = load_stages(name)
     x = oracle_mod.cnn_prepare(sig, spc)
     for k in st["dump_idx"]:
         assert np.array_equal(x[int(k)], st["prep_%d" % int(k)])
