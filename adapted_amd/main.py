@@ -106,7 +106,7 @@ class _Writer:
 def _init_dist(device=None):
     """one process per GPU: the process group (RCCL = "nccl"; ADAPTED_DIST_BACKEND=gloo for CPU-side rehearsals / tests)"""
     rank, ws, local = parallel.world()
-    if ws <= 1:
+    if ws <= 1 and os.environ.get("ADAPTED_DIST_FORCE", "0") != "1":  # (forced: the several-ranks code on a group of one)
         return None
     import torch
     import torch.distributed as dist
@@ -115,7 +115,14 @@ def _init_dist(device=None):
     if not dist.is_initialized():
         if backend == "nccl":
             torch.cuda.set_device(local if device is None else device)
-        dist.init_process_group(backend)
+        if "MASTER_ADDR" not in os.environ:  # (forced group of one without a launcher)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+        dist.init_process_group(backend, rank=rank, world_size=ws)
     return dist
 
 
@@ -127,6 +134,7 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
         if ws > 1 and os.environ.get("ADAPTED_DIST_BACKEND", "nccl") != "nccl":
             device = local % max(lib.load().adp_device_count(), 1)  # (a rehearsal may share devices)
     dist = _init_dist(device)
+    multi = dist is not None  # several ranks (or a forced group of one): rows gathered to rank 0, written in stream order
     primary = spc.primary_method
     model = None  # CNN primary: the weights named in the config go to the engine on first use (no PyTorch module needed)
     m = spc.sig_preload_size
@@ -144,7 +152,7 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
     GROUP = 4  # minibatches per staging slot and detect call (normalisation stays per minibatch)
     pipe = HostPipeline(spc, minibatch, m, device=device, primary=primary, with_start_peak=start_peak,
                         model=model, int16_input=int16_ingest, group=GROUP, ragged=True)
-    sharder = GroupSharder(ws, rank, m) if ws > 1 else None
+    sharder = GroupSharder(ws, rank, m) if multi else None
     ordinals: List[int] = []  # stream index of the first read of every group this rank yields
 
     def fill(get_buffers):
@@ -159,7 +167,7 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
             yield k, tagged
 
     def on_rows(tagged, rows):
-        if ws > 1:
+        if multi:
             my_rows.append(rows)
             my_ids.extend(tagged[:, 0].tolist())
             my_ord.extend(int(x) for x in tagged[:, 1])
@@ -175,9 +183,9 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
         pipe.run(fill, on_rows, on_dropped)
     finally:
         pipe.close()
-    if ws > 1:
+    if multi:
         rows = np.concatenate(my_rows) if my_rows else np.zeros(0, dtype=lib.ROW_DTYPE)
-        allrows = parallel.gather_rows(rows, dst=0)
+        allrows = parallel.gather_rows(rows, dst=0, always=True)
         lists = [None] * ws if rank == 0 else None
         dist.gather_object((my_ids, my_ord), lists, dst=0)
         if rank == 0:
@@ -193,8 +201,9 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
                      tot / max(time.time() - t0, 1e-9), ws)
         if tot:
             logging.info("Pass: %d (%.2f%%), fail: %d", writer.n[True], 100.0 * writer.n[True] / tot, writer.n[False])
-    if ws > 1:
+    if multi:
         dist.barrier()
+        logging.info("process group: backend %s, %d rank(s); HIP runtimes mapped: %s", dist.get_backend(), ws, ", ".join(lib.hip_runtimes()))
 
 
 def main(argv=None):
@@ -213,8 +222,8 @@ def main(argv=None):
     else:
         args.output = args.output or os.getcwd()
         run_dir = os.path.join(args.output, "adapted_" + __version__.replace(".", "_") + "_" + str(uuid.uuid4())[:8])
-        if parallel.world()[1] > 1:  # one run directory for all ranks: rank 0's name
-            dist = _init_dist(getattr(args, "device", None))
+        dist = _init_dist(getattr(args, "device", None))
+        if dist is not None:  # one run directory for all ranks: rank 0's name
             box = [run_dir]
             dist.broadcast_object_list(box, src=0)
             run_dir = box[0]

@@ -32,13 +32,14 @@ def shard_reads(n_reads: int, minibatch: int, world_size: int, rank: int) -> Tup
     return min(r.start * minibatch, n_reads), min(r.stop * minibatch, n_reads)
 
 
-def gather_rows(rows, dst: int = 0, group=None):
+def gather_rows(rows, dst: int = 0, group=None, always: bool = False):
     """Gather per-rank row blocks (numpy structured array or uint8 torch tensor [n, row_bytes])
-    to `dst` in rank order.  Returns the concatenation on dst, None elsewhere."""
+    to `dst` in rank order.  Returns the concatenation on dst, None elsewhere.  A group of one returns its rows as they
+    are unless `always` asks for the collective all the same (how the RCCL branch is exercised on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return rows
     ws, rk = dist.get_world_size(group), dist.get_rank(group)
     backend = dist.get_backend(group)

@@ -115,9 +115,10 @@ def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens, pool, pr
             elif a != v:
                 mism += 1
     out = {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-           "sample": "%d reads (one minibatch) of the same synthetic workload, oracle/adapted_oracle.c, 1 thread, %.1f s; "
-                     "GPU rows of the same minibatch differ from it in %d fields" % (n_sample, dt, mism),
+           "sample": "%d reads (1 minibatch) of the workload, C port (oracle/), 1 thread, %.1f s" % (n_sample, dt),
+           "mismatched_fields": mism,  # GPU rows of the same minibatch against the port's, every field
            "host_cpus": os.cpu_count()}
+    out.update(cpu_grant())
     del sig
     if pool is not None and procs > 1:
         from multiprocessing import shared_memory
@@ -134,21 +135,71 @@ def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens, pool, pr
             shm.close()
             shm.unlink()
         out["cores_all"] = procs
+        out["cores_all_from"] = _CPU_WHY
         out["value_all_cores"] = procs * n_all / wall
-        out["sample_all_cores"] = ("%d worker processes x one minibatch of %d reads each (the reference's layout, adapted/file_proc.py:738-784), "
-                                   "%.1f s wall, slowest worker %.1f s" % (procs, n_all, wall, max(d for d, _ in res)))
-    tfile = os.path.join(ROOT, "profiles", "r02_reference_timing.json")
-    if os.path.exists(tfile):
+        out["sample_all_cores"] = "%d procs x %d reads (reference's pool layout), %.1f s wall" % (procs, n_all, wall)
+    for tname in ("r03_reference_timing.json", "r02_reference_timing.json"):
+        tfile = os.path.join(ROOT, "profiles", tname)
+        if not os.path.exists(tfile):
+            continue
         with open(tfile) as fh:
             t = json.load(fh)
+        # the real reference beside the port, same reads, build container (tools/time_reference.py); numbers only, so
+        # that the driver's record alone carries the GPU / reference ratio
         rp, ra = t["port_over_reference_per_proc"], t["port_over_reference_all_procs"]
-        out["port_over_reference"] = {"per_process": rp, "all_processes": ra,
-                                      "source": "profiles/r02_reference_timing.json (tools/time_reference.py: the real reference beside "
-                                                "the port, %d processes, build container)" % t["reference_all_procs"]["procs"]}
-        out["reference_equivalent"] = {"per_core": out["value"] / rp, "unit": "reads/s"}
+        out["port_over_reference"] = rp
+        out["port_over_reference_all_procs"] = ra
+        out["port_over_reference_source"] = "profiles/" + tname
+        out["reference_equivalent"] = out["value"] / rp  # reads/s of the reference on ONE core of this host
         if "value_all_cores" in out:
-            out["reference_equivalent"]["all_cores"] = out["value_all_cores"] / ra
+            out["reference_equivalent_all_cores"] = out["value_all_cores"] / ra  # ... on `cores_all` cores
+        break
     return out
+
+
+_CPU_WHY = None
+
+
+def cpu_grant():
+    """what this process may use of the host: the affinity mask, the cgroup CPU quota, and the worker count derived from
+    them (a 1-GPU lease of the pool is a 16-CPU share of a 256-CPU host; nothing in the mask or the quota says so)"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    raw = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(f) as fh:
+                raw = fh.read().strip()
+            break
+        except OSError:
+            continue
+    if raw:
+        parts = raw.split()
+        try:
+            if len(parts) == 2 and parts[0] != "max":
+                quota = float(parts[0]) / float(parts[1])
+            elif len(parts) == 1 and int(parts[0]) > 0:
+                quota = int(parts[0]) / 100000.0
+        except ValueError:
+            pass
+    return {"affinity_cpus": aff, "cgroup_cpu_max": raw, "cgroup_cpus": quota}
+
+
+def cpu_worker_count(requested):
+    """worker processes of the all-cores baseline: every CPU the mask and the quota grant; where neither limits anything
+    (mask = the whole host, quota "max") the pool's documented share of a one-GPU box, 16"""
+    if requested:
+        return int(requested), "--cpu-procs"
+    g = cpu_grant()
+    n = g["affinity_cpus"]
+    why = "affinity mask"
+    if g["cgroup_cpus"]:
+        q = max(1, int(g["cgroup_cpus"] + 0.5))
+        if q < n:
+            n, why = q, "cgroup cpu.max"
+    if n > 64 and not g["cgroup_cpus"]:
+        n, why = 16, "unrestricted mask (%d CPUs): the 1-GPU lease's 16-CPU share" % g["affinity_cpus"]
+    return n, why
 
 
 def host_pipeline_bench(args, spc, device):
@@ -258,13 +309,16 @@ F32_MFMA_PEAK_TF = 157.3  # MI355X float32 matrix peak (/opt/skills/guides/MI355
 
 
 def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=0):
-    """One workload (w: argparse-like namespace) on this rank's GPU; rank 0 returns the JSON object, the others None."""
+    """One workload (w: argparse-like namespace) on this rank's GPU; rank 0 returns the JSON object, the others None.
+    dist is None on the plain one-GPU path; with a process group (N > 1, or ADP_BENCH_FORCE_DIST=1 at N = 1: the same code
+    on a group of one) every step ends with the row gather and the clock is the max over ranks."""
     import threading
 
     import torch
     from adapted_amd import lib
 
     dev = torch.device("cuda", local)
+    multi = dist is not None
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
     spc = make_spc(w.max_obs_trace, w.primary)
     cnn_mod = None
@@ -286,7 +340,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         lens_host = np.array([_synth.pareto_length(w.seed, rank * R + i) for i in range(R)], dtype=np.int32)
     len_t = torch.from_numpy(lens_host).to(dev)
     # two row buffers: with several ranks the gather of step k (RCCL, its own stream) runs beside the kernels of step k + 1
-    rows_bufs = [torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    rows_bufs = [torch.empty((R, lib.ROW_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(2 if multi else 1)]
     rows_t = rows_bufs[0]
     torch.cuda.synchronize()
     # rank r owns reads [r*R, (r+1)*R) of the global stream: contiguous whole minibatches
@@ -318,7 +372,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         sig_t = None
         torch.cuda.empty_cache()
     gathered = None
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         gathered = [torch.empty_like(rows_t, device=comm_dev) for _ in range(world)]
 
     state = {"rows": rows_t, "pending": None, "i": 0}
@@ -350,7 +404,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                 t.start()
             for t in ths:
                 t.join()
-        if world > 1:
+        if multi:
             # every detect call ends with its stream drained, so the rows are complete here; the gather is left running
             # and waited for before the next one starts (and before the clock stops)
             if state["pending"] is not None:
@@ -366,7 +420,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         if state["pending"] is not None:
             state["pending"].wait()
             state["pending"] = None
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -389,7 +443,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
     dt = time.perf_counter() - t0
     for e in engines:
         e.set_profiling(False)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -397,8 +451,13 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
     value = total_reads / dt
     out = None
     if rank == 0:
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload shape, where one was taken (else null)
         traffic = None
-        for tname in ("r02_traffic.json", "r01_traffic.json"):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        shape = None
+        if w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and NS == 1:
+            shape = "int16" if getattr(w, "int16", False) else "f32"
+        tnames = {"f32": ("r03_traffic.json", "r02_traffic.json"), "int16": ("r03_traffic_int16.json", "r02_traffic_int16.json")}.get(shape, ())
+        for tname in tnames:
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile):
                 with open(tfile) as fh:
@@ -406,8 +465,17 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                 traffic["_file"] = "profiles/" + tname
                 break
         rows = np.zeros(R, dtype=lib.ROW_DTYPE)
-        eng.d2h(rows, rows_bufs[(state["i"] - 1) % 2 if world > 1 else 0].data_ptr())  # (the last step's rows)
+        eng.d2h(rows, rows_bufs[(state["i"] - 1) % 2 if multi else 0].data_ptr())  # (the last step's rows)
         n_ok = int(rows["success"].sum())
+        import hashlib
+
+        gather_ok = None
+        if multi:  # what the collective delivered for this rank's block against the block itself
+            gather_ok = bool(np.array_equal(gathered[0].cpu().numpy().reshape(-1), rows.view(np.uint8).reshape(-1)))
+        hrows = rows.copy()
+        hrows["open_pores_more"] = 0  # (arena offsets: handed out by an atomic counter, any order)
+        rows_digest = hashlib.sha256(hrows.tobytes()).hexdigest()  # (last step, this rank: equal between a plain and a grouped run)
+        del hrows
         kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
         dom = max(kavg, key=kavg.get)
         # 4 bytes per PRELOADED sample, each read once; a launch covers the Rs reads of one engine
@@ -430,13 +498,16 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic.get(dom, {}).get("hbm_bytes") * (Rs / traffic["_reads_per_launch"])
-                                     if traffic and dom in traffic and w.lens == "full" and w.primary == "llr" else None),
+                                     if traffic and dom in traffic else None),
                          "traffic_source": (traffic["_file"] + " (rocprofv3 --pmc, FETCH_SIZE doubled per MI355X_MICROARCH.md)") if traffic else None,
                          "kernel_ms": kavg[dom], "algorithmic_bytes_per_launch": b_alg,
                          "whole_path_frac": (bps * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS},
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "kernel_ms_sum": sum(kavg.values()),
+            "rows_sha256": rows_digest,
         }
+        if multi:
+            out["gathered_block_equals_local_rows"] = gather_ok
         if w.primary == "cnn":
             # configs[2] is a dense contraction: the float32 matrix peak bounds the conv stack
             Lc = (m - spc.core.min_obs_adapter + spc.core.downscale_factor - 1) // spc.core.downscale_factor
@@ -465,7 +536,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                       "mad_not_predicted": int(c[3]), "mad_bracket_overflow": int(c[4]),
                                       "n1_fused_minibatches": int(c[5]), "n1_fused_fallbacks": int(c[6]) + int(c[7]),
                                       "n1_heavy_keys": int(c[22]), "n1_heavy_samples": int(c[23])}
-        if world == 1 and w.cpu_sample > 0 and w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and raw_t is None:
+        if world == 1 and not multi and w.cpu_sample > 0 and w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and raw_t is None:
             n_s = min(w.cpu_sample, R)
             n_all = min(w.cpu_sample_all, R // max(cpu_procs, 1)) if cpu_procs > 1 else 0
             out["cpu_baseline"] = cpu_baseline(eng, spc, sig_t.data_ptr(), n_s, m, rows, lens_host, cpu_pool, cpu_procs if n_all > 0 else 0,
@@ -525,7 +596,8 @@ def main():
     ap.add_argument("--max_obs_trace", type=int, default=200000)
     ap.add_argument("--cpu-sample", type=int, default=1000, help="reads timed on the CPU oracle, one thread (rank 0, N=1)")
     ap.add_argument("--cpu-sample-all", type=int, default=500, help="reads per worker process of the all-cores CPU baseline")
-    ap.add_argument("--cpu-procs", type=int, default=None, help="worker processes of the all-cores CPU baseline (default: the host's cores, at most 16)")
+    ap.add_argument("--cpu-procs", type=int, default=None, help="worker processes of the all-cores CPU baseline (default: every CPU the affinity "
+                                                                "mask and the cgroup quota grant; 16 when neither restricts a big host)")
     ap.add_argument("--lens", choices=["full", "pareto"], default="full",
                     help="read lengths: full (the headline workload: every read fills the window) or pareto (BASELINE configs[4]: "
                          "Pareto(1.2) clipped to [10k, 1M] samples -- most reads much shorter than the window, NaN padded; a probe)")
@@ -567,8 +639,9 @@ def main():
 
     # the all-cores CPU baseline runs in worker processes: start them before this process initialises the GPU
     cpu_pool, cpu_procs = None, 0
-    if world == 1 and args.cpu_sample > 0 and args.cpu_sample_all > 0 and default_run:
-        cpu_procs = args.cpu_procs or min(len(os.sched_getaffinity(0)), 16)
+    if world == 1 and args.cpu_sample > 0 and args.cpu_sample_all > 0 and default_run and os.environ.get("ADP_BENCH_FORCE_DIST", "0") != "1":
+        global _CPU_WHY
+        cpu_procs, _CPU_WHY = cpu_worker_count(args.cpu_procs)
         if cpu_procs > 1:
             cpu_pool = _cpu_pool_start(cpu_procs)
 
@@ -584,9 +657,19 @@ def main():
     if backend != "nccl":
         local = local % max(ndev, 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    # ADP_BENCH_FORCE_DIST=1: the N > 1 code path on a process group of ONE (RCCL init, double-buffered row gather, barrier,
+    # all-reduce of the clock) -- how the RCCL branch is exercised on a one-GPU box (tests/test_gpu_rccl.py)
+    force_dist = os.environ.get("ADP_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
+        if world_env == 0:  # (forced, no launcher: a rendezvous of our own)
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.host_pipeline > 0:
@@ -595,7 +678,12 @@ def main():
     if cpu_pool is not None:
         cpu_pool.close()
         cpu_pool.join()
-    if rank == 0 and world == 1 and default_run and not args.no_secondary:
+    if rank == 0 and dist is not None:
+        from adapted_amd import lib as _lib
+
+        out["dist"] = {"backend": backend, "world_size": world, "forced_group_of_one": bool(force_dist and world == 1),
+                       "hip_runtimes": _lib.hip_runtimes(), "row_gather": "dist.gather of %d-byte rows, double-buffered" % _lib.ROW_DTYPE.itemsize}
+    if rank == 0 and world == 1 and dist is None and default_run and not args.no_secondary:
         # the other single-GPU configurations of BASELINE.json, driver-run with the headline (each its own roofline)
         sec = {}
         # (cnn_200k at 8000 reads per step: the moving-window series of the candidate validation is a sequential float32
@@ -616,7 +704,7 @@ def main():
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

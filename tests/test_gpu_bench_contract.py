@@ -33,4 +33,5 @@ def test_bench_json_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
-    assert "differ from it in 0 fields" in c["sample"]
+    assert c["mismatched_fields"] == 0 and len(c["sample"]) <= 100
+    assert c["affinity_cpus"] >= 1 and "cgroup_cpu_max" in c

@@ -93,7 +93,7 @@ def _results_from_golden(name):
     return out
 
 
-@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores"])
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k"])
 def test_csv_text_equals_reference(tmp_path, name):
     from adapted_amd.output import CSV_COLUMNS, save_detected_boundaries
 
