@@ -62,8 +62,24 @@ class GroupSharder:
         self.load[self.owner] += max(0, min(int(n_samples), self.m))
 
 
-def _iter_reads(filename: str, selection: Optional[List[str]]):
-    """yield (read_id, n_samples, get) -- get() decodes and returns the pA signal; reads nobody asks for cost nothing"""
+def _lazy(fn, threadsafe: bool):
+    fn.threadsafe = threadsafe
+    return fn
+
+
+def _fetch(get):
+    """what goes to the copy pool for one read: the accessor itself when any thread may call it (.npz arrays), else the
+    signal decoded HERE, in the thread that iterates the reader (a pod5 Reader is neither promised to be thread-safe nor
+    alive once its file's iteration ends)"""
+    if getattr(get, "threadsafe", False):
+        return get
+    sig = get()
+    return lambda: sig
+
+
+def _iter_reads(filename: str, selection: Optional[List[str]], drain=None):
+    """yield (read_id, n_samples, get) -- get() decodes and returns the pA signal; reads nobody asks for cost nothing.
+    drain: called before a .pod5 file is closed (the caller's pending row copies finish while the reader is alive)."""
     if filename.endswith(".npz"):
         z = np.load(filename, allow_pickle=True)
         ids = [str(x) for x in z["read_ids"]]
@@ -73,15 +89,19 @@ def _iter_reads(filename: str, selection: Optional[List[str]]):
         for i, rid in enumerate(ids):
             if sel is not None and rid not in sel:
                 continue
-            yield rid, int(lens[i]), (lambda i=i: dense[i] if dense is not None else z["signal_%d" % i])
+            yield rid, int(lens[i]), _lazy((lambda i=i: dense[i] if dense is not None else z["signal_%d" % i]), True)
     else:
         try:
             from pod5 import Reader
         except ImportError as e:  # pragma: no cover
             raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
         with Reader(filename) as fh:
-            for rec in fh.reads(selection=selection, missing_ok=True):
-                yield str(rec.read_id), int(rec.num_samples), (lambda rec=rec: rec.signal_pa)
+            try:
+                for rec in fh.reads(selection=selection, missing_ok=True):
+                    yield str(rec.read_id), int(rec.num_samples), _lazy((lambda rec=rec: rec.signal_pa), False)
+            finally:
+                if drain is not None:
+                    drain()
 
 
 def _copy_pool(workers: Optional[int]):
@@ -137,7 +157,7 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
     mine = True
     try:
         for fn in files:
-            for rid, n_samples, get in _iter_reads(fn, selection):
+            for rid, n_samples, get in _iter_reads(fn, selection, finish):
                 if rid in read_ids_excl:
                     continue
                 if k == 0 and sharder is not None:
@@ -148,7 +168,7 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
                     if sig is None:
                         sig, lens, ids = fresh()
                     if pool is not None:
-                        pending.append(pool.submit(lambda d, gt, ns: put_row(d, gt(), ns), sig[k], get, n_samples))
+                        pending.append(pool.submit(lambda d, gt, ns: put_row(d, gt(), ns), sig[k], _fetch(get), n_samples))
                     else:
                         put_row(sig[k], get(), n_samples)
                     lens[k] = n_samples
@@ -173,8 +193,8 @@ def yield_minibatches(files: Iterable[str], read_ids_incl: Set[str], read_ids_ex
             pool.shutdown(wait=True)
 
 
-def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
-    """yield (read_id, n_samples, get, scale, offset) -- get() returns the raw int16 samples"""
+def _iter_reads_i16(filename: str, selection: Optional[List[str]], drain=None):
+    """yield (read_id, n_samples, get, scale, offset) -- get() returns the raw int16 samples (drain: as in _iter_reads)"""
     if filename.endswith(".npz"):
         z = np.load(filename, allow_pickle=True)
         if "raw" not in z and "raw_0" not in z:
@@ -186,16 +206,20 @@ def _iter_reads_i16(filename: str, selection: Optional[List[str]]):
         for i, rid in enumerate(ids):
             if sel is not None and rid not in sel:
                 continue
-            yield rid, int(lens[i]), (lambda i=i: dense[i] if dense is not None else z["raw_%d" % i]), float(scale[i]), float(offset[i])
+            yield rid, int(lens[i]), _lazy((lambda i=i: dense[i] if dense is not None else z["raw_%d" % i]), True), float(scale[i]), float(offset[i])
     else:
         try:
             from pod5 import Reader
         except ImportError as e:  # pragma: no cover
             raise RuntimeError("reading .pod5 files needs the `pod5` package") from e
         with Reader(filename) as fh:
-            for rec in fh.reads(selection=selection, missing_ok=True):
-                yield (str(rec.read_id), int(rec.num_samples), (lambda rec=rec: rec.signal), float(rec.calibration.scale),
-                       float(rec.calibration.offset))
+            try:
+                for rec in fh.reads(selection=selection, missing_ok=True):
+                    yield (str(rec.read_id), int(rec.num_samples), _lazy((lambda rec=rec: rec.signal), False), float(rec.calibration.scale),
+                           float(rec.calibration.offset))
+            finally:
+                if drain is not None:
+                    drain()
 
 
 def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_ids_excl: Set[str], batch_size: int,
@@ -238,7 +262,7 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
     mine = True
     try:
         for fn in files:
-            for rid, n_samples, get, scale, offset in _iter_reads_i16(fn, selection):
+            for rid, n_samples, get, scale, offset in _iter_reads_i16(fn, selection, finish):
                 if rid in read_ids_excl:
                     continue
                 if k == 0 and sharder is not None:
@@ -250,7 +274,7 @@ def yield_minibatches_i16(files: Iterable[str], read_ids_incl: Set[str], read_id
                         cur = fresh()
                     raw, lens, sc, of, ids = cur
                     if pool is not None:
-                        pending.append(pool.submit(lambda d, gt, ns, r: put_row(d, gt(), ns, r), raw[k], get, n_samples, rid))
+                        pending.append(pool.submit(lambda d, gt, ns, r: put_row(d, gt(), ns, r), raw[k], _fetch(get), n_samples, rid))
                     else:
                         put_row(raw[k], get(), n_samples, rid)
                     lens[k], sc[k], of[k], ids[k] = n_samples, scale, offset, rid
@@ -307,10 +331,10 @@ def yield_minibatches_packed(files: Iterable[str], read_ids_incl: Set[str], read
     k = 0
     g = 0
     mine = True
-    it = _iter_reads_i16 if int16 else (lambda fn, sel: ((r, n, s, None, None) for r, n, s in _iter_reads(fn, sel)))
+    it = _iter_reads_i16 if int16 else (lambda fn, sel, drain: ((r, n, s, None, None) for r, n, s in _iter_reads(fn, sel, drain)))
     try:
         for fn in files:
-            for rid, n_samples, get, scale, offset in it(fn, selection):
+            for rid, n_samples, get, scale, offset in it(fn, selection, finish):
                 if rid in read_ids_excl:
                     continue
                 if k == 0 and sharder is not None:
@@ -326,7 +350,7 @@ def yield_minibatches_packed(files: Iterable[str], read_ids_incl: Set[str], read
                     take = max(0, min(m, int(n_samples)))
                     a = int(offs[k])
                     if pool is not None:
-                        pending.append(pool.submit(lambda d, gt, tk, r: put(d, gt(), tk, r), flat[a:a + take], get, take, rid))
+                        pending.append(pool.submit(lambda d, gt, tk, r: put(d, gt(), tk, r), flat[a:a + take], _fetch(get), take, rid))
                     else:
                         put(flat[a:a + take], get(), take, rid)
                     offs[k + 1] = a + take

@@ -270,3 +270,95 @@ def test_minibatches_fill_caller_buffers_in_place(tmp_path):
         assert list(ids) == list(plain[k][2])
         seen += sig.shape[0]
     assert seen == n and len(handed) == 3
+
+
+def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(monkeypatch):
+    """The copy pool must never touch a pod5 record: decoding happens in the thread that iterates the Reader and before the
+    file is closed (groups that span two files, the final partial group).  A stand-in `pod5` whose records refuse any other
+    use (wrong thread, closed reader) drives all three assemblers over three files."""
+    import sys
+    import threading
+    import types
+
+    from adapted_amd import io_utils
+
+    m, per_file = 700, 5
+    rng = np.random.default_rng(3)
+    store = {"f%d.pod5" % f: [(("r%d_%d" % (f, i)), rng.integers(200, 900, int(rng.integers(300, 1000))).astype(np.int16))
+                              for i in range(per_file)] for f in range(3)}
+
+    class Cal:
+        scale, offset = 0.25, -3.0
+
+    class Rec:
+        def __init__(self, owner, rid, raw):
+            self._o, self.read_id, self._raw, self.num_samples, self.calibration = owner, rid, raw, raw.size, Cal()
+
+        def _check(self):
+            assert not self._o.closed, "record used after its Reader was closed"
+            assert threading.get_ident() == self._o.thread, "record decoded outside the reader's thread"
+
+        @property
+        def signal(self):
+            self._check()
+            return self._raw
+
+        @property
+        def signal_pa(self):
+            self._check()
+            return (np.float32(0.25) * (self._raw.astype(np.float32) + np.float32(-3.0))).astype(np.float32)
+
+    class Reader:
+        def __init__(self, fn):
+            self.fn, self.closed, self.thread = os.path.basename(fn), False, threading.get_ident()
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            self.closed = True
+
+        def reads(self, selection=None, missing_ok=True):
+            for rid, raw in store[self.fn]:
+                if selection is None or rid in selection:
+                    yield Rec(self, rid, raw)
+
+    monkeypatch.setitem(sys.modules, "pod5", types.SimpleNamespace(Reader=Reader))
+    files = sorted(store)
+    flat_all = [raw for f in files for _, raw in store[f]]
+    ids_all = [rid for f in files for rid, _ in store[f]]
+    N = 4  # groups of 4 over files of 5: every group but the first spans two files; 15 reads leave a partial group
+    got_ids, k0 = [], 0
+    for sig, lens, ids in io_utils.yield_minibatches(files, set(), set(), N, m, workers=4):
+        for j in range(len(ids)):
+            raw = flat_all[k0 + j]
+            want = (np.float32(0.25) * (raw.astype(np.float32) + np.float32(-3.0)))[:m]
+            assert np.array_equal(sig[j, :want.size], want) and np.isnan(sig[j, want.size:]).all() and lens[j] == raw.size
+        got_ids += list(ids)
+        k0 += len(ids)
+    assert got_ids == ids_all
+    k0 = 0
+    for raw, lens, sc, of, ids in io_utils.yield_minibatches_i16(files, set(), set(), N, m, workers=4):
+        for j in range(len(ids)):
+            w = flat_all[k0 + j][:m]
+            assert np.array_equal(raw[j, :w.size], w) and sc[j] == np.float32(0.25) and of[j] == np.float32(-3.0)
+        k0 += len(ids)
+    assert k0 == len(ids_all)
+    for i16 in (False, True):
+        bufs = []
+
+        def buffers():
+            b = (np.zeros(N * m, dtype=np.int16 if i16 else np.float32), np.zeros(N, np.int32), np.zeros(N + 1, np.int64),
+                 np.zeros(N, np.float32), np.zeros(N, np.float32))
+            bufs.append(b)
+            return b
+
+        k0 = 0
+        for k, ids in io_utils.yield_minibatches_packed(files, set(), set(), N, m, buffers, int16=i16, workers=4):
+            flat, lens, offs = bufs[-1][0], bufs[-1][1], bufs[-1][2]
+            for j in range(k):
+                raw = flat_all[k0 + j][:m]
+                want = raw if i16 else (np.float32(0.25) * (raw.astype(np.float32) + np.float32(-3.0)))
+                assert np.array_equal(flat[offs[j]:offs[j + 1]], want)
+            k0 += k
+        assert k0 == len(ids_all)
