@@ -51,6 +51,7 @@ struct DevBuf {
 };
 
 struct ProfEntry { const char *name; hipEvent_t a, b; };
+#define ADP_MAX_LANES 4
 
 struct adp_handle {
     int device = 0;
@@ -81,6 +82,14 @@ struct adp_handle {
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
+    // grouped execution of the LLR path (llr_grouped): child handles ("lanes") with their own streams and a workspace for ONE
+    // group of minibatches; consecutive groups go to alternating lanes so that the phases of neighbouring groups overlap
+    adp_handle *lane[ADP_MAX_LANES] = {};
+    adp_handle *owner = nullptr;            // a lane's parent: owns the open-pore arena and collects the profile
+    DevBuf mbstat, mbparams;                // parent: minibatch status / N1 parameters of a grouped call
+    std::vector<hipEvent_t> ev_sync;        // parent: phase-done events of the groups (no timing)
+    hipEvent_t ev_start = nullptr;          // parent: inputs staged, arena counter reset
+    bool last_grouped = false;
 };
 
 static int geom(adp_handle *h)
@@ -115,12 +124,14 @@ static int geom(adp_handle *h)
     return 0;
 }
 
-static int alloc_all(adp_handle *h)
+// Workspace for a call over `reads` reads (grow-only; allocated by the call that needs it, not by adp_create: a grouped LLR
+// call keeps its big buffers in the lanes, sized for one group).  llr: the pooled signal / trace / peak-list buffers too.
+static int alloc_all(adp_handle *h, int reads, bool llr)
 {
-    const size_t R = (size_t)h->max_reads, Lp = (size_t)h->Lp;
+    const size_t R = (size_t)(reads < 1 ? 1 : reads), Lp = (size_t)h->Lp;
     int bad = 0;
+    if (llr) {
     bad |= h->down.ensure(R * Lp * 4);
-    bad |= h->nvalid.ensure(R * 4);
     bad |= h->gstat.ensure(R * 24);
     bad |= h->ck.ensure(R * h->nck * sizeof(double2));
     bad |= h->tail.ensure(R * sizeof(double2));
@@ -128,6 +139,8 @@ static int alloc_all(adp_handle *h)
     bad |= h->bmax.ensure(R * h->nsum * 8);
     bad |= h->bmin.ensure(R * h->nsum * 8);
     bad |= h->t1.ensure(R * sizeof(int2));
+    }
+    bad |= h->nvalid.ensure(R * 4);
     bad |= h->adapter_idx.ensure(R * 4);
     bad |= h->polya_idx.ensure(R * 4);
     bad |= h->bounds.ensure(R * (1 + ADP_MAX_CAND) * 8);
@@ -149,9 +162,11 @@ static int alloc_all(adp_handle *h)
     }
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);
     h->pslots = (int)(R < 8192 ? R : 8192);
+    if (llr) {
     bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
     bad |= h->npk.ensure(R * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
+    }
     if (bad) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     return 0;
 }
@@ -223,8 +238,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
         hipStreamCreate(&h->stream3) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
-    rc = alloc_all(h);
-    if (rc) { adp_destroy(h); return rc; }
+    if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) { adp_destroy(h); g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     *out = h;
     return ADP_OK;
@@ -234,7 +248,11 @@ int adp_destroy(adp_handle *h)
 {
     if (!h) return ADP_OK;
     (void)hipSetDevice(h->device);
+    for (int i = 0; i < ADP_MAX_LANES; i++) if (h->lane[i]) { adp_destroy(h->lane[i]); h->lane[i] = nullptr; }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    h->mbstat.release(); h->mbparams.release();
     DevBuf *all[] = {&h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
@@ -258,7 +276,8 @@ int adp_set_config(adp_handle *h, const adp_cfg *cfg)
     h->cfg = *cfg;
     int rc = geom(h);
     if (rc) return rc;
-    return alloc_all(h);
+    for (int i = 0; i < ADP_MAX_LANES; i++) if (h->lane[i]) { h->lane[i]->cfg = *cfg; (void)geom(h->lane[i]); }
+    return ADP_OK;
 }
 
 void *adp_stream(adp_handle *h) { return h ? (void *)h->stream : nullptr; }
@@ -367,6 +386,28 @@ static void sync_ablate(hipStream_t st)
     }
 }
 
+// ---- the open-pore arena of one API call --------------------------------------------------
+// arena_begin: allocated, counter zeroed (on the handle's stream, ahead of every kernel of the call).  arena_end (the call's
+// stream(s) drained): how much the call wanted; > capacity = lists were dropped: grow and tell the caller to run again.
+static int arena_begin(adp_handle *h)
+{
+    if (h->op_used.ensure(8) || (h->op_arena.cap == 0 && h->op_arena.ensure((size_t)65536 * 4))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    HIPCHK(hipMemsetAsync(h->op_used.p, 0, 4, h->stream));
+    return 0;
+}
+// -> 0 done, 1 run the call again (arena grown), < 0 error
+static int arena_end(adp_handle *h)
+{
+    if (!h->cfg.detect_open_pores) { h->op_last_used = 0; return 0; }
+    unsigned int used = 0;
+    HIPCHK(hipMemcpyAsync(&used, h->op_used.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->op_last_used = used;
+    if ((size_t)used * 4 <= h->op_arena.cap) return 0;
+    if (h->op_arena.ensure((size_t)used * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    return 1;
+}
+
 template <int THREADS, int L0, int LN>
 static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
 {
@@ -426,21 +467,12 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     }
     int grid = n < h->vslots ? n : h->vslots;
     sync_ablate(h->stream);
-    // open-pore lists longer than a row holds go to an arena; if it turns out too small the kernel runs again on a larger one
-    if (h->op_used.ensure(8) || (h->op_arena.cap == 0 && h->op_arena.ensure((size_t)65536 * 4))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-    for (int attempt = 0; attempt < 3; attempt++) {
-        in.op_arena = h->op_arena.as<int32_t>(); in.op_used = h->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(h->op_arena.cap / 4);
-        HIPCHK(hipMemsetAsync(h->op_used.p, 0, 4, h->stream));
-        { Scope s(h, attempt ? nullptr : "k_validate");
-          hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
-        if (!h->cfg.detect_open_pores) { h->op_last_used = 0; break; }
-        unsigned int used = 0;
-        HIPCHK(hipMemcpyAsync(&used, h->op_used.p, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->op_last_used = used;
-        if ((size_t)used * 4 <= h->op_arena.cap) break;
-        if (h->op_arena.ensure((size_t)used * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-    }
+    // open-pore lists longer than a row holds go to the arena of the CALL (arena_begin / arena_end: cumulative over every
+    // launch of the call, shared by the lanes of a grouped call; a call that overflowed it is repeated on a larger one)
+    adp_handle *a = h->owner ? h->owner : h;
+    in.op_arena = a->op_arena.as<int32_t>(); in.op_used = a->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(a->op_arena.cap / 4);
+    { Scope s(h, "k_validate");
+      hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
     { Scope s(h, "k_partition_stats");
       hipLaunchKernelGGL(k_partition_stats<SIG>, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
@@ -523,10 +555,23 @@ static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch
     return 0;
 }
 
-// the LLR path over a resident signal matrix: float32 pA (SigF32) or int16 ADC + calibration (SigI16)
+// ---- the LLR path over a resident signal matrix: float32 pA (SigF32) or int16 ADC + calibration (SigI16) ----------------
+// Three phases per group of minibatches: S (N1 + normalised pooling: streams the signal twice), C (cumulative sums, both
+// gains passes, peak picking: float64 ALU / latency, touches only the pooled signal), V (validation + partition statistics:
+// streams the signal twice more).  llr_enqueue puts one group on a handle's stream WITHOUT waiting for anything on the host;
+// PhaseSync lets the caller order the phases of different groups against each other across streams.
+struct PhaseSync {
+    hipEvent_t wait[3] = {nullptr, nullptr, nullptr};  // before phase S / C / V: wait for this event (another stream's)
+    hipEvent_t done[3] = {nullptr, nullptr, nullptr};  // after phase S / C / V: record this event
+};
+
+static __device__ __host__ inline SigF32 sig_from(const SigF32 &s, size_t r0, int m) { return SigF32{s.base + r0 * (size_t)m}; }
+static __device__ __host__ inline SigI16 sig_from(const SigI16 &s, size_t r0, int m) { return SigI16{s.base + r0 * (size_t)m, s.scale + r0, s.offset + r0, s.full_len + r0}; }
+
 template <class SIG>
-static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int minibatch, int flags,
-                          adp_row *rows_out, int32_t *mb_status, int upto)
+static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int minibatch, int flags,
+                       adp_row *rows_dev, int rows_kind /* hipMemcpyKind of the row delivery */, int32_t *mb_status_dev, double *mb_params_dev,
+                       int upto, const PhaseSync *ps)
 {
     int rc = 0;
     const int n_mb = (n + minibatch - 1) / minibatch;
@@ -534,8 +579,11 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
     if (h->mbs.ensure((size_t)n_mb * sizeof(MbState)) || h->ghist.ensure((size_t)n_mb * N1_BINS * 4) || h->gbelow.ensure((size_t)n_mb * 8) || h->gcnt.ensure((size_t)n_mb * 8 * N1_NCNT)) {
         g_err = "device allocation failed"; return ADP_ERR_HIP;
     }
+    rc = alloc_all(h, n, true);
+    if (rc) return rc;
     hipStream_t st = h->stream;
     sync_ablate(st);
+    if (ps && ps->wait[0]) HIPCHK(hipStreamWaitEvent(st, ps->wait[0], 0));
     MbState *mbs = h->mbs.as<MbState>();
     HIPCHK(hipMemsetAsync(mbs, 0, (size_t)n_mb * sizeof(MbState), st));
     HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)n_mb * N1_BINS * 4, st));
@@ -545,7 +593,9 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
     bool sp_forked = false;
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
+        if (ps) for (int k = 0; k < 2; k++) { if (k && ps->wait[k]) HIPCHK(hipStreamWaitEvent(st, ps->wait[k], 0)); if (ps->done[k]) HIPCHK(hipEventRecord(ps->done[k], st)); }
     } else {
+        // ---- phase S
         const int32_t *tails = (flags & ADP_TAILS_NAN) ? dlen : nullptr;
         rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true, tails);
         if (rc) return rc;
@@ -559,7 +609,7 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
                 std::vector<int64_t> hr((size_t)2 * n);
                 for (int i = 0; i < n; i++) { hr[2 * i] = 0; hr[2 * i + 1] = T; }
                 HIPCHK(hipMemcpyAsync(h->rng0.p, hr.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
-                HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope)
+                HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope; this layout is never grouped)
                 rng = h->rng0.as<int64_t>();
             }
             hipLaunchKernelGGL(k_norm_pool<SIG>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
@@ -568,6 +618,7 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
         }
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);
+        if (ps && ps->done[0]) HIPCHK(hipEventRecord(ps->done[0], st));
         if (upto >= 8 && (flags & ADP_WITH_START_PEAK)) {
             // the start-peak scan depends on nothing computed here: it streams the signal on the side stream while the
             // main stream runs the ALU-bound cumulative sums and gains
@@ -578,6 +629,8 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
             HIPCHK(hipEventRecord(h->ev_join, h->stream2));
             sp_forked = true;
         }
+        // ---- phase C
+        if (ps && ps->wait[1]) HIPCHK(hipStreamWaitEvent(st, ps->wait[1], 0));
         if (upto >= 3) {
             Scope s(h, "k_cumsum");
             hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
@@ -609,8 +662,11 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
                                h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
         }
+        if (ps && ps->done[1]) HIPCHK(hipEventRecord(ps->done[1], st));
     }
     if (upto >= 8) {
+        // ---- phase V
+        if (ps && ps->wait[2]) HIPCHK(hipStreamWaitEvent(st, ps->wait[2], 0));
         if (h->L > 0)
             hipLaunchKernelGGL(k_llr_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->adapter_idx.as<int32_t>(),
                                h->polya_idx.as<int32_t>(), n, h->ds, h->pos_off, h->bounds.as<int64_t>(), h->topk_none.as<int8_t>(), h->layout == ADP_LAYOUT_SINGLE_READ ? 1 : 0);
@@ -625,16 +681,133 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
             hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 0,
                                (const int32_t *)nullptr);
         }
-        rc = deliver_rows(h, n, flags, rows_out);
-        if (rc) return rc;
+        if (rows_dev)
+            HIPCHK(hipMemcpyAsync(rows_dev, h->rows.p, (size_t)n * sizeof(adp_row), (hipMemcpyKind)rows_kind, st));
     }
-    if (mb_status) {
-        // through a small device buffer -> host
-        hipLaunchKernelGGL(k_mb_status_out, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, h->gbelow.as<int32_t>());
-        HIPCHK(hipMemcpyAsync(mb_status, h->gbelow.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, st));
-    }
+    if (mb_status_dev)
+        hipLaunchKernelGGL(k_mb_status_out, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, mb_status_dev);
+    if (mb_params_dev)
+        hipLaunchKernelGGL(k_mb_params_out, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, mb_params_dev);
+    if (ps && ps->done[2]) HIPCHK(hipEventRecord(ps->done[2], st));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    return ADP_OK;
+}
+
+// how a call's minibatches are cut into groups: ADP_GROUPS (0 / unset: automatic, 1: one group = the plain serial pipeline, k: aim at
+// k groups); ADP_LANES (streams the groups rotate over, default 2); ADP_STAGGER (bit p set: phase p of group g + 1 starts
+// after phase p of group g; default 1 = the streaming S phases take turns, which keeps neighbouring groups one phase apart)
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static int lane_get(adp_handle *h, int i, int reads, adp_handle **out)
+{
+    adp_handle *l = h->lane[i];
+    if (!l) {
+        int rc = adp_create(h->device, &h->cfg, h->max_reads, h->m, &l);
+        if (rc) return rc;
+        l->owner = h;
+        l->n_cu = h->n_cu;
+        h->lane[i] = l;
+    }
+    l->profiling = h->profiling;
+    *out = l;
+    (void)reads;
+    return 0;
+}
+
+template <class SIG>
+static int llr_grouped(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int minibatch, int flags, adp_row *rows_out,
+                       int32_t *mb_status, int mb_per_group, int n_lanes)
+{
+    const int n_mb = (n + minibatch - 1) / minibatch;
+    const int G = (n_mb + mb_per_group - 1) / mb_per_group;
+    const int stagger = env_int("ADP_STAGGER", 1);
+    h->last_n = n; h->last_nmb = n_mb; h->last_grouped = true;
+    const bool out_dev = (flags & ADP_OUT_DEVICE) != 0;
+    if (h->mbstat.ensure((size_t)n_mb * 4) || h->mbparams.ensure((size_t)n_mb * 32) || (rows_out && !out_dev && h->rows.ensure((size_t)n * sizeof(adp_row)))) {
+        g_err = "device allocation failed"; return ADP_ERR_HIP;
+    }
+    while (h->ev_sync.size() < (size_t)G * 3) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_sync.push_back(e);
+    }
+    adp_handle *lanes[ADP_MAX_LANES];
+    for (int i = 0; i < n_lanes; i++) {
+        int rc = lane_get(h, i, mb_per_group * minibatch, &lanes[i]);
+        if (rc) return rc;
+        lanes[i]->prof.clear(); lanes[i]->ev_used = 0;
+    }
+    adp_row *rows_dev = rows_out ? (out_dev ? rows_out : h->rows.as<adp_row>()) : nullptr;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        int rc = arena_begin(h);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev_start, h->stream));      // (inputs staged on this stream, arena counter zeroed)
+        for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamWaitEvent(lanes[i]->stream, h->ev_start, 0));
+        for (int g = 0; g < G; g++) {
+            adp_handle *l = lanes[g % n_lanes];
+            const int mb0 = g * mb_per_group, r0 = mb0 * minibatch;
+            const int ng = (n - r0) < mb_per_group * minibatch ? (n - r0) : mb_per_group * minibatch;
+            PhaseSync ps;
+            for (int p = 0; p < 3; p++) {
+                ps.done[p] = h->ev_sync[(size_t)g * 3 + p];
+                if (g > 0 && (stagger >> p & 1)) ps.wait[p] = h->ev_sync[(size_t)(g - 1) * 3 + p];
+            }
+            rc = llr_enqueue(l, sig_from(dsig, (size_t)r0, m), dlen + r0, ng, m, minibatch, flags, rows_dev ? rows_dev + r0 : nullptr,
+                             hipMemcpyDeviceToDevice, h->mbstat.as<int32_t>() + mb0, h->mbparams.as<double>() + 4 * (size_t)mb0, 8, &ps);
+            if (rc) { for (int i = 0; i < n_lanes; i++) (void)hipStreamSynchronize(lanes[i]->stream); return rc; }
+        }
+        for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamSynchronize(lanes[i]->stream));
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
+    }
+    if (rows_out && !out_dev) HIPCHK(hipMemcpyAsync(rows_out, h->rows.p, (size_t)n * sizeof(adp_row), hipMemcpyDeviceToHost, h->stream));
+    if (mb_status) HIPCHK(hipMemcpyAsync(mb_status, h->mbstat.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+template <class SIG>
+static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int minibatch, int flags,
+                          adp_row *rows_out, int32_t *mb_status, int upto)
+{
+    const int n_mb = (n + minibatch - 1) / minibatch;
+    // grouped: the whole path, the minibatch layout, at least two minibatches
+    int want = env_int("ADP_GROUPS", 0), n_lanes = env_int("ADP_LANES", 2);
+    if (n_lanes < 1) n_lanes = 1;
+    if (n_lanes > ADP_MAX_LANES) n_lanes = ADP_MAX_LANES;
+    if (want <= 0) want = 3 * n_lanes;
+    if (upto == 8 && h->layout == ADP_LAYOUT_MINIBATCH && n_mb >= 2 && want > 1) {
+        int per = (n_mb + want - 1) / want;
+        if (per < 1) per = 1;
+        if ((n_mb + per - 1) / per < n_lanes) n_lanes = (n_mb + per - 1) / per;
+        return llr_grouped(h, dsig, dlen, n, m, minibatch, flags, rows_out, mb_status, per, n_lanes);
+    }
+    h->last_grouped = false;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        int rc = arena_begin(h);
+        if (rc) return rc;
+        rc = llr_enqueue(h, dsig, dlen, n, m, minibatch, flags, upto >= 8 ? rows_out : nullptr,
+                         (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, nullptr, nullptr, upto, nullptr);
+        if (rc) return rc;
+        if (mb_status) {
+            // through a small device buffer -> host
+            hipLaunchKernelGGL(k_mb_status_out, dim3((n_mb + 255) / 256), dim3(256), 0, h->stream, h->mbs.as<MbState>(), n_mb, h->gbelow.as<int32_t>());
+            HIPCHK(hipMemcpyAsync(mb_status, h->gbelow.p, (size_t)n_mb * 4, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (upto < 8) break;
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
+    }
     return ADP_OK;
 }
 
@@ -647,6 +820,7 @@ static int llr_pipeline(adp_handle *h, const float *signals, const int32_t *full
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear();
     h->ev_used = 0;
+    h->last_grouped = false;
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
     if (rc) return rc;
@@ -662,7 +836,6 @@ int adp_set_layout(adp_handle *h, int layout)
     const int old = h->layout;
     h->layout = layout;
     int rc = geom(h);
-    if (!rc && alloc_all(h)) { g_err = "device allocation failed"; rc = ADP_ERR_HIP; }
     if (rc) { h->layout = old; (void)geom(h); }
     return rc;
 }
@@ -684,6 +857,7 @@ int adp_detect_llr_i16(adp_handle *h, const int16_t *raw, const int32_t *full_le
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear();
     h->ev_used = 0;
+    h->last_grouped = false;
     // (samples at or beyond min(full_len, m) read as NaN: the padding is implied, so the passes always stop at a read's end)
     return llr_pipeline_t(h, SigI16{raw, scale, offset, full_len}, full_len, n_reads, m, minibatch, flags | ADP_TAILS_NAN, rows_out, mb_status, 8);
 }
@@ -718,7 +892,7 @@ int adp_c_llr_trace(adp_handle *h, const double *raw, const int32_t *len, const 
     for (int r = 0; r < n_reads; r++)
         if (len[r] < 0 || len[r] > L || start[r] < 0 || start[r] > end[r] || end[r] > len[r]) { g_err = "need 0 <= start <= end <= len <= L for every read"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const size_t row = (size_t)L * 8, mat = row * n_reads;
     // device staging: [raw | c | c2 | gain] as far as the caller's arrays are host memory
     const int need = (in_dev ? 0 : (from_sums ? 2 : 1)) + ((!from_sums && (!c_io || !out_dev)) ? 2 : 0) + (out_dev ? 0 : 1);
@@ -820,32 +994,43 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
     if (!h || !signals || !full_len || n_reads < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    // the pandas float-column quirk couples the reads of ONE minibatch: process minibatch by minibatch
-    for (int s0 = 0; s0 < n_reads; s0 += minibatch) {
-        int n = n_reads - s0 < minibatch ? n_reads - s0 : minibatch;
-        const float *sg = dsig + (size_t)s0 * m;
-        const int32_t *ln = dlen + s0;
-        HIPCHK(hipMemsetAsync(h->any_none.p, 0, 4, st));
-        { Scope s(h, "k_start_peak");
-          hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{sg}, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
-        hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
-                           h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
-        rc = launch_validate(h, SigF32{sg}, ln, n, m, 1, minibatch, false);
+    rc = alloc_all(h, n_reads < minibatch ? n_reads : minibatch, false);
+    if (rc) return rc;
+    // the pandas float-column quirk couples the reads of ONE minibatch: process minibatch by minibatch (one arena for the
+    // whole call: the offsets in the rows of every minibatch stay valid until the next call)
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = arena_begin(h);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 1,
-                           h->any_none.as<int32_t>());
-        if (rows_out) {
-            HIPCHK(hipMemcpyAsync(rows_out + s0, h->rows.p, (size_t)n * sizeof(adp_row),
-                                  (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+        for (int s0 = 0; s0 < n_reads; s0 += minibatch) {
+            int n = n_reads - s0 < minibatch ? n_reads - s0 : minibatch;
+            const float *sg = dsig + (size_t)s0 * m;
+            const int32_t *ln = dlen + s0;
+            HIPCHK(hipMemsetAsync(h->any_none.p, 0, 4, st));
+            { Scope s(h, "k_start_peak");
+              hipLaunchKernelGGL(k_start_peak<SigF32>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, SigF32{sg}, ln, n, m, h->cfg, h->sp.as<SpOut>()); }
+            hipLaunchKernelGGL(k_sp_bounds, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), n, h->bounds.as<int64_t>(),
+                               h->topk_none.as<int8_t>(), h->any_none.as<int32_t>());
+            rc = launch_validate(h, SigF32{sg}, ln, n, m, 1, minibatch, false);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_sp_decorate, dim3((n + 255) / 256), dim3(256), 0, st, h->sp.as<SpOut>(), h->rows.as<adp_row>(), n, 1,
+                               h->any_none.as<int32_t>());
+            if (rows_out) {
+                HIPCHK(hipMemcpyAsync(rows_out + s0, h->rows.p, (size_t)n * sizeof(adp_row),
+                                      (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+            }
+            HIPCHK(hipStreamSynchronize(st));
         }
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipGetLastError());
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     }
-    HIPCHK(hipGetLastError());
     return ADP_OK;
 }
 
@@ -855,20 +1040,30 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
     if (!h || !signals || !full_len || !bounds || n_reads < 1 || k < 1 || k > ADP_MAX_CAND) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
     if (rc) return rc;
     hipStream_t st = h->stream;
-    HIPCHK(hipMemcpyAsync(h->bounds.p, bounds, (size_t)n_reads * (1 + k) * 8,
-                          ((flags & ADP_IN_DEVICE) && !(flags & ADP_BOUNDS_HOST)) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(h->topk_none.p, (flags & ADP_TOPK_NONE) ? 1 : 0, (size_t)n_reads, st));
-    rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, k, n_reads, false);
+    rc = alloc_all(h, n_reads, false);
     if (rc) return rc;
-    rc = deliver_rows(h, n_reads, flags, rows_out);
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = arena_begin(h);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h->bounds.p, bounds, (size_t)n_reads * (1 + k) * 8,
+                              ((flags & ADP_IN_DEVICE) && !(flags & ADP_BOUNDS_HOST)) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(h->topk_none.p, (flags & ADP_TOPK_NONE) ? 1 : 0, (size_t)n_reads, st));
+        rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, k, n_reads, false);
+        if (rc) return rc;
+        rc = deliver_rows(h, n_reads, flags, rows_out);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
+    }
     return ADP_OK;
 }
 
@@ -898,7 +1093,7 @@ int adp_cnn_topk(adp_handle *h, const float *scores_dev, const int64_t *adapter_
     if (!h || !scores_dev || !adapter_pos_dev || !polya_pos_dev || !cand_out || !n_peaks_out || n_reads < 1 || Lo < 3 ||
         k < 1 || k > ADP_MAX_CAND) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     int rc = cnn_topk_dev(h, scores_dev, (const long long *)adapter_pos_dev, (const long long *)polya_pos_dev, n_reads, n_reads, Lo, k);
     if (rc) return rc;
     hipStream_t st = h->stream;
@@ -917,7 +1112,7 @@ static int cnn_predict_dev(adp_handle *h, const float *scores, int n, int mbsize
     const int k = c.polya_cand_k, kk = k < 1 ? 1 : k;
     if (k > ADP_MAX_CAND) { g_err = "polya_cand_k too large"; return ADP_ERR_UNSUPPORTED; }
     if (n > h->max_reads) { g_err = "n_reads exceeds the handle's capacity"; return ADP_ERR_CAPACITY; }
-    if (h->ct_ap.ensure((size_t)n * 16)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    if (h->ct_ap.ensure((size_t)n * 16) || h->bounds.ensure((size_t)n * (1 + ADP_MAX_CAND) * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     long long *dap = h->ct_ap.as<long long>(), *dpp = dap + n;
     const int na = (c.max_obs_adapter - c.min_obs_adapter) / c.downscale_factor;
     hipStream_t st = h->stream;
@@ -940,7 +1135,7 @@ int adp_cnn_predict(adp_handle *h, const float *scores_dev, int n_reads, int min
 {
     if (!h || !scores_dev || !bounds_out || n_reads < 1 || minibatch < 1 || Lo < 3) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     int kk = 1;
     int rc = cnn_predict_dev(h, scores_dev, n_reads, minibatch, Lo, &kk);
     if (rc) return rc;
@@ -955,7 +1150,7 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
     if (!h || !signals || !prepared_out || n_reads < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (m != h->m) { g_err = "m differs from the handle's"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
     if (m <= off) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
     const int Lc = (m - off + ds - 1) / ds;
@@ -1068,7 +1263,7 @@ int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, f
 {
     if (!h || !prepared || !scores_out || n_reads < 1 || Lc < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     int rc = cnn_forward_dev(h, prepared, n_reads, Lc, scores_out);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -1084,7 +1279,7 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     if (!h || !signals || !full_len || n_reads < 1 || minibatch < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
     if (m <= off) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
     const float *dsig; const int32_t *dlen;
@@ -1093,21 +1288,31 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     const int Lc = (m - off + ds - 1) / ds, L1 = (Lc - 1) / 3 + 1, Lo = 3 * L1 - 2;
     if (h->cnn_x.ensure((size_t)n_reads * Lc * 4) || h->cnn_sc.ensure((size_t)n_reads * 2 * Lo * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     hipStream_t st = h->stream;
-    { Scope s(h, "k_cnn_prepare");
-      hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, st, dsig, n_reads, m, off, ds, Lc, h->cnn_x.as<float>()); }
-    rc = cnn_forward_dev(h, h->cnn_x.as<float>(), n_reads, Lc, h->cnn_sc.as<float>());
+    rc = alloc_all(h, n_reads, false);
     if (rc) return rc;
-    int kk = 1;
-    rc = cnn_predict_dev(h, h->cnn_sc.as<float>(), n_reads, minibatch, Lo, &kk);
-    if (rc) return rc;
-    if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
-    rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, kk, n_reads, false);
-    if (rc) return rc;
-    rc = deliver_rows(h, n_reads, flags, rows_out);
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    for (int attempt = 0; attempt < 3; attempt++) {
+        rc = arena_begin(h);
+        if (rc) return rc;
+        { Scope s(h, "k_cnn_prepare");
+          hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, st, dsig, n_reads, m, off, ds, Lc, h->cnn_x.as<float>()); }
+        rc = cnn_forward_dev(h, h->cnn_x.as<float>(), n_reads, Lc, h->cnn_sc.as<float>());
+        if (rc) return rc;
+        int kk = 1;
+        rc = cnn_predict_dev(h, h->cnn_sc.as<float>(), n_reads, minibatch, Lo, &kk);
+        if (rc) return rc;
+        if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
+        rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, kk, n_reads, false);
+        if (rc) return rc;
+        rc = deliver_rows(h, n_reads, flags, rows_out);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
+    }
     return ADP_OK;
 }
 
@@ -1130,11 +1335,13 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     if (!h || !signals || !full_len || !ranges || !polya_out || !status_out || n < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     if (n > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
-    h->prof.clear(); h->ev_used = 0;
+    h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n, m, flags, &dsig, &dlen);
     if (rc) return rc;
     hipStream_t st = h->stream;
+    rc = alloc_all(h, n, true);
+    if (rc) return rc;
     if (h->mbs.ensure((size_t)n * sizeof(MbState)) || h->ghist.ensure((size_t)n * N1_BINS * 4) || h->gbelow.ensure((size_t)n * 8) || h->gcnt.ensure((size_t)n * 8 * N1_NCNT) ||
         h->bounds_stage.ensure((size_t)n * 16 + (size_t)n * 12)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     int64_t *drng = h->bounds_stage.as<int64_t>();
@@ -1324,14 +1531,19 @@ int adp_kernel_times(adp_handle *h, const char **names_out, float *ms_out, int c
     if (!h) return ADP_ERR_INVALID;
     HIPCHK(hipSetDevice(h->device));
     int k = 0;
-    for (const ProfEntry &e : h->prof) {
-        if (k >= cap) break;
-        float ms = 0.f;
-        HIPCHK(hipEventSynchronize(e.b));
-        HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-        names_out[k] = e.name;
-        ms_out[k] = ms;
-        k++;
+    const adp_handle *src[1 + ADP_MAX_LANES] = {h};
+    int ns = 1;
+    if (h->last_grouped) for (int i = 0; i < ADP_MAX_LANES; i++) if (h->lane[i]) src[ns++] = h->lane[i];
+    for (int q = 0; q < ns; q++) {
+        for (const ProfEntry &e : src[q]->prof) {
+            if (k >= cap) break;
+            float ms = 0.f;
+            HIPCHK(hipEventSynchronize(e.b));
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            names_out[k] = e.name;
+            ms_out[k] = ms;
+            k++;
+        }
     }
     return k;
 }
@@ -1343,6 +1555,12 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     const void *src = nullptr;
     switch (what) {
     case 0: {
+        if (h->last_grouped) {
+            if (bytes > (uint64_t)h->last_nmb * 32) return ADP_ERR_INVALID;
+            HIPCHK(hipMemcpyAsync(host_out, h->mbparams.p, bytes, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            return ADP_OK;
+        }
         if (h->ghist.cap < (size_t)h->last_nmb * 32) return ADP_ERR_INVALID;
         hipLaunchKernelGGL(k_mb_params_out, dim3((h->last_nmb + 255) / 256), dim3(256), 0, h->stream, h->mbs.as<MbState>(),
                            h->last_nmb, h->ghist.as<double>());

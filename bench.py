@@ -494,7 +494,8 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                     "BASELINE configs[2]: RNA004 CNN head (hand-written float32 MFMA conv stack) + predict + validate") +
                                    ", max_obs_trace=%d (m=%d), minibatch=%d, %d reads/step/GPU resident in HBM"
                                    % (w.max_obs_trace, m, mb, R),
-                       "reads_per_step_per_gpu": R, "minibatch": mb, "m": m, "pass_rate": n_ok / R, "streams_per_gpu": NS},
+                       "reads_per_step_per_gpu": R, "minibatch": mb, "m": m, "pass_rate": n_ok / R, "streams_per_gpu": NS,
+                       "grouping": {k: os.environ.get(k) for k in ("ADP_GROUPS", "ADP_LANES", "ADP_STAGGER") if os.environ.get(k)} or "default (groups over 2 lanes)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (traffic.get(dom, {}).get("hbm_bytes") * (Rs / traffic["_reads_per_launch"])
@@ -687,19 +688,28 @@ def main():
         # the other single-GPU configurations of BASELINE.json, driver-run with the headline (each its own roofline)
         sec = {}
         # (cnn_200k at 8000 reads per step: the moving-window series of the candidate validation is a sequential float32
-        # recurrence per read, ~11 ms per call whatever the number of reads; two_streams: the headline with two engines per
-        # GPU, each on its own HIP stream with half of the minibatches -- the ALU-bound gains of one overlap the streaming
-        # passes of the other; the headline itself stays on one stream so that a launch has the GPU to itself for the roofline)
+        # recurrence per read, ~11 ms per call whatever the number of reads)
         for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=8000, steps=3, warmup=1)),
                          ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
                          ("pareto", dict(lens="pareto", steps=4, warmup=1)),
                          ("int16", dict(int16=True, steps=4, warmup=1)),
-                         ("two_streams", dict(streams=2, steps=4, warmup=1))):
+                         # the headline with its phases one after another on one stream (ADP_GROUPS=1): what the software
+                         # pipelining inside adp_detect_llr buys, and every kernel's duration with the GPU to itself
+                         ("serial", dict(env={"ADP_GROUPS": "1"}, steps=4, warmup=1))):
             w = argparse.Namespace(**vars(args))
             w.cpu_sample = 0
+            env = kw.pop("env", {})
             for k, v in kw.items():
                 setattr(w, k, v)
-            o = run_workload(w, 0, 1, local, None, backend)
+            saved = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                o = run_workload(w, 0, 1, local, None, backend)
+            finally:
+                for k, v in saved.items():
+                    os.environ.pop(k, None)
+                    if v is not None:
+                        os.environ[k] = v
             sec[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "kernel_ms")}
         out["secondary"] = sec
     if rank == 0:

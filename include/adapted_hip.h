@@ -13,16 +13,22 @@
  *                              c_llr_trace :202-236, c_llr_trace_gains :176-199, _gains :67-88
  *   adp_detect_start_peak   <- combined_detect_start_peak(...)   adapted/detect/combined.py:312-355
  *                              (detect_rna_start_peak, adapted/detect/start_peak.py:7-119)
+ *   adp_detect_cnn          <- combined_detect_cnn(...)          adapted/detect/combined.py:230-250 (up to its short-read
+ *                              fallback :251-301 = adp_llr_refine_polya + adp_validate_candidates)
  *   adp_cnn_prepare         <- prepare_data(...)                 adapted/detect/cnn.py:70-82
+ *   adp_cnn_forward         <- BoundariesCNN.forward / cnn_score adapted/detect/cnn.py:16-52, 85-98 (hand-written float32
+ *                              MFMA conv stack, adapted_amd/csrc/cnn_conv.h; PyTorch is not involved)
+ *   adp_cnn_predict         <- cnn_predict + cnn_detect scaling  adapted/detect/cnn.py:101-182
  *   adp_validate_candidates <- the validate_boundaries loop of combined_detect_cnn
- *                              adapted/detect/combined.py:243-305 (the conv net itself runs
- *                              in PyTorch-ROCm, as BASELINE.json:north_star prescribes)
+ *                              adapted/detect/combined.py:243-305
  *   adp_cfg                 <- SigProcConfig                     adapted/config/sig_proc.py:161-221
  *   adp_row                 <- DetectResults                     adapted/container_types.py:23-92
  *
  * Conventions: plain C, caller-allocated outputs, no exceptions.  Every function returns 0
- * or a negative ADP_ERR_* code.  A handle owns one device, one HIP stream and its workspace;
- * it is not thread-safe, distinct handles are independent.  `signals` is the reference's
+ * or a negative ADP_ERR_* code.  A handle owns one device, its HIP streams and its workspace
+ * (allocated by the first call that needs it, for the reads of that call, and kept: a call may
+ * therefore return ADP_ERR_HIP for an allocation that adp_create did not attempt); it is not
+ * thread-safe, distinct handles are independent.  Every call returns with its work finished.  `signals` is the reference's
  * minibatch layout (adapted/file_proc.py:143-190): row-major float32 [n_reads, m], NaN from
  * each read's end to m; full_len[i] is the read's true length (may exceed m).  A call may
  * carry several minibatches: reads [k*minibatch, (k+1)*minibatch) form minibatch k, and the
@@ -165,13 +171,21 @@ int adp_set_config(adp_handle *h, const adp_cfg *cfg);
 #define ADP_LAYOUT_MINIBATCH 0
 #define ADP_LAYOUT_SINGLE_READ 1
 int adp_set_layout(adp_handle *h, int layout);
-/* The handle's HIP stream (hipStream_t as void*); all work of a call is ordered on it. */
+/* The handle's main HIP stream (hipStream_t as void*): staging copies, single-group calls and the non-LLR entry points are
+ * ordered on it; asynchronous helpers (adp_calibrate_i16, adp_expand_ragged*) enqueue on it and a following detect call is
+ * ordered behind them. */
 void *adp_stream(adp_handle *h);
 int adp_synchronize(adp_handle *h);
 
 /* LLR primary + validation (+ optional start-peak columns) over n_reads reads.
  * rows_out: adp_row[n_reads]; mb_status: int32[ceil(n_reads/minibatch)] (host, may be NULL).
- * Rows of a dropped minibatch are zeroed with fail_code = 0 and success = 0. */
+ * Rows of a dropped minibatch are zeroed with fail_code = 0 and success = 0.
+ * A call that carries two or more minibatches is cut into groups of whole minibatches that run software-pipelined over
+ * two internal streams ("lanes": while one group streams the signal for its normalisation, pooling or partition
+ * statistics, its neighbour runs the float64 gains and the peak picking on its pooled trace); minibatches are independent
+ * of each other, so the rows are the same bytes whatever the grouping.  Environment (developer switches): ADP_GROUPS=1
+ * runs the phases one after another on one stream, ADP_GROUPS=k aims at k groups, ADP_LANES=n uses n streams (<= 4),
+ * ADP_STAGGER=bits orders phase p (bit p: 0 streaming-in, 1 gains, 2 validation) of consecutive groups. */
 int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                    int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
 
@@ -189,7 +203,7 @@ int adp_detect_llr_i16(adp_handle *h, const int16_t *raw, const int32_t *full_le
 int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads,
                           int m, int minibatch, int flags, adp_row *rows_out);
 
-/* CNN head, device-side pre/post-processing around the PyTorch conv stack.
+/* CNN head, C1: the network's input.
  * prepared_out: float32 [n_reads, Lc] with Lc = ceil((m - min_obs_adapter)/downscale_factor). */
 int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out);
 /* C2, the conv net itself (BoundariesCNN adapted/detect/cnn.py:16-52; cnn_score :85-98), hand-written for gfx950
@@ -232,8 +246,10 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
 
 /* The open-pore arena of the LAST detect / validate call on this handle: find_open_pores (adapted/detect/anomalies.py:15-35)
  * returns a list without a length limit, and the CSV prints all of it; rows with more than ADP_MAX_OPEN_PORES entries keep
- * their whole list here (row.open_pores_more = offset, row.n_open_pores = length).  Copies min(used, cap) int32 entries to
- * the HOST buffer `out` and the number in use to *used (the arena grows by itself; a call never loses entries). */
+ * their whole list here (row.open_pores_more = offset, row.n_open_pores = length).  ONE arena per API call, whatever the
+ * number of minibatches (or internal groups) the call carries: the offsets of all its rows index the same array.  Copies
+ * min(used, cap) int32 entries to the HOST buffer `out` and the number in use to *used (a call that finds the arena too
+ * small grows it and runs again before it returns: a call never loses entries). */
 int adp_open_pores_arena(adp_handle *h, int32_t *out, uint64_t cap, uint64_t *used);
 
 /* Synthetic squiggles generated on the device (bit-identical to adapted_amd/synth.py).

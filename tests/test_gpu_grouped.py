@@ -1,0 +1,112 @@
+"""Grouped (software-pipelined) execution of adp_detect_llr: a call with several minibatches is cut into groups that run
+over two or more internal streams, phases of neighbouring groups overlapping.  Minibatches are independent (N1 couples only
+the reads of one minibatch: reference adapted/detect/normalize.py:15-22 as called at combined.py:128-132), so rows must be the
+same BYTES for every grouping, lane count and phase ordering, equal to the one-stream serial pipeline and to the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_scale import _rows_equal, _spc200k
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [{"ADP_GROUPS": "1"}, {}, {"ADP_GROUPS": "2"}, {"ADP_GROUPS": "6", "ADP_LANES": "3"}, {"ADP_STAGGER": "7"},
+         {"ADP_STAGGER": "0", "ADP_LANES": "4", "ADP_GROUPS": "12"}, {"ADP_LANES": "1", "ADP_GROUPS": "3"}]
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in ("ADP_GROUPS", "ADP_LANES", "ADP_STAGGER")}
+    try:
+        for k in old:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        return fn()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _canon(rows, lib):
+    """rows with the overflow lists resolved and the registry tokens blanked: comparable across calls"""
+    lists = {int(i): lib._OPEN_PORES_MORE[int(rows[i]["open_pores_more"])].tolist() for i in np.flatnonzero(rows["n_open_pores"] > lib.MAX_OPEN_PORES)}
+    r = rows.copy()
+    r["open_pores_more"] = 0
+    return r.tobytes(), lists
+
+
+def test_grouped_rows_equal_serial_rows_and_the_oracle(oracle_mod):
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m = spc.sig_preload_size
+    mb, n_mb = 32, 7                                  # 7 minibatches: groups of unequal size, a ragged last one
+    n = mb * n_mb - 5
+    lens = np.array([m if i % 3 else max(1200, synth.pareto_length(5, i, lo=1200, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(71, 0, n, m, lens)
+    for r in (4, 40, 100, 200):                       # open_pores lists beyond a row's 16 entries, in different groups
+        for j in range(20 + r % 7):
+            sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
+    sig[3 * mb: 4 * mb] = 80.0                        # minibatch 3: MAD == 0, dropped (status 1); its neighbours are untouched
+    eng = lib.Engine(spc, n, m, device=0)
+    ref = None
+    for env in KNOBS:
+        rows, mbs = _with_env(env, lambda: eng.detect_llr_rows(sig, lens, n, mb, with_start_peak=True))
+        assert list(mbs) == [0, 0, 0, 1, 0, 0, 0], (env, mbs)
+        cur = _canon(rows, lib)
+        if ref is None:
+            ref, ref_rows = cur, rows
+        assert cur[0] == ref[0] and cur[1] == ref[1], env
+        assert sorted(cur[1]) == [4, 40, 200], cur[1].keys()   # (read 100 sits in the dropped minibatch)
+        # N1 parameters of every minibatch travel back through the grouped call as well
+        prm = eng.debug_norm_params(n_mb)
+        if env == KNOBS[0]:
+            prm0 = prm.copy()
+        keep = [k for k in range(n_mb) if k != 3]
+        assert np.array_equal(prm[keep], prm0[keep]), env
+    # per-kernel times of a grouped call: every group's launches are reported
+    eng.set_profiling(True)
+    _with_env({"ADP_GROUPS": "4"}, lambda: eng.detect_llr_rows(sig, lens, n, mb, with_start_peak=True))
+    names = [k for k, _ in eng.kernel_times()]
+    eng.set_profiling(False)
+    assert names.count("k_partition_stats") == 4 and names.count("k_gains<1>") == 4, names
+    # and the oracle, minibatch by minibatch
+    got = lib.rows_to_results(ref_rows, "llr")
+    for k in (0, 2, 6):
+        a, b = k * mb, min(n, (k + 1) * mb)
+        want = oracle_mod.detect_llr(sig[a:b], lens[a:b], spc, with_start_peak=True)
+        assert not _rows_equal(got[a:b], want), (k, _rows_equal(got[a:b], want)[:6])
+    eng.close()
+
+
+def test_grouped_equals_serial_at_the_200k_window_on_device_rows():
+    """the headline shape: device-resident input, rows delivered to a device buffer (bench.py's call), int16 twin included"""
+    from adapted_amd import lib
+
+    spc = _spc200k()
+    m = spc.sig_preload_size
+    mb, n = 250, 1500
+    eng = lib.Engine(spc, n, m, device=0)
+    dsig, dlen, drows = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4), eng.dev_alloc(n * lib.ROW_DTYPE.itemsize)
+    eng.h2d(dlen, np.full(n, m, dtype=np.int32))
+    eng.synth_fill(dsig, dlen, n, seed=21, first_read=7000)
+    out = []
+    for env in ({"ADP_GROUPS": "1"}, {}, {"ADP_LANES": "3"}):
+        _, mbs = _with_env(env, lambda: eng.detect_llr_rows(dsig, dlen, n, mb, with_start_peak=True, device_ptrs=True, rows_dev=drows, tails_nan=True))
+        assert (mbs == 0).all()
+        rows = np.zeros(n, dtype=lib.ROW_DTYPE)
+        eng.d2h(rows, drows)
+        rows["open_pores_more"] = 0
+        out.append(rows.tobytes())
+    assert out[0] == out[1] == out[2]
+    rows = np.frombuffer(out[0], dtype=lib.ROW_DTYPE)
+    assert rows["success"].mean() > 0.8
+    for p in (dsig, dlen, drows):
+        eng.dev_free(p)
+    eng.close()
