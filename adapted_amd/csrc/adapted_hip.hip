@@ -693,9 +693,10 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
     return ADP_OK;
 }
 
-// how a call's minibatches are cut into groups: ADP_GROUPS (0 / unset: automatic, 1: one group = the plain serial pipeline, k: aim at
-// k groups); ADP_LANES (streams the groups rotate over, default 2); ADP_STAGGER (bit p set: phase p of group g + 1 starts
-// after phase p of group g; default 1 = the streaming S phases take turns, which keeps neighbouring groups one phase apart)
+// how a call's minibatches are cut into groups: ADP_GROUPS (unset / 1: one group = the plain serial pipeline, 0: automatic = three
+// groups per lane, k: aim at k groups); ADP_LANES (streams the groups rotate over, default 2); ADP_STAGGER (bit p set: phase p of
+// group g + 1 starts after phase p of group g; default 1 = the streaming S phases take turns, which keeps neighbouring groups one
+// phase apart)
 static int env_int(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -777,8 +778,12 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
                           adp_row *rows_out, int32_t *mb_status, int upto)
 {
     const int n_mb = (n + minibatch - 1) / minibatch;
-    // grouped: the whole path, the minibatch layout, at least two minibatches
-    int want = env_int("ADP_GROUPS", 0), n_lanes = env_int("ADP_LANES", 2);
+    // grouped execution is OPT-IN (ADP_GROUPS > 1): measured on MI355X, overlapping the float64 gains of one group with the
+    // streaming passes of its neighbour buys nothing (+-1.5 %, profiles/r03_overlap_*: the kernels do run side by side -- two or
+    // more resident for 82 % of the busy time -- and stretch each other by the same factor; even a PURE read beside a PURE
+    // float64 FMA kernel reaches only 0.81-0.88 of the serial time on this chip), while one launch over all reads of the
+    // call has the shortest tails.  What grouping does buy is memory: the lanes' workspace is sized for one group.
+    int want = env_int("ADP_GROUPS", 1), n_lanes = env_int("ADP_LANES", 2);
     if (n_lanes < 1) n_lanes = 1;
     if (n_lanes > ADP_MAX_LANES) n_lanes = ADP_MAX_LANES;
     if (want <= 0) want = 3 * n_lanes;

@@ -354,7 +354,7 @@ class Engine:
         self._check(self.lib.adp_set_profiling(self._h, int(on)))
 
     def kernel_times(self):
-        cap = 64
+        cap = 4096  # (a grouped call reports every group's launches)
         names = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         k = self._check(self.lib.adp_kernel_times(self._h, names, ms, cap))

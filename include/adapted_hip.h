@@ -180,12 +180,13 @@ int adp_synchronize(adp_handle *h);
 /* LLR primary + validation (+ optional start-peak columns) over n_reads reads.
  * rows_out: adp_row[n_reads]; mb_status: int32[ceil(n_reads/minibatch)] (host, may be NULL).
  * Rows of a dropped minibatch are zeroed with fail_code = 0 and success = 0.
- * A call that carries two or more minibatches is cut into groups of whole minibatches that run software-pipelined over
- * two internal streams ("lanes": while one group streams the signal for its normalisation, pooling or partition
- * statistics, its neighbour runs the float64 gains and the peak picking on its pooled trace); minibatches are independent
- * of each other, so the rows are the same bytes whatever the grouping.  Environment (developer switches): ADP_GROUPS=1
- * runs the phases one after another on one stream, ADP_GROUPS=k aims at k groups, ADP_LANES=n uses n streams (<= 4),
- * ADP_STAGGER=bits orders phase p (bit p: 0 streaming-in, 1 gains, 2 validation) of consecutive groups. */
+ * Optional grouped execution (environment, read per call): ADP_GROUPS=k (k > 1; 0 = automatic) cuts a call that carries two or
+ * more minibatches into about k groups of whole minibatches that run software-pipelined over ADP_LANES (default 2, <= 4)
+ * internal streams, each with a workspace for ONE group -- while one group streams the signal for its normalisation, pooling
+ * or partition statistics, its neighbour runs the float64 gains and the peak picking on its pooled trace; ADP_STAGGER=bits
+ * orders phase p (bit 0 streaming-in, 1 gains, 2 validation) of consecutive groups.  Minibatches are independent of each
+ * other, so the rows are the same bytes whatever the grouping (tests/test_gpu_grouped.py).  The default is one group: on
+ * MI355X the overlap buys no time (profiles/r03_overlap_*), a smaller workspace is what grouping is for. */
 int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                    int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
 

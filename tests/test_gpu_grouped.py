@@ -11,7 +11,7 @@ from test_gpu_scale import _rows_equal, _spc200k
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = [{"ADP_GROUPS": "1"}, {}, {"ADP_GROUPS": "2"}, {"ADP_GROUPS": "6", "ADP_LANES": "3"}, {"ADP_STAGGER": "7"},
+KNOBS = [{"ADP_GROUPS": "1"}, {"ADP_GROUPS": "0"}, {"ADP_GROUPS": "2"}, {"ADP_GROUPS": "6", "ADP_LANES": "3"}, {"ADP_STAGGER": "7"},
          {"ADP_STAGGER": "0", "ADP_LANES": "4", "ADP_GROUPS": "12"}, {"ADP_LANES": "1", "ADP_GROUPS": "3"}]
 
 
@@ -97,7 +97,7 @@ def test_grouped_equals_serial_at_the_200k_window_on_device_rows():
     eng.h2d(dlen, np.full(n, m, dtype=np.int32))
     eng.synth_fill(dsig, dlen, n, seed=21, first_read=7000)
     out = []
-    for env in ({"ADP_GROUPS": "1"}, {}, {"ADP_LANES": "3"}):
+    for env in ({}, {"ADP_GROUPS": "0"}, {"ADP_GROUPS": "5", "ADP_LANES": "3"}):
         _, mbs = _with_env(env, lambda: eng.detect_llr_rows(dsig, dlen, n, mb, with_start_peak=True, device_ptrs=True, rows_dev=drows, tails_nan=True))
         assert (mbs == 0).all()
         rows = np.zeros(n, dtype=lib.ROW_DTYPE)
