@@ -1150,6 +1150,19 @@ int adp_cnn_predict(adp_handle *h, const float *scores_dev, int n_reads, int min
     return ADP_OK;
 }
 
+// C1 on the handle's stream: pooled values (k_cnn_pool), then their per-read median / MAD scaling in place (k_cnn_prepare)
+static int launch_cnn_prepare(adp_handle *h, const float *dsig, int n_reads, int m, int off, int ds, int Lc, float *dout)
+{
+    if (h->npk.ensure((size_t)n_reads * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; } // (npk: unused on this path)
+    int32_t *nan_cnt = h->npk.as<int32_t>();
+    HIPCHK(hipMemsetAsync(nan_cnt, 0, (size_t)n_reads * 4, h->stream));
+    { Scope s(h, "k_cnn_pool");
+      hipLaunchKernelGGL(k_cnn_pool, dim3(n_reads), dim3(256), (size_t)4 * 64 * ds * 4, h->stream, dsig, n_reads, m, off, ds, Lc, dout, nan_cnt); }
+    { Scope s(h, "k_cnn_prepare");
+      hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, h->stream, n_reads, Lc, dout, (const int32_t *)nan_cnt); }
+    return 0;
+}
+
 int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int flags, float *prepared_out)
 {
     if (!h || !signals || !prepared_out || n_reads < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
@@ -1170,8 +1183,7 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
         if (h->bounds_stage.ensure((size_t)n_reads * Lc * 4)) { g_err = "staging allocation failed"; return ADP_ERR_HIP; }
         dout = h->bounds_stage.as<float>();
     }
-    { Scope s(h, "k_cnn_prepare");
-      hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, h->stream, dsig, n_reads, m, off, ds, Lc, dout); }
+    { int rc2 = launch_cnn_prepare(h, dsig, n_reads, m, off, ds, Lc, dout); if (rc2) return rc2; }
     if (!(flags & ADP_OUT_DEVICE))
         HIPCHK(hipMemcpyAsync(prepared_out, dout, (size_t)n_reads * Lc * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipGetLastError());
@@ -1224,7 +1236,8 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 // the conv stack over device buffers, asynchronous on the handle's stream
 static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
 {
-    if (!h->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
+    adp_handle *wh = h->owner ? h->owner : h; // (a lane runs with its parent's weights)
+    if (!wh->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
     const int L1 = (Lc + 2 * 3 - CNN_K) / 3 + 1, Lo = (L1 - 1) * 3 - 2 * 3 + CNN_K;
     // positions per workgroup step: the NT (32-position tiles per wave) that wastes least of the last step
     int NT = 4; { long long best = -1; for (int nt = 4; nt >= 2; nt--) { const long long pb = 64 * nt, cover = (L1 + pb - 1) / pb * pb; if (best < 0 || cover < best) { best = cover; NT = nt; } } }
@@ -1241,7 +1254,7 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
         h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read);
     }
     C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
-    const float *W = h->cnn_w.as<float>();
+    const float *W = wh->cnn_w.as<float>();
     float *A = h->cnn_act[0].as<float>(), *B = h->cnn_act[1].as<float>();
     for (int s0 = 0; s0 < n_reads; s0 += C) {
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
@@ -1276,8 +1289,84 @@ int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, f
     return ADP_OK;
 }
 
-// combined_detect_cnn up to (not including) the short-read fallback, in one call: C1 prepare -> C2 conv stack -> C3 predict
-// -> V1 with the k candidates.  bounds_out (host, may be NULL): int64 [n, 1 + max(k, 1)], what cnn_detect returns.
+// combined_detect_cnn up to (not including) the short-read fallback: C1 prepare -> C2 conv stack -> C3 predict -> V1 with the
+// k candidates, enqueued on the handle's stream without waiting for anything on the host.  bounds_dst (may be NULL): int64
+// [n, 1 + max(k, 1)] what cnn_detect returns, copied with bounds_kind.
+static int cnn_enqueue(adp_handle *h, const float *dsig, const int32_t *dlen, int n_reads, int m, int minibatch, adp_row *rows_dst,
+                       int rows_kind, int64_t *bounds_dst, int bounds_kind)
+{
+    const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
+    const int Lc = (m - off + ds - 1) / ds, L1 = (Lc - 1) / 3 + 1, Lo = 3 * L1 - 2;
+    if (h->cnn_x.ensure((size_t)n_reads * Lc * 4) || h->cnn_sc.ensure((size_t)n_reads * 2 * Lo * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    hipStream_t st = h->stream;
+    int rc = alloc_all(h, n_reads, false);
+    if (rc) return rc;
+    rc = launch_cnn_prepare(h, dsig, n_reads, m, off, ds, Lc, h->cnn_x.as<float>());
+    if (rc) return rc;
+    rc = cnn_forward_dev(h, h->cnn_x.as<float>(), n_reads, Lc, h->cnn_sc.as<float>());
+    if (rc) return rc;
+    int kk = 1;
+    rc = cnn_predict_dev(h, h->cnn_sc.as<float>(), n_reads, minibatch, Lo, &kk);
+    if (rc) return rc;
+    if (bounds_dst) HIPCHK(hipMemcpyAsync(bounds_dst, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, (hipMemcpyKind)bounds_kind, st));
+    HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
+    rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, kk, n_reads, false);
+    if (rc) return rc;
+    if (rows_dst) HIPCHK(hipMemcpyAsync(rows_dst, h->rows.p, (size_t)n_reads * sizeof(adp_row), (hipMemcpyKind)rows_kind, st));
+    HIPCHK(hipGetLastError());
+    return ADP_OK;
+}
+
+// Chunks of whole minibatches over two lanes, free-running: while one lane's chunk is in the conv stack (matrix cores, one
+// wave per SIMD, little HBM traffic), the other's is in the candidate validation -- the moving-window recurrences (latency of one
+// wave's instruction stream, ~11 ms per launch whatever the number of reads), the order-statistics sweeps (HBM), the partition
+// statistics.  Reads of different minibatches never interact on this path (find_peaks / row compaction are per minibatch).
+static int cnn_grouped(adp_handle *h, const float *dsig, const int32_t *dlen, int n, int m, int minibatch, int flags, adp_row *rows_out,
+                       int64_t *bounds_out, int mb_per_group, int n_lanes)
+{
+    const int n_mb = (n + minibatch - 1) / minibatch;
+    const int G = (n_mb + mb_per_group - 1) / mb_per_group;
+    const int k = h->cfg.polya_cand_k, kk = k < 1 ? 1 : k;
+    const bool out_dev = (flags & ADP_OUT_DEVICE) != 0;
+    h->last_n = n; h->last_nmb = n_mb; h->last_grouped = true;
+    if ((rows_out && !out_dev && h->rows.ensure((size_t)n * sizeof(adp_row))) || (bounds_out && h->bounds.ensure((size_t)n * (1 + ADP_MAX_CAND) * 8))) {
+        g_err = "device allocation failed"; return ADP_ERR_HIP;
+    }
+    adp_handle *lanes[ADP_MAX_LANES];
+    for (int i = 0; i < n_lanes; i++) {
+        int rc = lane_get(h, i, mb_per_group * minibatch, &lanes[i]);
+        if (rc) return rc;
+        lanes[i]->prof.clear(); lanes[i]->ev_used = 0;
+    }
+    adp_row *rows_dev = rows_out ? (out_dev ? rows_out : h->rows.as<adp_row>()) : nullptr;
+    int64_t *bounds_dev = bounds_out ? h->bounds.as<int64_t>() : nullptr;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        int rc = arena_begin(h);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(h->ev_start, h->stream));
+        for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamWaitEvent(lanes[i]->stream, h->ev_start, 0));
+        for (int g = 0; g < G; g++) {
+            adp_handle *l = lanes[g % n_lanes];
+            const int r0 = g * mb_per_group * minibatch;
+            const int ng = (n - r0) < mb_per_group * minibatch ? (n - r0) : mb_per_group * minibatch;
+            rc = cnn_enqueue(l, dsig + (size_t)r0 * m, dlen + r0, ng, m, minibatch, rows_dev ? rows_dev + r0 : nullptr, hipMemcpyDeviceToDevice,
+                             bounds_dev ? bounds_dev + (size_t)r0 * (1 + kk) : nullptr, hipMemcpyDeviceToDevice);
+            if (rc) { for (int i = 0; i < n_lanes; i++) (void)hipStreamSynchronize(lanes[i]->stream); return rc; }
+        }
+        for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamSynchronize(lanes[i]->stream));
+        rc = arena_end(h);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
+    }
+    if (rows_out && !out_dev) HIPCHK(hipMemcpyAsync(rows_out, h->rows.p, (size_t)n * sizeof(adp_row), hipMemcpyDeviceToHost, h->stream));
+    if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n * (1 + kk) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return ADP_OK;
+}
+
+// combined_detect_cnn up to its short-read fallback in one call.  bounds_out (host, may be NULL): int64 [n, 1 + max(k, 1)], what
+// cnn_detect returns.
 int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m, int minibatch, int flags,
                    adp_row *rows_out, int64_t *bounds_out)
 {
@@ -1285,34 +1374,38 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     if (n_reads > h->max_reads || m != h->m) { g_err = "n_reads/m exceed the handle's capacity"; return ADP_ERR_CAPACITY; }
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
-    const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
-    if (m <= off) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
+    if (m <= h->cfg.min_obs_adapter) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
+    if (!h->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
     if (rc) return rc;
-    const int Lc = (m - off + ds - 1) / ds, L1 = (Lc - 1) / 3 + 1, Lo = 3 * L1 - 2;
-    if (h->cnn_x.ensure((size_t)n_reads * Lc * 4) || h->cnn_sc.ensure((size_t)n_reads * 2 * Lo * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-    hipStream_t st = h->stream;
-    rc = alloc_all(h, n_reads, false);
-    if (rc) return rc;
+    // ADP_CNN_GROUPS: 1 = one chunk on one stream; 0 / unset = automatic (chunks of about a quarter of the call, at most what the
+    // conv stack's activation buffers hold, over two lanes); k = aim at k chunks
+    const int n_mb = (n_reads + minibatch - 1) / minibatch;
+    int want = env_int("ADP_CNN_GROUPS", 0), n_lanes = env_int("ADP_CNN_LANES", 2);
+    if (n_lanes < 1) n_lanes = 1;
+    if (n_lanes > ADP_MAX_LANES) n_lanes = ADP_MAX_LANES;
+    if (want <= 0) want = 4;
+    if (n_mb >= 2 && want > 1) {
+        int per = (n_mb + want - 1) / want;
+        // a chunk beyond the activation buffers' capacity would be cut again inside the conv stack: keep chunks below it
+        const int off = h->cfg.min_obs_adapter, ds = h->cfg.downscale_factor;
+        const int Lc = (m - off + ds - 1) / ds, L1 = (Lc - 1) / 3 + 1;
+        const size_t per_read = (size_t)CNN_C * ((size_t)L1 + 264) * 4;
+        long long cap_mb = (long long)(((size_t)4 << 30) / per_read) / minibatch;
+        if (cap_mb >= 1 && per > cap_mb) per = (int)cap_mb;
+        if (per < 1) per = 1;
+        const int G = (n_mb + per - 1) / per;
+        if (G < n_lanes) n_lanes = G;
+        if (G >= 2) return cnn_grouped(h, dsig, dlen, n_reads, m, minibatch, flags, rows_out, bounds_out, per, n_lanes);
+    }
     for (int attempt = 0; attempt < 3; attempt++) {
         rc = arena_begin(h);
         if (rc) return rc;
-        { Scope s(h, "k_cnn_prepare");
-          hipLaunchKernelGGL(k_cnn_prepare, dim3(n_reads), dim3(64), 0, st, dsig, n_reads, m, off, ds, Lc, h->cnn_x.as<float>()); }
-        rc = cnn_forward_dev(h, h->cnn_x.as<float>(), n_reads, Lc, h->cnn_sc.as<float>());
+        rc = cnn_enqueue(h, dsig, dlen, n_reads, m, minibatch, rows_out, (flags & ADP_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                         bounds_out, hipMemcpyDeviceToHost);
         if (rc) return rc;
-        int kk = 1;
-        rc = cnn_predict_dev(h, h->cnn_sc.as<float>(), n_reads, minibatch, Lo, &kk);
-        if (rc) return rc;
-        if (bounds_out) HIPCHK(hipMemcpyAsync(bounds_out, h->bounds.p, (size_t)n_reads * (1 + kk) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemsetAsync(h->topk_none.p, 0, (size_t)n_reads, st));
-        rc = launch_validate(h, SigF32{dsig}, dlen, n_reads, m, kk, n_reads, false);
-        if (rc) return rc;
-        rc = deliver_rows(h, n_reads, flags, rows_out);
-        if (rc) return rc;
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipStreamSynchronize(h->stream));
         rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;

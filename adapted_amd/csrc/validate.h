@@ -1150,27 +1150,37 @@ __global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int3
 // ---------------------------------------------------------------- C1 prepare_data (CNN head input)
 // reference adapted/detect/cnn.py:70-82: mean-pool the RAW signal from min_obs_adapter on, per-read
 // nanmedian / MAD of the pooled values, (x - med) / mad, NaN -> -5.0 (torch.nan_to_num: +-inf ->
-// +-FLT_MAX).  One wave per read; pooled NaNs form a tail (minibatch layout B0).
-__global__ void __launch_bounds__(64) k_cnn_prepare(const float *__restrict__ sigs, int n_reads, int m, int off, int ds, int Lc,
-                                                    float *__restrict__ out)
+// +-FLT_MAX).  Two kernels: k_cnn_pool (a 256-thread block per read; every wave pools tiles of 64 blocks staged in LDS with
+// coalesced 16-byte loads, numpy's summation order -- sp_pooled_tile; lane-strided scalar loads ran at 1.8 TB/s) and
+// k_cnn_prepare (a wave per read: the two medians and the scaling of the pooled values, in place).  Pooled NaNs form a tail
+// (minibatch layout B0).
+__global__ void __launch_bounds__(256) k_cnn_pool(const float *__restrict__ sigs, int n_reads, int m, int off, int ds, int Lc,
+                                                   float *__restrict__ out, int32_t *__restrict__ nan_cnt)
+{
+    extern __shared__ float cp_tiles_raw[]; // 4 waves x 64 * ds floats
+    const int r = blockIdx.x;
+    const int ln = lane_id(), wv = threadIdx.x >> 6;
+    LDS float *tile = (LDS float *)cp_tiles_raw + (size_t)wv * 64 * ds;
+    const RowF32 row = RowF32{(const GLB float *)sigs + (size_t)r * m + off};
+    const int Lseg = m - off;
+    float *o = out + (size_t)r * Lc;
+    int nn = 0;
+    for (int j0 = wv * 64; j0 < Lc; j0 += 256) {
+        const float v = sp_pooled_tile(row, Lseg, ds, j0, tile);
+        const int j = j0 + ln;
+        if (j < Lc) { o[j] = v; if (v != v) nn++; }
+    }
+    nn = wave_sum(nn);
+    if (ln == 0 && nn) atomicAdd(&nan_cnt[r], nn);
+}
+
+__global__ void __launch_bounds__(64) k_cnn_prepare(int n_reads, int Lc, float *__restrict__ out, const int32_t *__restrict__ nan_cnt)
 {
     __shared__ WaveScratch ws_;
     const int r = blockIdx.x;
     const int ln = lane_id();
-    const float *row = sigs + (size_t)r * m + off;
-    const int Lseg = m - off;
     float *o = out + (size_t)r * Lc;
-    int nan_cnt = 0;
-    for (int j = ln; j < Lc; j += 64) {
-        const int b = j * ds;
-        float v = pw_leaf_f32(ds, [&](int k) { int i = b + k; return i < Lseg ? row[i] : 0.0f; }) / (float)ds;
-        o[j] = v;
-        if (v != v) nan_cnt++;
-    }
-    nan_cnt = wave_sum(nan_cnt);
-    __threadfence_block();
-    __syncthreads();
-    const int n = Lc - nan_cnt;
+    const int n = Lc - nan_cnt[r];
     LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
     float med = wave_median(o, n, 0, 0.f, ws);
     float mad = wave_median(o, n, 1, med, ws);

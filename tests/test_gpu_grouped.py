@@ -11,7 +11,7 @@ from test_gpu_scale import _rows_equal, _spc200k
 
 pytestmark = pytest.mark.gpu
 
-KNOBS = [{"ADP_GROUPS": "1"}, {"ADP_GROUPS": "0"}, {"ADP_GROUPS": "2"}, {"ADP_GROUPS": "6", "ADP_LANES": "3"}, {"ADP_STAGGER": "7"},
+KNOBS = [{"ADP_GROUPS": "1"}, {"ADP_GROUPS": "0"}, {"ADP_GROUPS": "2"}, {"ADP_GROUPS": "6", "ADP_LANES": "3"}, {"ADP_STAGGER": "7", "ADP_GROUPS": "0"},
          {"ADP_STAGGER": "0", "ADP_LANES": "4", "ADP_GROUPS": "12"}, {"ADP_LANES": "1", "ADP_GROUPS": "3"}]
 
 
@@ -109,4 +109,47 @@ def test_grouped_equals_serial_at_the_200k_window_on_device_rows():
     assert rows["success"].mean() > 0.8
     for p in (dsig, dlen, drows):
         eng.dev_free(p)
+    eng.close()
+
+
+def test_cnn_chunks_over_lanes_equal_one_chunk():
+    """adp_detect_cnn cuts a call into chunks of whole minibatches over two lanes (conv stack of one beside the candidate
+    validation of the other); find_peaks / row compaction are per minibatch (reference adapted/detect/cnn.py:136-160), so rows and
+    predictions must not depend on the chunking."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+    from adapted_amd.detect import cnn
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = False, True
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m = spc.sig_preload_size
+    mb, n = 16, 16 * 7 - 3
+    lens = np.array([m if i % 3 else max(1200, synth.pareto_length(5, i, lo=1200, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(77, 0, n, m, lens)
+    for r in (4, 40, 100):
+        for j in range(20 + r % 7):
+            sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
+    eng = lib.Engine(spc, n, m, device=0)
+    cnn.ensure_weights(eng, None, spc)
+    ref = None
+    for env in ({"ADP_CNN_GROUPS": "1"}, {}, {"ADP_CNN_GROUPS": "7", "ADP_CNN_LANES": "3"}, {"ADP_CNN_GROUPS": "2", "ADP_CNN_LANES": "1"}):
+        def call():
+            old = {k: os.environ.pop(k, None) for k in ("ADP_CNN_GROUPS", "ADP_CNN_LANES")}
+            os.environ.update(env)
+            try:
+                return eng.detect_cnn_rows(sig, lens, n, mb)
+            finally:
+                for k in ("ADP_CNN_GROUPS", "ADP_CNN_LANES"):
+                    os.environ.pop(k, None)
+                    if old[k] is not None:
+                        os.environ[k] = old[k]
+        rows, bounds = call()
+        cur = _canon(rows, lib) + (bounds.tobytes(),)
+        if ref is None:
+            ref = cur
+        assert cur == ref, env
+    assert sorted(ref[1]) == [4, 40, 100]
+    assert np.frombuffer(ref[0], dtype=lib.ROW_DTYPE)["success"].sum() > n // 3
     eng.close()
