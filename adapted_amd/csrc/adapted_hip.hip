@@ -386,6 +386,12 @@ static void sync_ablate(hipStream_t st)
     }
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 // ---- the open-pore arena of one API call --------------------------------------------------
 // arena_begin: allocated, counter zeroed (on the handle's stream, ahead of every kernel of the call).  arena_end (the call's
 // stream(s) drained): how much the call wanted; > capacity = lists were dropped: grow and tell the caller to run again.
@@ -473,9 +479,16 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     in.op_arena = a->op_arena.as<int32_t>(); in.op_used = a->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(a->op_arena.cap / 4);
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
+    // S1: a wave per SHORT read (all three segments together at most small_max samples), a workgroup per read for the others
+    const int small_max = env_int("ADP_PART_SMALL", 16384);
+    if (small_max > 0) {
+        Scope s(h, "k_partition_stats_small");
+        hipLaunchKernelGGL(k_partition_stats_small<SIG>, dim3((n + 3) / 4), dim3(256), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
+                           h->rows.as<adp_row>(), n, small_max);
+    }
     { Scope s(h, "k_partition_stats");
       hipLaunchKernelGGL(k_partition_stats<SIG>, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
-                         h->rows.as<adp_row>()); }
+                         h->rows.as<adp_row>(), small_max); }
     return 0;
 }
 
@@ -531,6 +544,10 @@ static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch
         { Scope s(h, !profile ? nullptr : "k_n1_fused_finish");
           hipLaunchKernelGGL(k_n1_fused_finish, pg, dim3(1024), 0, st, mbs, fz, fc, (const float *)cb, thr, (const uint32_t *)hvy); }
     }
+    // behind the fused pass these launches only serve the (rare) minibatch it could not settle: with many minibatches in the call
+    // such a minibatch would be left to 4096 / n_mb blocks -- one missed bracket among 96 Pareto-length minibatches cost 3.5 ms of a
+    // 50 ms step -- so it gets at least 128 (the blocks of settled minibatches return at once)
+    if ((long long)minibatch * T >= fused_min && T >= 64 && bpm < 128) hg = dim3(128, n_mb);
     for (int mode = 0; mode < 2; mode++) {
         // guess from a row sample
         hipLaunchKernelGGL((k_n1_hist<0, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
@@ -697,11 +714,6 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
 // groups per lane, k: aim at k groups); ADP_LANES (streams the groups rotate over, default 2); ADP_STAGGER (bit p set: phase p of
 // group g + 1 starts after phase p of group g; default 1 = the streaming S phases take turns, which keeps neighbouring groups one
 // phase apart)
-static int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-}
 
 static int lane_get(adp_handle *h, int i, int reads, adp_handle **out)
 {
@@ -1379,10 +1391,13 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
     if (rc) return rc;
-    // ADP_CNN_GROUPS: 1 = one chunk on one stream; 0 / unset = automatic (chunks of about a quarter of the call, at most what the
-    // conv stack's activation buffers hold, over two lanes); k = aim at k chunks
+    // ADP_CNN_GROUPS (opt-in): unset / 1 = one chunk on one stream; 0 = automatic (chunks of about a quarter of the call, at most
+    // what the conv stack's activation buffers hold, over two lanes); k = aim at k chunks.  Measured at the 200 k window (8000
+    // reads, profiles/r03_cnn_chunks.txt): 4 chunks over 2 lanes 107.5 ms against 95.4 ms for one chunk -- the moving-window
+    // series costs the same ~11 ms per LAUNCH whatever the number of reads (one wave's instruction stream per chain), so
+    // chunking multiplies it, and the conv stack stretches by as much as its neighbours gain; equal at the default window.
     const int n_mb = (n_reads + minibatch - 1) / minibatch;
-    int want = env_int("ADP_CNN_GROUPS", 0), n_lanes = env_int("ADP_CNN_LANES", 2);
+    int want = env_int("ADP_CNN_GROUPS", 1), n_lanes = env_int("ADP_CNN_LANES", 2);
     if (n_lanes < 1) n_lanes = 1;
     if (n_lanes > ADP_MAX_LANES) n_lanes = ADP_MAX_LANES;
     if (want <= 0) want = 4;

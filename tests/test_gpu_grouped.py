@@ -134,7 +134,7 @@ def test_cnn_chunks_over_lanes_equal_one_chunk():
     eng = lib.Engine(spc, n, m, device=0)
     cnn.ensure_weights(eng, None, spc)
     ref = None
-    for env in ({"ADP_CNN_GROUPS": "1"}, {}, {"ADP_CNN_GROUPS": "7", "ADP_CNN_LANES": "3"}, {"ADP_CNN_GROUPS": "2", "ADP_CNN_LANES": "1"}):
+    for env in ({"ADP_CNN_GROUPS": "1"}, {"ADP_CNN_GROUPS": "0"}, {"ADP_CNN_GROUPS": "7", "ADP_CNN_LANES": "3"}, {"ADP_CNN_GROUPS": "2", "ADP_CNN_LANES": "1"}):
         def call():
             old = {k: os.environ.pop(k, None) for k in ("ADP_CNN_GROUPS", "ADP_CNN_LANES")}
             os.environ.update(env)
