@@ -479,16 +479,9 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     in.op_arena = a->op_arena.as<int32_t>(); in.op_used = a->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(a->op_arena.cap / 4);
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
-    // S1: a wave per SHORT read (all three segments together at most small_max samples), a workgroup per read for the others
-    const int small_max = env_int("ADP_PART_SMALL", 16384);
-    if (small_max > 0) {
-        Scope s(h, "k_partition_stats_small");
-        hipLaunchKernelGGL(k_partition_stats_small<SIG>, dim3((n + 3) / 4), dim3(256), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
-                           h->rows.as<adp_row>(), n, small_max);
-    }
     { Scope s(h, "k_partition_stats");
       hipLaunchKernelGGL(k_partition_stats<SIG>, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
-                         h->rows.as<adp_row>(), small_max); }
+                         h->rows.as<adp_row>()); }
     return 0;
 }
 

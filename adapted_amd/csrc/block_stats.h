@@ -826,24 +826,16 @@ struct PartReq {
     int32_t p_none;     // polya_end is None (mvs_detect_overwrite): poly(A) keeps its start only, the RNA partition is all None
 };
 
-static __device__ __forceinline__ bool part_is_small(const PartReq &q, int small_max)
-{
-    const long long a0 = q.a_s < 0 ? 0 : q.a_s;
-    return small_max > 0 && (long long)q.S - a0 <= (long long)small_max;
-}
-
 // grid = n_reads blocks of 256 threads
-// small_max: reads with at most this many samples behind the adapter start belong to k_partition_stats_small (0: none do)
 template <class SIG>
 __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int m, const PartReq *__restrict__ req,
-                                                               adp_row *__restrict__ rows, int small_max)
+                                                               adp_row *__restrict__ rows)
 {
     __shared__ BlockScratch bs_;
     LDS BlockScratch *bs = (LDS BlockScratch *)&bs_;
     const int r = blockIdx.x;
     const PartReq q = req[r];
     if (!q.valid) return;
-    if (part_is_small(q, small_max)) return;
     if (threadIdx.x == 0) bs->tail_cached = -1;
     __syncthreads();
     const typename SIG::Row sig = sigs.row(r, m);
@@ -878,69 +870,7 @@ __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int
     if (threadIdx.x == 0) row->present |= present;
 }
 
-// ---------------------------------------------------------------- short reads: a wave per read
-// A 256-thread workgroup per read pays its barriers, its 4096-bucket histogram and the bracket machinery whatever the
-// segment's length; with heavy-tailed read lengths (BASELINE configs[4]: half of the reads below 18 k samples) most
-// workgroups spend their time there.  Reads whose three segments together hold at most `small_max` samples go to one WAVE
-// instead (no workgroup barrier anywhere): numpy-ordered sums and exact radix selects of wave_stats.h -- the same values
-// by construction (both paths restate np.mean / np.std / np.median on float32 slices, signal_partitions.py:81-96).
-template <class ROW>
-static __device__ SegStats wave_segment_stats(ROW x, int n, LDS WaveScratch *ws, bool have_medmad, float med_in, float mad_in)
-{
-    SegStats o;
-    o.mean = wave_np_sum_t<ROW>(x, n, 0, 0.f, ws) / (float)n;
-    if (o.mean != o.mean) { // a NaN sample makes every statistic NaN; infinities of both signs only the mean and what follows from it
-        bool nanhere = false;
-        for (int i = lane_id(); i < n; i += 64) { const float v = x[i]; nanhere |= v != v; }
-        if (__any(nanhere)) { o.sd = o.med = o.mad = __builtin_nanf(""); return o; }
-    }
-    o.sd = sqrtf(wave_np_sum_t<ROW>(x, n, 2, o.mean, ws) / (float)n);
-    if (have_medmad) { o.med = med_in; o.mad = mad_in; return o; }
-    o.med = wave_median(x, n, 0, 0.f, ws);
-    o.mad = wave_median(x, n, 1, o.med, ws);
-    return o;
-}
-
-// grid = ceil(n_reads / 4) blocks of 4 waves, a read per wave
-template <class SIG>
-__global__ void __launch_bounds__(256) k_partition_stats_small(SIG sigs, int m, const PartReq *__restrict__ req, adp_row *__restrict__ rows,
-                                                                int n_reads, int small_max)
-{
-    __shared__ WaveScratch ws_[4];
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_reads) return;
-    LDS WaveScratch *ws = (LDS WaveScratch *)&ws_[threadIdx.x >> 6];
-    const PartReq q = req[r];
-    if (!q.valid || !part_is_small(q, small_max)) return;
-    const typename SIG::Row sig = sigs.row(r, m);
-    adp_row *row = rows + r;
-    const int S = q.S;
-    const int ln = lane_id();
-    unsigned long long present = 0;
-    const long long starts[3] = {q.a_s, q.a_e, q.p_e};
-    const long long ends[3] = {q.a_e, q.p_e, (long long)S};
-    const int c_start[3] = {ADP_C_ADAPTER_START, ADP_C_POLYA_START, ADP_C_RNA_START};
-    const int c_len[3] = {ADP_C_ADAPTER_LEN, ADP_C_POLYA_LEN, ADP_C_RNA_LEN};
-    for (int p = 0; p < 3; p++) {
-        const long long st = starts[p], en = ends[p];
-        if (p == 2 && q.p_none) continue;
-        if (ln == 0) row->col[c_start[p]] = (double)st;
-        present |= 1ull << c_start[p];
-        if (en <= st || (p == 1 && q.p_none)) continue;
-        long long a = st < S ? st : S, b = en < S ? en : S;
-        int n = (int)(b - a);
-        SegStats s;
-        if (n <= 0) s.mean = s.sd = s.med = s.mad = __builtin_nanf("");
-        else s = wave_segment_stats(sig + a, n, ws, p == 0 && q.have_adapter_medmad, q.adapter_med, q.adapter_mad);
-        if (ln == 0) {
-            row->col[c_len[p]] = (double)(en - st);
-            row->col[c_len[p] + 1] = (double)s.mean;
-            row->col[c_len[p] + 2] = (double)s.sd;
-            row->col[c_len[p] + 3] = (double)s.med;
-            row->col[c_len[p] + 4] = (double)s.mad;
-        }
-        present |= 31ull << c_len[p];
-        ws_sync();
-    }
-    if (ln == 0) row->present |= present;
-}
+// (Round 3, measured and dropped: a wave per SHORT read -- numpy-ordered sums and radix selects of wave_stats.h, no workgroup
+// barriers -- for reads of at most 16 k samples.  On Pareto lengths that kernel took 42 ms for the reads it relieved this one of
+// 3 ms for (profiles/r03_partition_small_sweep.txt): a single wave's scalar loads and four-pass selects are far slower per
+// sample than this workgroup's staged passes, however short the segment.)
