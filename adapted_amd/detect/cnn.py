@@ -251,5 +251,5 @@ def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarr
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", category=RuntimeWarning)
         rows = detect_rows(eng, sig, lens, model, spc, conv=conv)
-    res = lib.rows_to_results(rows, "cnn")
+    res = lib.rows_to_results(rows, "cnn", consume=True)
     return res if len(res) > 1 else res[0]

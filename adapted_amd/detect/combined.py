@@ -73,7 +73,7 @@ def combined_detect_llr2(batch_of_signals: np.ndarray, full_signal_lens: np.ndar
     if mbs[0] == lib.MB_EMPTY_TRACE:
         # the reference dies in np.argmin on a read whose pooled trace is empty (llr.py:136)
         raise ValueError("attempt to get argmin of an empty sequence")
-    return lib.rows_to_results(rows, "llr")
+    return lib.rows_to_results(rows, "llr", consume=True)
 
 
 _EXC_TYPES = {9: TypeError, 10: TypeError, 11: ValueError, 12: ValueError, 13: ValueError, 14: ValueError}
@@ -107,7 +107,7 @@ def combined_detect_llr(calibrated_signal: np.ndarray, full_signal_len: int, spc
     fc = int(rows[0]["fail_code"])
     if 9 <= fc <= 14:  # raised inside validate_boundaries: not caught on this path
         raise _EXC_TYPES[fc](lib.fail_reason_of(rows[0]))
-    return lib.rows_to_results(rows, "llr")[0]
+    return lib.rows_to_results(rows, "llr", consume=True)[0]
 
 
 def combined_detect_start_peak(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, spc,
@@ -118,7 +118,7 @@ def combined_detect_start_peak(batch_of_signals: np.ndarray, full_signal_lens: n
         return []
     eng = get_engine(spc, n, m, device)
     rows = eng.detect_start_peak_rows(sig, lens, n, n)
-    return lib.rows_to_results(rows, "start_peak")
+    return lib.rows_to_results(rows, "start_peak", consume=True)
 
 
 def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_signal_len: int,
@@ -144,7 +144,7 @@ def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_si
     rows = eng.validate_rows(sig, np.array([eff_len], dtype=np.int32), 1, b, topk_none=none)
     if eff_len != int(full_signal_len) and int(rows[0]["present"]) & 1:
         rows[0]["col"][0] = float(full_signal_len)  # signal_len reports the read's true length
-    return lib.rows_to_results(rows, spc.primary_method)[0]
+    return lib.rows_to_results(rows, spc.primary_method, consume=True)[0]
 
 
 def combined_detect_cnn(batch_of_signals: np.ndarray, full_signal_lens: np.ndarray, model, spc,

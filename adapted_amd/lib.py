@@ -257,9 +257,11 @@ def fail_reason_of(row) -> Optional[str]:
     return fr
 
 
-def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
+def rows_to_results(rows: np.ndarray, primary: str, consume: bool = False) -> List[DetectResults]:
     """adp_row[] -> DetectResults, value for value what the reference's validate_boundaries
-    returns (types: python int / float, np.float32 where the reference keeps numpy scalars)."""
+    returns (types: python int / float, np.float32 where the reference keeps numpy scalars).
+    consume: the rows are not needed again -- their overflow open_pores lists leave the registry (a long run converts
+    every row exactly once: adapted_amd/main.py)."""
     out = []
     names = [c.format(primary=primary) for c in COLS]
     for r in rows:
@@ -288,7 +290,7 @@ def rows_to_results(rows: np.ndarray, primary: str) -> List[DetectResults]:
             if no <= MAX_OPEN_PORES:
                 d.open_pores = np.asarray(r["open_pores"][:no], dtype=np.int64)
             else:  # the whole list was fetched from the call's arena (Engine._attach_open_pores)
-                more = _OPEN_PORES_MORE.get(int(r["open_pores_more"]))
+                more = (_OPEN_PORES_MORE.pop if consume else _OPEN_PORES_MORE.get)(int(r["open_pores_more"]), None)
                 if more is None or more.size != no:
                     raise HipLibraryError("a row with %d open pores lost its overflow list (rows from a device buffer? fetch them "
                                           "through Engine.attach_open_pores)" % no)

@@ -172,7 +172,7 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
             my_ids.extend(tagged[:, 0].tolist())
             my_ord.extend(int(x) for x in tagged[:, 1])
         else:
-            res = lib.rows_to_results(rows, primary)
+            res = lib.rows_to_results(rows, primary, consume=True)
             writer.add([ReadResult(read_id=str(rid), success=r.success, fail_reason=r.fail_reason, detect_results=r)
                         for rid, r in zip(tagged[:, 0], res)])
 
@@ -191,7 +191,7 @@ def run_detect(files, read_ids_incl, read_ids_excl, spc, run_dir, minibatch, bat
         if rank == 0:
             ids = [x for part in lists for x in part[0]]
             order = np.argsort(np.array([x for part in lists for x in part[1]], dtype=np.int64), kind="stable")
-            res = lib.rows_to_results(allrows[order], primary)  # stream order: the files read like a one-GPU run's
+            res = lib.rows_to_results(allrows[order], primary, consume=True)  # stream order: the files read like a one-GPU run's
             writer.add([ReadResult(read_id=str(ids[i]), success=r.success, fail_reason=r.fail_reason, detect_results=r)
                         for i, r in zip(order, res)])
     if writer is not None:

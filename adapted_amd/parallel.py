@@ -67,7 +67,8 @@ def gather_rows(rows, dst: int = 0, group=None, always: bool = False):
         # process's registry -> the lists -> tokens of the destination's registry
         from . import lib as _lib
 
-        mine = [(int(i), _lib._OPEN_PORES_MORE[int(rows[i]["open_pores_more"])]) for i in np.flatnonzero(rows["n_open_pores"] > _lib.MAX_OPEN_PORES)]
+        # (the sender's copies leave its registry: the destination registers them again under its own tokens)
+        mine = [(int(i), _lib._OPEN_PORES_MORE.pop(int(rows[i]["open_pores_more"]))) for i in np.flatnonzero(rows["n_open_pores"] > _lib.MAX_OPEN_PORES)]
         more = [None] * ws if rk == dst else None
         dist.gather_object(mine, more, dst=dst, group=group)
     if rk != dst:

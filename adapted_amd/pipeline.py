@@ -54,7 +54,15 @@ class HostPipeline:
             self.dsig16 = self.eng.dev_alloc(self.N * self.m * 2) if self.ragged else None
         elif self.i16 or self.ragged:
             self.dsig16 = self.eng.dev_alloc(self.N * self.m * 4)
-        for _ in range(min(16, max(2, n_slots))):
+        # staging slots are made when first handed out (page-locking a 3.2 GB slot takes about a second: a short run pins only
+        # the slots it uses, and the second and third are pinned by the producer thread while the first is being processed)
+        self.slots = [None] * min(16, max(2, n_slots))
+        self.free: "queue.Queue[int]" = queue.Queue()
+        for i in range(len(self.slots)):
+            self.free.put(i)
+
+    def _slot(self, j: int):
+        if self.slots[j] is None:
             sig = self.eng.host_alloc((self.N * self.m,) if self.ragged else (self.N, self.m), np.int16 if self.i16 else np.float32)
             lens = self.eng.host_alloc((self.N,), np.int32)
             slot = {"sig": sig, "lens": lens, "ds": self.eng.dev_alloc(self.N * self.m * (2 if self.i16 else 4)),
@@ -65,13 +73,13 @@ class HostPipeline:
             if self.i16:
                 slot["cal"] = self.eng.host_alloc((2, self.N), np.float32)  # scale, offset
                 slot["dcal"] = self.eng.dev_alloc(2 * self.N * 4)
-            self.slots.append(slot)
-        self.free: "queue.Queue[int]" = queue.Queue()
-        for i in range(len(self.slots)):
-            self.free.put(i)
+            self.slots[j] = slot
+        return self.slots[j]
 
     def close(self):
         for s in self.slots:
+            if s is None:
+                continue
             self.eng.host_free(s["sig"])
             self.eng.host_free(s["lens"])
             self.eng.dev_free(s["ds"])
@@ -146,7 +154,7 @@ class HostPipeline:
         def get_buffers():
             j = self.free.get()
             cur["j"] = j
-            sl = self.slots[j]
+            sl = self._slot(j)
             head = (sl["sig"], sl["lens"], sl["offs"]) if self.ragged else (sl["sig"], sl["lens"])
             if self.i16:
                 return head + (sl["cal"][0], sl["cal"][1])
@@ -232,9 +240,18 @@ class HostPipeline:
                     break
             for j in range(len(self.slots)):
                 self.free.put(j)
-            tp.join(timeout=60)
+            tp.join(timeout=120)
+            producer_gone = not tp.is_alive()
             done.put(None)
             tc.join()
+            try:
+                self.eng.copy_wait(-1)  # no H2D copy may still be reading a pinned slot when the caller frees them
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+            if not producer_gone:
+                # still inside a read / decode that does not return: its slots must outlive it -- close() will not free them
+                self.slots = [None] * len(self.slots)
+                err.insert(0, RuntimeError("the reader thread did not stop within 120 s; its pinned staging slots are left allocated"))
             # the free list back to one token per slot for the next run()
             while True:
                 try:

@@ -362,3 +362,20 @@ def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(mo
                 assert np.array_equal(flat[offs[j]:offs[j + 1]], want)
             k0 += k
         assert k0 == len(ids_all)
+
+
+def test_adapted_console_script_is_declared():
+    """`adapted` (the reference's entry point, setup.py:49) resolves to this package's main()"""
+    try:
+        import tomllib
+    except ImportError:
+        import tomli as tomllib
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as fh:
+        cfg = tomllib.load(fh)
+    target = cfg["project"]["scripts"]["adapted"]
+    mod, fn = target.split(":")
+    import importlib
+
+    main = getattr(importlib.import_module(mod), fn)
+    p = __import__("adapted_amd.main", fromlist=["build_parser"]).build_parser()
+    assert callable(main) and {"detect", "continue"} <= set(p._subparsers._group_actions[0].choices)
