@@ -86,6 +86,7 @@ struct adp_handle {
     // group of minibatches; consecutive groups go to alternating lanes so that the phases of neighbouring groups overlap
     adp_handle *lane[ADP_MAX_LANES] = {};
     adp_handle *owner = nullptr;            // a lane's parent: owns the open-pore arena and collects the profile
+    DevBuf sphead;                          // K1 state between k_sp_head, the pooling pass and k_sp_tail
     DevBuf mbstat, mbparams;                // parent: minibatch status / N1 parameters of a grouped call
     std::vector<hipEvent_t> ev_sync;        // parent: phase-done events of the groups (no timing)
     hipEvent_t ev_start = nullptr;          // parent: inputs staged, arena counter reset
@@ -252,7 +253,7 @@ int adp_destroy(adp_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-    h->mbstat.release(); h->mbparams.release();
+    h->mbstat.release(); h->mbparams.release(); h->sphead.release();
     DevBuf *all[] = {&h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
@@ -600,7 +601,7 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
     HIPCHK(hipMemsetAsync(h->gbelow.p, 0, (size_t)n_mb * 8, st));
     HIPCHK(hipMemsetAsync(h->gcnt.p, 0, (size_t)n_mb * 8 * N1_NCNT, st));
     const int T = h->T;
-    bool sp_forked = false;
+    bool sp_forked = false, sp_done = false;
     if (h->L <= 0) {
         hipLaunchKernelGGL(k_mb_set_status, dim3((n_mb + 255) / 256), dim3(256), 0, st, mbs, n_mb, ADP_MB_EMPTY_TRACE);
         if (ps) for (int k = 0; k < 2; k++) { if (k && ps->wait[k]) HIPCHK(hipStreamWaitEvent(st, ps->wait[k], 0)); if (ps->done[k]) HIPCHK(hipEventRecord(ps->done[k], st)); }
@@ -609,7 +610,26 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         const int32_t *tails = (flags & ADP_TAILS_NAN) ? dlen : nullptr;
         rc = launch_n1(h, dsig, n, m, T, minibatch, n_mb, true, tails);
         if (rc) return rc;
-        if (upto >= 2) {
+        // K1 riding the pooling pass (k_norm_pool<SIG, true>): when both pooling factors agree and min_obs_adapter is a multiple of
+        // them the start-peak scan costs no sweep of its own (ADP_SP_FUSED=0: the separate k_start_peak on the side stream)
+        const bool sp_fused = upto >= 8 && (flags & ADP_WITH_START_PEAK) && h->layout == ADP_LAYOUT_MINIBATCH &&
+                              h->cfg.sp_downscale_factor == h->ds && h->off % h->ds == 0 && T > h->off && env_int("ADP_SP_FUSED", 1) != 0;
+        if (sp_fused) {
+            if (h->sphead.ensure((size_t)n * sizeof(SpHead))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+            Scope s(h, "k_sp_head");
+            hipLaunchKernelGGL(k_sp_head<SIG>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->off, h->sphead.as<SpHead>());
+        }
+        if (upto >= 2 && sp_fused) {
+            { Scope s(h, "k_norm_pool");
+              hipLaunchKernelGGL((k_norm_pool<SIG, true>), dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+                                 minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
+                                 dlen, (flags & ADP_TAILS_NAN) ? 1 : 0, h->sphead.as<SpHead>(), (float)h->cfg.open_pore_pa); }
+            const int cov0 = h->off / h->ds, cov1 = cov0 + (T - h->off) / h->ds;
+            Scope s(h, "k_sp_tail");
+            hipLaunchKernelGGL(k_sp_tail<SIG>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, cov0, cov1,
+                               (const SpHead *)h->sphead.as<SpHead>(), h->sp.as<SpOut>());
+            sp_done = true;
+        } else if (upto >= 2) {
             Scope s(h, "k_norm_pool");
             const int64_t *rng = nullptr;
             if (h->layout == ADP_LAYOUT_SINGLE_READ) {
@@ -629,7 +649,7 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);
         if (ps && ps->done[0]) HIPCHK(hipEventRecord(ps->done[0], st));
-        if (upto >= 8 && (flags & ADP_WITH_START_PEAK)) {
+        if (upto >= 8 && (flags & ADP_WITH_START_PEAK) && !sp_fused) {
             // the start-peak scan depends on nothing computed here: it streams the signal on the side stream while the
             // main stream runs the ALU-bound cumulative sums and gains
             HIPCHK(hipEventRecord(h->ev_fork, st));
@@ -684,7 +704,7 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         if (rc) return rc;
         if (flags & ADP_WITH_START_PEAK) {
             if (sp_forked) HIPCHK(hipStreamWaitEvent(st, h->ev_join, 0));
-            else {
+            else if (!sp_done) {
                 Scope s(h, "k_start_peak");
                 hipLaunchKernelGGL(k_start_peak<SIG>, dim3(n), dim3(64), (size_t)64 * h->cfg.sp_downscale_factor * 4, st, dsig, dlen, n, m, h->cfg, h->sp.as<SpOut>());
             }

@@ -30,15 +30,29 @@ __device__ const double g_logcr_table[3 * LOGCR_N] = LOGCR_TABLE;
 // ranges != nullptr (CNN fallback C4): per-read pooled region [ranges[2r], min(ranges[2r+1], T, full_len))
 // tails_nan (ADP_TAILS_NAN): the row is NaN padding from full_len[r] on -- pooled blocks that reach into it are NaN without
 // being read
-template <class SIG>
+// SP (the start-peak scan of K1 rides this pass, reference adapted/detect/start_peak.py:26-52): the tile then holds the RAW
+// samples (normalised on their way into the pooled sums: the same operations on the same values) and every complete pooled
+// block also yields the mean of its raw samples -- start_peak.py's `pooled` when both pooling factors agree and min_obs_adapter
+// is a multiple of them -- which is compared with the read's start-peak maximum (SpHead, left by k_sp_head): the first block
+// above it inside [a2, e0), and the first raw sample above the open-pore level before op_end.  k_sp_tail finishes the row.
+struct SpHead {
+    int32_t valid, max_idx, a2, e0;   // K1 state after the head: still valid, arg-max of pooled[off1:spmax], scan range [a2, e0)
+    float mx;                         // max(pooled[off1:spmax]) (NaN if a NaN was there)
+    int32_t op_end;                   // raw samples [0, op_end) are searched for the open pore (min(full_len, m) // ds: the quirk)
+    int32_t op_head, op_body, hit;    // first raw index above the level in the head / in this pass's range; first block above mx here
+    int32_t pad;
+};
+
+template <class SIG, bool SP = false>
 __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
                                                    float *__restrict__ down, int32_t *__restrict__ nvalid,
                                                    const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len,
-                                                   int tails_nan = 0)
+                                                   int tails_nan = 0, SpHead *__restrict__ sp_head = nullptr, float sp_thr = 0.f)
 {
     extern __shared__ float tile[];
     __shared__ int s_nan;
+    __shared__ int s_sp[2];
     const int r = blockIdx.x;
     const MbState st = mbs[r / mbsize];
     if (st.status != ADP_MB_OK) { if (threadIdx.x == 0) nvalid[r] = 0; return; }
@@ -56,6 +70,16 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
     const typename SIG::Row row = sig.row(r, m) + off;
     if (threadIdx.x == 0) s_nan = 0;
     int my_nan = 0;
+    // start-peak state of this read (SP)
+    float sp_mx = 0.f;
+    int sp_a2 = 0, sp_e0 = 0, sp_op_end = 0, sp_hit = 0x7fffffff, sp_op = 0x7fffffff;
+    const int sp_full = (T - off) / ds;      // complete pooled blocks of this pass: the ragged last one is left to k_sp_tail
+    const int sp_pb0 = off / ds;             // pooled index (start_peak.py's) of this pass's block 0
+    if (SP) {
+        const SpHead hd = sp_head[r];
+        sp_mx = hd.mx; sp_a2 = hd.valid ? hd.a2 : 0; sp_e0 = hd.valid ? hd.e0 : 0; sp_op_end = hd.op_end;
+        if (threadIdx.x < 2) s_sp[threadIdx.x] = 0x7fffffff;
+    }
     // pooled blocks worth computing: all of them, or only those that end before the padding starts
     int L_ok = L;
     if (tails_nan && !ranges) {
@@ -85,7 +109,16 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
             for (int q = threadIdx.x; q < tile_n / 4; q += 256) {
                 const int idx = base + 4 * q;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f); // np.pad(..., mode="constant") for a ragged tail
-                if (idx + 3 < Lseg) { v = rowb.f4s(q); v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
+                if (SP) { // raw samples; a sample behind the segment is marked (its normalised value is the pad's zero)
+                    const float padv = -__builtin_inff();
+                    v = make_float4(padv, padv, padv, padv);
+                    if (idx + 3 < Lseg) v = rowb.f4s(q);
+                    else {
+                        if (idx < Lseg) v.x = row[idx];
+                        if (idx + 1 < Lseg) v.y = row[idx + 1];
+                        if (idx + 2 < Lseg) v.z = row[idx + 2];
+                    }
+                } else if (idx + 3 < Lseg) { v = rowb.f4s(q); v.x = norm1(v.x); v.y = norm1(v.y); v.z = norm1(v.z); v.w = norm1(v.w); }
                 else {
                     if (idx < Lseg) v.x = norm1(row[idx]);
                     if (idx + 1 < Lseg) v.y = norm1(row[idx + 1]);
@@ -96,7 +129,8 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
         } else {
             for (int i = threadIdx.x; i < tile_n; i += 256) {
                 int idx = base + i;
-                tile[i] = (idx < Lseg) ? norm1(row[idx]) : 0.0f;
+                if (SP) tile[i] = (idx < Lseg) ? row[idx] : -__builtin_inff();
+                else tile[i] = (idx < Lseg) ? norm1(row[idx]) : 0.0f;
             }
         }
         __syncthreads();
@@ -104,17 +138,40 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
             const int j = tb + jj;
             if (j < L) {
                 const float *p = tile + jj * ds;
-                float s = pw_leaf_f32(ds, [&](int k) { return p[k]; });
+                float s;
+                if (SP) {
+                    // (only the ragged last block holds pad marks: -inf never is a sample's value there, the range test says so)
+                    const int nin = Lseg - j * ds; // samples of this block inside the segment (>= ds for a complete block)
+                    s = pw_leaf_f32(ds, [&](int k) { return k < nin ? norm1(p[k]) : 0.0f; });
+                    if (j < sp_full) {
+                        const int g = sp_pb0 + j;
+                        if (g >= sp_a2 && g < sp_e0) {
+                            const float v = pw_leaf_f32(ds, [&](int k) { return p[k]; }) / (float)ds;
+                            if (v > sp_mx && g < sp_hit) sp_hit = g;
+                        }
+                        const int i0 = off + j * ds; // raw index of the block's first sample
+                        if (i0 < sp_op_end && sp_op == 0x7fffffff) {
+                            for (int k = 0; k < ds; k++) if (i0 + k < sp_op_end && p[k] > sp_thr) { sp_op = i0 + k; break; }
+                        }
+                    }
+                } else s = pw_leaf_f32(ds, [&](int k) { return p[k]; });
                 float pooled = s / (float)ds;
                 down[(size_t)r * Lp + j] = pooled;
                 if (pooled != pooled) my_nan++;
             }
         }
     }
+    if (SP) {
+        sp_hit = wave_min(sp_hit); sp_op = wave_min(sp_op);
+        if (lane_id() == 0) { if (sp_hit != 0x7fffffff) atomicMin(&s_sp[0], sp_hit); if (sp_op != 0x7fffffff) atomicMin(&s_sp[1], sp_op); }
+    }
     my_nan = wave_sum(my_nan);
     if (lane_id() == 0 && my_nan) atomicAdd(&s_nan, my_nan);
     __syncthreads();
-    if (threadIdx.x == 0) nvalid[r] = L - s_nan;
+    if (threadIdx.x == 0) {
+        nvalid[r] = L - s_nan;
+        if (SP) { sp_head[r].hit = s_sp[0]; sp_head[r].op_body = s_sp[1]; }
+    }
 }
 
 // ---------------------------------------------------------------- cumulative sums

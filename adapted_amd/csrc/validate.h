@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "common.h"
 #include "wave_stats.h"
+#include "llr_stream.h"
 #include "block_stats.h"
 #include "cand_stats.h"
 
@@ -1085,6 +1086,131 @@ __global__ void __launch_bounds__(64) k_start_peak(SIG sigs, const int32_t *__re
         if (has_op) {
             if (fabs((double)nxt - (double)op) <= 2.0 + 0.01 * fabs((double)op)) o.flagged_type = 1;
             else if (max_idx < op && op < nxt) o.flagged_type = 2;
+            if (o.flagged_type) { o.has_open_pore = 1; o.open_pore_idx = (int64_t)op * ds; }
+        }
+    }
+    if (ln == 0) out[r] = o;
+}
+
+// ---- K1 riding the pooling pass of the LLR path (k_norm_pool<SIG, true>, llr_stream.h) -----------------------------------
+// k_sp_head: what lies in front of min_obs_adapter -- the maximum of pooled[offset1 : start_peak_max_idx] and the open-pore scan
+// over raw[0 : scan_to) -- and the scan ranges; k_sp_tail: the blocks and samples the pooling pass did not cover (behind
+// max_obs_trace, or in front of min_obs_adapter), the flags, the row's SpOut.  Same operations as k_start_peak on the same
+// values: the first block above the maximum and the first sample above the open-pore level do not depend on who finds them.
+template <class SIG>
+__global__ void __launch_bounds__(64) k_sp_head(SIG sigs, const int32_t *__restrict__ full_len, int n_reads, int m, adp_cfg cfg,
+                                                int scan_to, SpHead *__restrict__ hd)
+{
+    extern __shared__ float sp_tile_raw[];
+    LDS float *tile = (LDS float *)sp_tile_raw;
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    const typename SIG::Row row = sigs.row(r, m);
+    const int ds = cfg.sp_downscale_factor;
+    const int off1 = cfg.sp_offset1, spmax = cfg.start_peak_max_idx, off2 = cfg.sp_offset2;
+    const long long fl = full_len[r];
+    const int end_idx = (int)((fl < m ? fl : m) / ds);
+    const int L = (m + ds - 1) / ds;
+    SpHead o; memset(&o, 0, sizeof(o));
+    o.op_end = end_idx < m ? end_idx : m;
+    o.op_head = 0x7fffffff; o.op_body = 0x7fffffff; o.hit = 0x7fffffff;
+    const float thr = (float)cfg.open_pore_pa;
+    const int lim = o.op_end < scan_to ? o.op_end : scan_to;
+    int op = 0x7fffffff;
+    for (int base = 0; base < lim && op == 0x7fffffff; base += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + u * 64 + ln; v[u] = row.at_or(i, i < lim, -__builtin_inff()); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long mk = __ballot(v[u] > thr);
+            if (mk && op == 0x7fffffff) op = base + u * 64 + __ffsll((long long)mk) - 1;
+        }
+    }
+    o.op_head = op;
+    const int a = min(off1, L), b = min(spmax, L);
+    bool valid = (b - a > 0);
+    float mx = 0.f; int max_idx = 0;
+    if (valid) {
+        float lm = -__builtin_inff(); int li = 0x7fffffff; bool anynan = false;
+        for (int j0 = a; j0 < b; j0 += 64) {
+            const int j = j0 + ln;
+            float v = sp_pooled_tile(row, m, ds, j0, tile);
+            if (j >= b) continue;
+            if (v != v) anynan = true;
+            else if (v > lm || li == 0x7fffffff) { lm = v; li = j; }
+        }
+        anynan = __any(anynan);
+        const float wm = wave_max(lm);
+        mx = anynan ? __builtin_nanf("") : wm;
+        int first = (!anynan && li != 0x7fffffff && lm == wm) ? li : 0x7fffffff;
+        first = wave_min(first);
+        max_idx = (first == 0x7fffffff ? 0 : first - a) + off1;
+    }
+    const int s0 = spmax + off2;
+    const int e0 = min(end_idx, L), a2 = min(s0, L);
+    if (valid && e0 - a2 <= 0) valid = false;
+    o.valid = valid ? 1 : 0; o.mx = mx; o.max_idx = max_idx; o.a2 = a2; o.e0 = e0;
+    if (ln == 0) hd[r] = o;
+}
+
+// cov0 / cov1: the pooling pass looked at the pooled blocks [cov0, cov1) (inside [a2, e0)) and at the raw samples [cov0 * ds, cov1 * ds)
+template <class SIG>
+__global__ void __launch_bounds__(64) k_sp_tail(SIG sigs, const int32_t *__restrict__ full_len, int n_reads, int m, adp_cfg cfg,
+                                                int cov0, int cov1, const SpHead *__restrict__ hd, SpOut *__restrict__ out)
+{
+    extern __shared__ float sp_tile_raw[];
+    LDS float *tile = (LDS float *)sp_tile_raw;
+    const int r = blockIdx.x;
+    const int ln = lane_id();
+    const typename SIG::Row row = sigs.row(r, m);
+    const int ds = cfg.sp_downscale_factor;
+    const int spmax = cfg.start_peak_max_idx, off2 = cfg.sp_offset2;
+    const int L = (m + ds - 1) / ds;
+    const SpHead h = hd[r];
+    SpOut o; memset(&o, 0, sizeof(o));
+    // open pore: the head's find, else the pooling pass's, else whatever lies behind its range
+    int op = h.op_head != 0x7fffffff ? h.op_head : h.op_body;
+    const float thr = (float)cfg.open_pore_pa;
+    for (int base = cov1 * ds; base < h.op_end && op == 0x7fffffff; base += 512) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + u * 64 + ln; v[u] = row.at_or(i, i < h.op_end, -__builtin_inff()); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const unsigned long long mk = __ballot(v[u] > thr);
+            if (mk && op == 0x7fffffff) op = base + u * 64 + __ffsll((long long)mk) - 1;
+        }
+    }
+    op = (op == 0x7fffffff) ? 0 : op / ds;
+    const bool has_op = op > 0;
+    bool valid = h.valid != 0;
+    const float mx = h.mx;
+    const int s0 = spmax + off2, a2 = h.a2, e0 = h.e0;
+    int nxt = 0;
+    if (valid) {
+        int hit = 0x7fffffff;
+        auto scan = [&](int from, int to) { // first block in [from, to) above the maximum
+            for (int base = from; base < to && hit == 0x7fffffff; base += 64) {
+                const int j = base + ln;
+                const float v = sp_pooled_tile(row, m, ds, base, tile);
+                const unsigned long long mk = __ballot(j < to && v > mx);
+                if (mk) hit = base + __ffsll((long long)mk) - 1;
+            }
+        };
+        scan(a2, min(e0, max(a2, cov0)));                 // in front of the pooling pass's range
+        if (hit == 0x7fffffff) hit = h.hit;              // inside it
+        if (hit == 0x7fffffff) scan(max(a2, cov1), e0);  // behind it
+        nxt = (hit == 0x7fffffff ? 0 : hit - a2) + s0;
+        if (nxt >= L) valid = false;
+    }
+    if (valid) {
+        o.valid = 1;
+        o.start_peak_idx = (int64_t)h.max_idx * ds; o.start_peak_pa = mx;
+        o.next_greater_idx = (int64_t)nxt * ds; o.next_greater_pa = sp_pooled(row, m, ds, nxt);
+        if (has_op) {
+            if (fabs((double)nxt - (double)op) <= 2.0 + 0.01 * fabs((double)op)) o.flagged_type = 1;
+            else if (h.max_idx < op && op < nxt) o.flagged_type = 2;
             if (o.flagged_type) { o.has_open_pore = 1; o.open_pore_idx = (int64_t)op * ds; }
         }
     }

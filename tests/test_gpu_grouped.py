@@ -153,3 +153,63 @@ def test_cnn_chunks_over_lanes_equal_one_chunk():
     assert sorted(ref[1]) == [4, 40, 100]
     assert np.frombuffer(ref[0], dtype=lib.ROW_DTYPE)["success"].sum() > n // 3
     eng.close()
+
+
+@pytest.mark.parametrize("window", [None, 60000])
+def test_start_peak_riding_the_pooling_pass_equals_the_separate_scan(oracle_mod, window):
+    """K1 (reference adapted/detect/start_peak.py:7-119) inside k_norm_pool + k_sp_head / k_sp_tail against the separate
+    k_start_peak sweep (ADP_SP_FUSED=0) and the oracle: open pores in front of min_obs_adapter, inside the pooled range and
+    behind max_obs_trace, start peaks that nothing exceeds (the scan runs to the read's end), reads shorter than every range,
+    NaN tails with and without ADP_TAILS_NAN."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect, spc.cnn_boundaries.cnn_detect = True, False
+    if window:
+        spc.core.max_obs_trace = window
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m, T = spc.sig_preload_size, spc.core.max_obs_trace
+    n = 96
+    rng = np.random.default_rng(5)
+    lens = np.array([m + 100 if i % 3 == 0 else max(1012, synth.pareto_length(11, i, lo=1200, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    lens[1], lens[2], lens[3] = 1012, 2600, m
+    sig, lens = synth.synth_batch(91, 0, n, m, lens)
+    have = np.minimum(lens, m)
+    for i in range(n):
+        kind = i % 8
+        e = int(have[i]) // 10                      # the open-pore scan looks at raw[:e] only (the reference's quirk)
+        if kind == 1 and e > 40:
+            sig[i, rng.integers(20, min(e, 990))] = 230.0           # open pore in front of min_obs_adapter
+        elif kind == 2 and e > 1100:
+            sig[i, rng.integers(1005, e)] = 230.0                   # ... inside the pooled range
+        elif kind == 3:
+            sig[i, 100:1500] = np.minimum(sig[i, 100:1500], 60.0)   # a low start region: the next block above it comes early
+        elif kind == 4:
+            sig[i, 300:340] = 400.0                                 # a start peak nothing exceeds: the scan runs to the end
+        elif kind == 5 and have[i] > T + 200:
+            sig[i, 300:340] = 180.0
+            sig[i, T + 40: T + 60] = 900.0                          # ... except a block behind max_obs_trace
+        elif kind == 6 and have[i] > 4000:
+            sig[i, 2505:2515] = 300.0                               # the block right at pooled index 250 / 251
+    eng = lib.Engine(spc, n, m, device=0)
+    outs = []
+    for fused in ("1", "0"):
+        for tails in (False, True):
+            os.environ["ADP_SP_FUSED"] = fused
+            try:
+                rows, mbs = eng.detect_llr_rows(sig, lens, n, n // 2, with_start_peak=True, tails_nan=tails)
+            finally:
+                os.environ.pop("ADP_SP_FUSED", None)
+            assert (mbs == 0).all()
+            outs.append(_canon(rows, lib))
+    assert all(o == outs[0] for o in outs[1:])
+    rows = np.frombuffer(outs[0][0], dtype=lib.ROW_DTYPE)
+    assert (rows["start_peak_type"] > 0).sum() >= 4 and (rows["present"] >> 22 & 1).sum() > n // 2   # flags and columns are exercised
+    got = lib.rows_to_results(rows, "llr")
+    for a in (0, n // 2):
+        want = oracle_mod.detect_llr(sig[a:a + n // 2], lens[a:a + n // 2], spc, with_start_peak=True)
+        bad = _rows_equal(got[a:a + n // 2], want)
+        assert not bad, bad[:6]
+    eng.close()
