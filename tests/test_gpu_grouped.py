@@ -180,10 +180,11 @@ def test_start_peak_riding_the_pooling_pass_equals_the_separate_scan(oracle_mod,
     for i in range(n):
         kind = i % 8
         e = int(have[i]) // 10                      # the open-pore scan looks at raw[:e] only (the reference's quirk)
-        if kind == 1 and e > 40:
-            sig[i, rng.integers(20, min(e, 990))] = 230.0           # open pore in front of min_obs_adapter
-        elif kind == 2 and e > 1100:
-            sig[i, rng.integers(1005, e)] = 230.0                   # ... inside the pooled range
+        if kind == 1 and e > 200:
+            sig[i, int(rng.integers(160, min(e, 990)))] = 230.0      # open pore in front of min_obs_adapter
+        elif kind == 2 and e > 1300:
+            p = 10 * int(rng.integers(110, e // 10))
+            sig[i, p: p + 10] = 230.0                               # ... inside the pooled range, a whole block: next-greater block = open pore
         elif kind == 3:
             sig[i, 100:1500] = np.minimum(sig[i, 100:1500], 60.0)   # a low start region: the next block above it comes early
         elif kind == 4:
@@ -206,7 +207,7 @@ def test_start_peak_riding_the_pooling_pass_equals_the_separate_scan(oracle_mod,
             outs.append(_canon(rows, lib))
     assert all(o == outs[0] for o in outs[1:])
     rows = np.frombuffer(outs[0][0], dtype=lib.ROW_DTYPE)
-    assert (rows["start_peak_type"] > 0).sum() >= 4 and (rows["present"] >> 22 & 1).sum() > n // 2   # flags and columns are exercised
+    assert (rows["start_peak_type"] > 0).sum() >= 2 and (rows["present"] >> np.uint64(22) & np.uint64(1)).sum() > n // 2   # flags and columns are exercised
     got = lib.rows_to_results(rows, "llr")
     for a in (0, n // 2):
         want = oracle_mod.detect_llr(sig[a:a + n // 2], lens[a:a + n // 2], spc, with_start_peak=True)
