@@ -621,7 +621,8 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         }
         if (upto >= 2 && sp_fused) {
             { Scope s(h, "k_norm_pool");
-              hipLaunchKernelGGL((k_norm_pool<SIG, true>), dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+              auto kern = (h->ds == 10 && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, true, 5> : k_norm_pool<SIG, true, 0>;
+              hipLaunchKernelGGL(kern, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                  minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
                                  dlen, (flags & ADP_TAILS_NAN) ? 1 : 0, h->sphead.as<SpHead>(), (float)h->cfg.open_pore_pa); }
             const int cov0 = h->off / h->ds, cov1 = cov0 + (T - h->off) / h->ds;
@@ -642,9 +643,10 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
                 HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope; this layout is never grouped)
                 rng = h->rng0.as<int64_t>();
             }
-            hipLaunchKernelGGL(k_norm_pool<SIG>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
+            auto kern = (h->ds == 10 && !rng && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, false, 5> : k_norm_pool<SIG, false, 0>;
+            hipLaunchKernelGGL(kern, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), rng,
-                               dlen, (flags & ADP_TAILS_NAN) ? 1 : 0);
+                               dlen, (flags & ADP_TAILS_NAN) ? 1 : 0, (SpHead *)nullptr, 0.f);
         }
         if (upto >= 2)
             hipLaunchKernelGGL(k_check_empty, dim3((n + 255) / 256), dim3(256), 0, st, h->nvalid.as<int32_t>(), n, minibatch, mbs);

@@ -43,7 +43,9 @@ struct SpHead {
     int32_t pad;
 };
 
-template <class SIG, bool SP = false>
+// NQ > 0 (= 16-byte loads per thread and tile, NP_TILE * ds / 1024): the loads of tile t + 1 are issued before tile t is pooled
+// and stay in flight across its two barriers (NQ = 0: load, barrier, pool, barrier)
+template <class SIG, bool SP = false, int NQ = 0>
 __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int off, int ds, int L, int Lp,
                                                    int mbsize, const MbState *__restrict__ mbs,
                                                    float *__restrict__ down, int32_t *__restrict__ nvalid,
@@ -97,6 +99,26 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
         c = c > hi ? hi : c;
         return fast_div ? fdiv_shared(c - med, mad, rmad) : (c - med) / mad;
     };
+    const bool use_pf = NQ > 0 && vec && tile_n / 4 == NQ * 256;
+    float4 pre[NQ > 0 ? NQ : 1];
+    auto fetch = [&](int tb_) { // the raw samples of tile tb_ into registers (positions behind the segment: zeros, never used as samples)
+        const int base_ = tb_ * ds;
+        const typename SIG::Row rowb = row + base_;
+#pragma unroll
+        for (int u = 0; u < (NQ > 0 ? NQ : 1); u++) {
+            const int q = threadIdx.x + u * 256;
+            const int idx = base_ + 4 * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx + 3 < Lseg) v = rowb.f4s(q);
+            else {
+                if (idx < Lseg) v.x = row[idx];
+                if (idx + 1 < Lseg) v.y = row[idx + 1];
+                if (idx + 2 < Lseg) v.z = row[idx + 2];
+            }
+            pre[u] = v;
+        }
+    };
+    if (use_pf && L_ok > 0 && L > 0) fetch(0);
     for (int tb = 0; tb < L; tb += NP_TILE) {
         const int base = tb * ds;
         if (tb >= L_ok) { // the padding: NaN blocks
@@ -104,7 +126,19 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
             continue;
         }
         __syncthreads();
-        if (vec) {
+        if (use_pf) {
+#pragma unroll
+            for (int u = 0; u < (NQ > 0 ? NQ : 1); u++) {
+                const int q = threadIdx.x + u * 256;
+                const int idx = base + 4 * q;
+                float4 v = pre[u];
+                if (!SP) { // normalised on the way into the tile; the pad behind the segment stays zero (np.pad)
+                    v.x = idx < Lseg ? norm1(v.x) : 0.f; v.y = idx + 1 < Lseg ? norm1(v.y) : 0.f;
+                    v.z = idx + 2 < Lseg ? norm1(v.z) : 0.f; v.w = idx + 3 < Lseg ? norm1(v.w) : 0.f;
+                }
+                reinterpret_cast<float4 *>(tile)[q] = v;
+            }
+        } else if (vec) {
             const typename SIG::Row rowb = row + base;
             for (int q = threadIdx.x; q < tile_n / 4; q += 256) {
                 const int idx = base + 4 * q;
@@ -134,6 +168,7 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
             }
         }
         __syncthreads();
+        if (use_pf) { const int nx = tb + NP_TILE; if (nx < L && nx < L_ok) fetch(nx); }
         for (int jj = threadIdx.x; jj < NP_TILE; jj += 256) {
             const int j = tb + jj;
             if (j < L) {
