@@ -872,5 +872,5 @@ __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int
 
 // (Round 3, measured and dropped: a wave per SHORT read -- numpy-ordered sums and radix selects of wave_stats.h, no workgroup
 // barriers -- for reads of at most 16 k samples.  On Pareto lengths that kernel took 42 ms for the reads it relieved this one of
-// 3 ms for (profiles/r03_partition_small_sweep.txt): a single wave's scalar loads and four-pass selects are far slower per
+// 3 ms for (profiles/r03_tried_and_dropped.txt): a single wave's scalar loads and four-pass selects are far slower per
 // sample than this workgroup's staged passes, however short the segment.)
