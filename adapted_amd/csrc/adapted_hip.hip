@@ -621,7 +621,8 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         }
         if (upto >= 2 && sp_fused) {
             { Scope s(h, "k_norm_pool");
-              auto kern = (h->ds == 10 && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, true, 5> : k_norm_pool<SIG, true, 0>;
+              // (float32 rows only: the int16 rows' conversion pushes the prefetching variant to 112 registers, 4 waves per SIMD -- 24 vs 14 ms)
+              auto kern = (h->ds == 10 && std::is_same<SIG, SigF32>::value && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, true, 5> : k_norm_pool<SIG, true, 0>;
               hipLaunchKernelGGL(kern, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                  minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)nullptr,
                                  dlen, (flags & ADP_TAILS_NAN) ? 1 : 0, h->sphead.as<SpHead>(), (float)h->cfg.open_pore_pa); }
@@ -643,7 +644,7 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
                 HIPCHK(hipStreamSynchronize(st)); // (hr goes out of scope; this layout is never grouped)
                 rng = h->rng0.as<int64_t>();
             }
-            auto kern = (h->ds == 10 && !rng && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, false, 5> : k_norm_pool<SIG, false, 0>;
+            auto kern = (h->ds == 10 && !rng && std::is_same<SIG, SigF32>::value && env_int("ADP_NP_PREFETCH", 1)) ? k_norm_pool<SIG, false, 5> : k_norm_pool<SIG, false, 0>;
             hipLaunchKernelGGL(kern, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, dsig, m, T, h->off, h->ds, h->L, h->Lp,
                                minibatch, mbs, h->down.as<float>(), h->nvalid.as<int32_t>(), rng,
                                dlen, (flags & ADP_TAILS_NAN) ? 1 : 0, (SpHead *)nullptr, 0.f);
