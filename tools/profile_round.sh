@@ -1,10 +1,10 @@
 #!/bin/bash
 # Evidence of a round, collected on the GPU box (run through gpurun from the repository root):
-#   tools/profile_round.sh r02
+#   tools/profile_round.sh r03
 # writes everything under gpurun_out/<tag>_*; the summaries worth keeping are copied to profiles/ by hand afterwards
 # (profiles/summarize_pmc.py, profiles/summarize_sq.py).  Counter passes run on their own (no --stats / trace domains with --pmc).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out
 BENCH="python3 bench.py --steps 6 --warmup 2"
