@@ -91,6 +91,10 @@ struct adp_handle {
     std::vector<hipEvent_t> ev_sync;        // parent: phase-done events of the groups (no timing)
     hipEvent_t ev_start = nullptr;          // parent: inputs staged, arena counter reset
     bool last_grouped = false;
+    // launch attributes already requested through this handle (hipFuncSetAttribute per kernel instantiation and device; kept per
+    // handle -- a handle is used by one thread at a time -- instead of in process-wide statics)
+    unsigned attr_done = 0;
+    size_t lds_series_set = 0;
 };
 
 static int geom(adp_handle *h)
@@ -419,8 +423,8 @@ template <int THREADS, int L0, int LN>
 static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
 {
     typedef CsSharedT<L0, LN> Sh;
-    static bool attr_set = false; // (per instantiation)
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats<THREADS, L0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); attr_set = true; }
+    const unsigned bit = THREADS == 1024 ? 1u : 2u;
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats<THREADS, L0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); h->attr_done |= bit; }
     hipLaunchKernelGGL((k_cand_stats<THREADS, L0, LN>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                        (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
     return 0;
@@ -450,8 +454,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
             Scope s(h, "k_mvs_series_wave");
             auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
             const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 4 * (MS_CHUNK + 4)) * 4; // (two out halves per wave)
-            static size_t lds_set = 0;
-            if (lds > lds_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); lds_set = lds; }
+            if (lds > h->lds_series_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->lds_series_set = lds; }
             hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         }
@@ -1252,8 +1255,8 @@ template <int NT>
 static int launch_conv64(adp_handle *h, const float *in, float *out, const float *w, const float *b, int n, int L1, int Lpad, int tiles)
 {
     const size_t lds = (size_t)2 * CNN_C * (64 * NT + 8) * 4;
-    static bool attr_set = false; // (per instantiation; the attribute belongs to the function, not to the handle)
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+    const unsigned bit = 4u << (NT - 2);
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
     long long total = (long long)n * tiles;
     int grid = (int)(total < h->n_cu ? total : h->n_cu);
     hipLaunchKernelGGL(k_cnn_conv64<NT>, dim3(grid), dim3(256), lds, h->stream, in, out, w, b, n, L1, Lpad, tiles);
