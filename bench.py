@@ -454,7 +454,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload shape, where one was taken (else null)
         traffic = None
         shape = None
-        if w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and NS == 1:
+        if w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and NS == 1 and os.environ.get("ADP_GROUPS", "1") == "1":
             shape = "int16" if getattr(w, "int16", False) else "f32"
         tnames = {"f32": ("r03_traffic.json", "r02_traffic.json"), "int16": ("r03_traffic_int16.json", "r02_traffic_int16.json")}.get(shape, ())
         for tname in tnames:
