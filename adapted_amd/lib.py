@@ -499,21 +499,14 @@ class Engine:
         return self.attach_open_pores(rows), mbs
 
     def detect_start_peak_rows(self, signals, full_lens, n: int, minibatch: int, device_ptrs: bool = False):
-        """one library call per minibatch (the pandas float-column quirk couples the reads of a minibatch, and the open-pore
-        arena belongs to one call)"""
-        parts = []
-        for s0 in range(0, n, minibatch):
-            k = min(minibatch, n - s0)
-            if device_ptrs:
-                sp, lp, flags, keep = self._in_ptrs(int(signals) + s0 * self.m * 4, int(full_lens) + s0 * 4, k, True)
-            else:
-                sp, lp, flags, keep = self._in_ptrs(signals[s0:s0 + k], full_lens[s0:s0 + k], k, False)
-            rows = np.zeros(k, dtype=ROW_DTYPE)
-            self._check(self.lib.adp_detect_start_peak(self._h, sp, lp, int(k), self.m, int(minibatch), flags,
-                                                       rows.ctypes.data_as(C.c_void_p)))
-            del keep
-            parts.append(self.attach_open_pores(rows))
-        return parts[0] if len(parts) == 1 else np.concatenate(parts)
+        """adp_detect_start_peak over n reads in ONE library call: the pandas float-column quirk couples the reads of a minibatch
+        (the library walks the minibatches), the open-pore arena belongs to the call (offsets of every minibatch index it)"""
+        sp, lp, flags, keep = self._in_ptrs(signals, full_lens, n, device_ptrs)
+        rows = np.zeros(n, dtype=ROW_DTYPE)
+        self._check(self.lib.adp_detect_start_peak(self._h, sp, lp, int(n), self.m, int(minibatch), flags,
+                                                   rows.ctypes.data_as(C.c_void_p)))
+        del keep
+        return self.attach_open_pores(rows)
 
     def validate_rows(self, signals, full_lens, n: int, bounds: np.ndarray, device_ptrs: bool = False,
                       topk_none: bool = False):

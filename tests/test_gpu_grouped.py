@@ -214,3 +214,37 @@ def test_start_peak_riding_the_pooling_pass_equals_the_separate_scan(oracle_mod,
         bad = _rows_equal(got[a:a + n // 2], want)
         assert not bad, bad[:6]
     eng.close()
+
+
+def test_start_peak_primary_several_minibatches_in_one_call_share_one_arena(oracle_mod):
+    """adp_detect_start_peak with n_reads > minibatch: ONE open-pore arena for the call -- the overflow lists of reads in the first
+    minibatch must still be there (and at their offsets) when the call returns (launch_validate used to reset the
+    arena per minibatch).  Rows equal the minibatch-by-minibatch calls and the oracle."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect = spc.cnn_boundaries.cnn_detect = False
+    spc.rna_start_peak.detect_rna_start_peak = True
+    spc.mvs_polya.mvs_detect_check = False
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m = spc.sig_preload_size
+    mb, n = 24, 72
+    sig, lens = synth.synth_batch(55, 0, n, m, np.full(n, m, dtype=np.int32))
+    for r, cnt in ((3, 30), (30, 22), (50, 41), (71, 18)):   # more open pores than a row holds, in all three minibatches
+        for j in range(cnt):
+            sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
+    eng = lib.Engine(spc, n, m, device=0)
+    rows = eng.detect_start_peak_rows(sig, lens, n, mb)
+    one = _canon(rows, lib)
+    parts = [eng.detect_start_peak_rows(sig[a:a + mb], lens[a:a + mb], mb, mb) for a in range(0, n, mb)]
+    per = _canon(np.concatenate(parts), lib)
+    assert one == per
+    assert sorted(one[1]) == [3, 30, 50, 71] and [len(one[1][k]) for k in (3, 30, 50, 71)] == [30, 22, 41, 18]
+    got = lib.rows_to_results(rows, "start_peak")
+    for a in range(0, n, mb):
+        want = oracle_mod.detect_start_peak(sig[a:a + mb], lens[a:a + mb], spc)
+        bad = _rows_equal(got[a:a + mb], want)
+        assert not bad, bad[:6]
+    eng.close()
