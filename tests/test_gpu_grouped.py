@@ -241,7 +241,7 @@ def test_start_peak_primary_several_minibatches_in_one_call_share_one_arena(orac
     parts = [eng.detect_start_peak_rows(sig[a:a + mb], lens[a:a + mb], mb, mb) for a in range(0, n, mb)]
     per = _canon(np.concatenate(parts), lib)
     assert one == per
-    assert sorted(one[1]) == [3, 30, 50, 71] and [len(one[1][k]) for k in (3, 30, 50, 71)] == [30, 22, 41, 18]
+    assert sorted(one[1]) == [3, 30, 50, 71] and [len(one[1][k]) for k in (3, 30, 50, 71)] == [29, 21, 40, 17]  # (find_open_pores never keeps the first position: reference anomalies.py:15-35)
     got = lib.rows_to_results(rows, "start_peak")
     for a in range(0, n, mb):
         want = oracle_mod.detect_start_peak(sig[a:a + mb], lens[a:a + mb], spc)
