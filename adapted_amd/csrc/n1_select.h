@@ -27,6 +27,12 @@
 
 #define N1_CB_LDS 4096          // per-block staging of bracket keys (flushed after every row)
 #define N1_CB_CAP (1u << 22)    // bracket keys kept per minibatch
+// half width of the sampled rank brackets in standard deviations of an independent sample (round 3: 4.5 -> 6; the sample is
+// clustered -- pieces of 96 consecutive samples -- and 1 of 96 Pareto-length minibatches missed its median bracket at 4.5, which
+// costs that minibatch three more passes; the wider bracket copies a third more of the ~1.5 % of samples it copies)
+#ifndef N1_BRACKET_SIGMAS
+#define N1_BRACKET_SIGMAS 6.0
+#endif
 #define N1_NCNT 8               // u64 counters per minibatch: n_valid, below window, below bracket, bracket count, overflow
 
 enum { N1_ALWAYS = 0, N1_IF_BAD = 1, N1_IF_NOT_DONE = 2 };
@@ -274,9 +280,12 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
         // and the bracket is only a good bet; whether it held is verified exactly after pass 1
         const unsigned long long tot = s_total;
         const unsigned long long Ms = st.n_valid; // sample size
-        // (4.5 sigma: with every read in the sample the clustering is that of positions inside a read only; a bracket
-        // that misses costs the multi-pass selection, never the result)
-        const unsigned long long D = (unsigned long long)(4.5 * sqrt((double)Ms)) + 16ull;
+        // (with every read in the sample the clustering is that of positions inside a read only; a bracket that misses
+        // costs the multi-pass selection, never the result)
+        // ... as wide as the lists allow: the fused pass copies about 2 D x 32 samples (the sample is a 32nd of the minibatch)
+        // into a median list of N1_CB_CAP / 4 entries; at the 200 k window that caps D near 4.6 sigma
+        unsigned long long D = (unsigned long long)(N1_BRACKET_SIGMAS * sqrt((double)Ms)) + 16ull;
+        { const unsigned long long dcap = (unsigned long long)(N1_CB_CAP / 4) * 7ull / 10ull / 64ull; if (D > dcap) D = dcap; }
         const bool cut = miss || krel < D || krel + D >= tot; // the bracket would be cut off by the window: no bracket
         const unsigned long long rlo = krel > D ? krel - D : 0ull;
         unsigned long long rhi = krel + D;
