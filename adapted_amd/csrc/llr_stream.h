@@ -177,7 +177,8 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
                 if (SP) {
                     // (only the ragged last block holds pad marks: -inf never is a sample's value there, the range test says so)
                     const int nin = Lseg - j * ds; // samples of this block inside the segment (>= ds for a complete block)
-                    s = pw_leaf_f32(ds, [&](int k) { return k < nin ? norm1(p[k]) : 0.0f; });
+                    if (nin >= ds) s = pw_leaf_f32(ds, [&](int k) { return norm1(p[k]); });
+                    else s = pw_leaf_f32(ds, [&](int k) { return k < nin ? norm1(p[k]) : 0.0f; });
                     if (j < sp_full) {
                         const int g = sp_pb0 + j;
                         if (g >= sp_a2 && g < sp_e0) {
