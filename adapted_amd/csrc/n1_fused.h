@@ -223,12 +223,14 @@ static __device__ __forceinline__ uint32_t n1f_count(float x, float med_s, float
 {
     const float u = x - med_s;
     const float t = fabsf(u);
-    const bool below = u < A0;
-    const bool inner = t < D0;
-    a.nvalid += (t == t) ? 1u : 0u;
-    a.nbelow += below ? 1u : 0u;
-    a.ninner += inner ? 1u : 0u;
-    const bool take = inner ? (!below && u < A1) : (t <= D1); // (a NaN takes neither branch's condition)
+    // pure mask arithmetic (no selects between conditions: the compiler turned `inner ? ... : ...` into exec-masked branches per
+    // sample).  The median bracket lies inside the inner zone (k_n1_fuse_setup: eps < D0), so [A0, A1) needs no `inner` test.
+    const bool valid = t == t;
+    const bool ge0 = u >= A0, lt1 = u < A1, ged = t >= D0, led = t <= D1;
+    a.nvalid += valid ? 1u : 0u;
+    a.nbelow += (valid & !ge0) ? 1u : 0u;
+    a.ninner += (valid & !ged) ? 1u : 0u;
+    const bool take = (ge0 & lt1) | (ged & led); // (every comparison is false for a NaN)
     return take ? 1u : 0u;
 }
 // the copy itself: median bracket -> first list, MAD band -> second
