@@ -1708,6 +1708,8 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
               HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost)); return ADP_OK; }
     default: return ADP_ERR_INVALID;
     }
+    // (the stage buffers belong to the plain pipeline: a grouped call keeps them in its lanes, a handle that has not run the LLR path has none)
+    if (!src || (what != 0 && h->last_grouped)) { g_err = "no stage buffers of a plain (one-group) LLR call on this handle"; return ADP_ERR_INVALID; }
     HIPCHK(hipMemcpyAsync(host_out, src, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (what == 0) HIPCHK(hipMemsetAsync(h->ghist.p, 0, (size_t)h->last_nmb * 32, h->stream));
