@@ -379,3 +379,46 @@ def test_adapted_console_script_is_declared():
     main = getattr(importlib.import_module(mod), fn)
     p = __import__("adapted_amd.main", fromlist=["build_parser"]).build_parser()
     assert callable(main) and {"detect", "continue"} <= set(p._subparsers._group_actions[0].choices)
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """adapted_amd.lib.load() before OR after `import torch` leaves exactly one libamdhip64 mapped (the torch wheel bundles a
+    runtime with the SONAME this library links: INTEGRATION.md section 3); ADAPTED_HIP_RUNTIME=system keeps /opt/rocm's."""
+    import subprocess
+    import sys
+
+    def run(code, **env):
+        e = dict(os.environ, PYTHONPATH=ROOT, **env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.strip().splitlines()[-1]
+
+    first = run("from adapted_amd import lib; lib.load(); import torch; print(len(lib.hip_runtimes()), lib.hip_runtimes())")
+    after = run("import torch; from adapted_amd import lib; lib.load(); print(len(lib.hip_runtimes()), lib.hip_runtimes())")
+    assert first.startswith("1 ") and after.startswith("1 "), (first, after)
+    if "torch" in after:  # a wheel with a bundled runtime: both orders end on it
+        assert "torch" in first
+    system = run("from adapted_amd import lib; lib.load(); print(len(lib.hip_runtimes()), lib.hip_runtimes())", ADAPTED_HIP_RUNTIME="system")
+    assert system.startswith("1 ") and "torch" not in system, system
+
+
+def test_cpu_baseline_worker_count_follows_mask_and_quota(monkeypatch):
+    """bench.py's all-cores CPU baseline: every CPU the affinity mask and the cgroup quota grant, the documented 16-CPU share of a
+    one-GPU lease only where neither restricts a big host, an explicit --cpu-procs above all"""
+    import bench
+
+    def grant(aff, quota):
+        monkeypatch.setattr(bench, "cpu_grant", lambda: {"affinity_cpus": aff, "cgroup_cpu_max": "x", "cgroup_cpus": quota})
+
+    grant(256, 16.0)
+    assert bench.cpu_worker_count(None) == (16, "cgroup cpu.max")
+    grant(8, None)
+    assert bench.cpu_worker_count(None)[0] == 8
+    grant(256, None)
+    n, why = bench.cpu_worker_count(None)
+    assert n == 16 and "unrestricted" in why
+    grant(32, 48.0)
+    assert bench.cpu_worker_count(None) == (32, "affinity mask")
+    assert bench.cpu_worker_count(5) == (5, "--cpu-procs")
+    g = bench.cpu_grant.__wrapped__() if hasattr(bench.cpu_grant, "__wrapped__") else None
+    assert g is None or g["affinity_cpus"] >= 1
