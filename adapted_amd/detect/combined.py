@@ -118,7 +118,8 @@ def combined_detect_start_peak(batch_of_signals: np.ndarray, full_signal_lens: n
         return []
     eng = get_engine(spc, n, m, device)
     rows = eng.detect_start_peak_rows(sig, lens, n, n)
-    return lib.rows_to_results(rows, "start_peak", consume=True)
+    res = lib.rows_to_results(rows, "start_peak", consume=True)
+    return lib.open_pore_float_column(res)
 
 
 def validate_boundaries(signal: np.ndarray, boundaries: Boundaries, spc, full_signal_len: int,

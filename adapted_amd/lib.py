@@ -310,6 +310,19 @@ def rows_to_results(rows: np.ndarray, primary: str, consume: bool = False) -> Li
     return out
 
 
+def open_pore_float_column(results: List[DetectResults]) -> List[DetectResults]:
+    """The start-peak primary's results of ONE minibatch as the reference returns them: detect_rna_start_peak keeps `open_pore_idx`
+    in a DataFrame column (adapted/detect/start_peak.py:86-116) and combined_detect_start_peak copies the cell (combined.py:337) --
+    all None: every row keeps None; one flagged read in the minibatch: the column is float64, the flagged rows read back as
+    floats, the others as NaN.  (The CSV text is the same either way.)  Pinned by tests/golden/rna004_start_peak_200k."""
+    if any(r.start_peak_open_pore_idx is not None for r in results):
+        for r in results:
+            if r.signal_len is None and r.start_peak_idx is None:
+                continue  # (a row that only carries a raised exception)
+            r.start_peak_open_pore_idx = float(r.start_peak_open_pore_idx) if r.start_peak_open_pore_idx is not None else float("nan")
+    return results
+
+
 class Engine:
     """One GPU's detect engine: a handle of libadapted_hip.so sized for (max_reads, m)."""
 

@@ -239,7 +239,21 @@ def detect_start_peak(batch, full_lens, spc):
     rows = np.zeros(n, dtype=ROW_DTYPE)
     L.orc_detect_start_peak_minibatch(bp, lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_long(n), C.c_long(m),
                                       C.byref(cfg), rows.ctypes.data_as(C.c_void_p))
-    return rows_to_dicts(rows, "start_peak")
+    return open_pore_float_column(rows_to_dicts(rows, "start_peak"))
+
+
+def open_pore_float_column(rows):
+    """detect_rna_start_peak collects `open_pore_idx` in a DataFrame column (reference adapted/detect/start_peak.py:86-116): all
+    None -> an object column, every row keeps None; as soon as ONE read of the minibatch has a flagged open pore the column is
+    float64 -- the flagged rows read back as floats (1540.0), the others as NaN (combined.py:337 copies the cell).  Pinned by
+    tests/golden/rna004_start_peak_200k (read 19 flagged, 19 reads NaN).  Rows of raised exceptions hold nothing."""
+    key = "start_peak_open_pore_idx"
+    if any(r.get(key) is not None for r in rows):
+        for r in rows:
+            if r.get("_exception"):
+                continue
+            r[key] = float(r[key]) if r.get(key) is not None else float("nan")
+    return rows
 
 
 def start_peak_table(batch, full_lens, spc):

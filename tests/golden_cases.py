@@ -34,6 +34,10 @@ CASES = {
     "rna004_start_peak_full": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=18,
                                    first=0, n=64, lens="full", minibatch=64, dump=[],
                                    mvs_detect_check=False, detect_med_shift=True),
+    # the start-peak primary at the north-star window (m = 201500): K1's scan behind max_obs_trace, end_idx = min(len, m) // 10
+    "rna004_start_peak_200k": dict(chem="RNA004", primary="start_peak", max_obs_trace=200000, seed=29,
+                                   first=3000, n=20, lens="long200", minibatch=20, dump=[],
+                                   mvs_detect_check=False, detect_med_shift=True),
     # start-peak primary with the preset's mvs check left on: polya_end_topk is None -> TypeError
     "rna004_start_peak_mvs": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=19,
                                   first=0, n=16, lens="full", minibatch=16, dump=[]),
@@ -96,6 +100,8 @@ def resolve_lens(spec, n, m):
         return [m] * n
     if spec == "mixed200":
         pat = ["m", "m+5000", 150000, "m", 60000, "m", 9000, "m", 1012, "m"]
+    elif spec == "long200":  # every read long enough for a start-peak row (a None row turns the whole minibatch into TypeErrors)
+        pat = ["m", "m+5000", 150000, "m", 60000, "m", 30000, "m", 21000, "m"]
     elif spec == "mixed200cnn":
         pat = ["m", "m+5000", 150000, 9000, 60000, "m", 12000, "m", 1012, 11000, "m", 7500]
     elif spec == "mixed002":  # RNA002: min_obs_adapter=2000, ds=20 -> need >= 2020 samples

@@ -245,6 +245,6 @@ def test_start_peak_primary_several_minibatches_in_one_call_share_one_arena(orac
     got = lib.rows_to_results(rows, "start_peak")
     for a in range(0, n, mb):
         want = oracle_mod.detect_start_peak(sig[a:a + mb], lens[a:a + mb], spc)
-        bad = _rows_equal(got[a:a + mb], want)
+        bad = _rows_equal(lib.open_pore_float_column(got[a:a + mb]), want)
         assert not bad, bad[:6]
     eng.close()
