@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness  # noqa: E402
 
 import numpy as np  # noqa: E402
-from golden_cases import CASES, apply_blips, apply_overrides, resolve_lens  # noqa: E402
+from golden_cases import CASES, apply_blips, apply_extra, apply_overrides, apply_quantise, resolve_lens  # noqa: E402
 
 _spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "adapted_amd", "synth.py"))
 synth = importlib.util.module_from_spec(_spec)
@@ -88,6 +88,8 @@ def run_case(name, case):
     lens = np.asarray(resolve_lens(case["lens"], n, m), dtype=np.int32)
     sig, lens = synth.synth_batch(case["seed"], case["first"], n, m, lens)
     apply_blips(sig, case)
+    apply_extra(sig, lens, case)
+    apply_quantise(sig, case)
     mb = case["minibatch"]
     results = []
     model = None

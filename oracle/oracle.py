@@ -403,8 +403,15 @@ def cnn_predict(scores, spc):
     a = np.argmax(scores[:, 0, :na], axis=1)
     k = spc.cnn_boundaries.polya_cand_k
     ar = np.arange(Lo)[None, :]
-    scores[:, 1, :][ar < a[:, None]] = -5.0
-    p = np.argmax(scores[:, 1, :], axis=1)
+    if k >= 1:  # (cnn.py:126-134; k < 1: no poly(A) search at all)
+        scores[:, 1, :][ar < a[:, None]] = -5.0
+        p = np.argmax(scores[:, 1, :], axis=1)
+    else:
+        p = np.zeros(n, dtype=np.int64)
+    if k <= 1:  # (cnn.py:160: the plain pair, no find_peaks, no row compaction -- pinned by tests/golden/rna004_cnn_k1)
+        preds = (np.column_stack((a, p)) * co.downscale_factor + co.min_obs_adapter).astype(int)
+        preds[preds == co.min_obs_adapter] = 0
+        return preds
     scores[:, 1, :][ar > p[:, None]] = -5.0
     flat = scores[:, 1, :].reshape(-1)
     cand, _ = find_peaks(flat, distance=5)

@@ -61,6 +61,34 @@ CASES = {
     # prints has no length limit (23 and 39 entries here, beside reads with 15, 16, 1, 0)
     "rna004_llr_open_pores": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=23, first=0, n=24, lens="full",
                                   minibatch=24, dump=[], blips=[24, 17, 16, 40, 2, 1]),
+    # ---- round 3: more of the reference's behaviour pinned (each case run through the real reference) ----
+    # samples on an ADC-like grid (0.18 pA): thousands of ties in every median / percentile / MAD (numpy's tie rules), heavy keys in N1
+    "rna004_llr_quantised": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=31, first=0, n=64, lens="mixed",
+                                 minibatch=64, dump=[0], quantise=0.18),
+    "rna004_llr_200k_quantised": dict(chem="RNA004", primary="llr", max_obs_trace=200000, seed=32, first=500, n=8, lens="mixed200",
+                                      minibatch=8, dump=[], quantise=0.18),
+    # RNA002 (ds = 20, adapter_peak_width 1500) at the 200 k window
+    "rna002_llr_200k": dict(chem="RNA002", primary="llr", max_obs_trace=200000, seed=33, first=0, n=8, lens="mixed200b",
+                            minibatch=8, dump=[0]),
+    # a pooling factor that divides neither the window nor min_obs_adapter (ragged last block, np.pad zeros), lower peak thresholds,
+    # the median-shift check on, open-pore detection off
+    "rna004_llr_ds7": dict(chem="RNA004", primary="llr", max_obs_trace=12345, seed=34, first=0, n=48, lens="mixed", minibatch=48,
+                           dump=[0, 2],
+                           override={"core.downscale_factor": 7, "llr_boundaries.adapter_peak_prominence": 0.7,
+                                     "llr_boundaries.adapter_peak_rel_height": 0.8, "med_shift.detect_med_shift": True,
+                                     "real_range.detect_open_pores": False}),
+    # open pores close to the adapter end and inside the poly(A) tail, the real-range check off
+    "rna004_llr_open_pores_near_end": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=35, first=0, n=32, lens="full",
+                                           minibatch=32, dump=[], blips_at="adapter_end",
+                                           override={"real_range.real_signal_check": False}),
+    # start-peak primary with flagged open pores at the default window (the float-column quirk again, several flagged reads)
+    "rna004_start_peak_blips": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=36, first=0, n=32, lens="full",
+                                    minibatch=32, dump=[], mvs_detect_check=False, detect_med_shift=True, start_blips=True),
+    # CNN primary with fewer candidates and without the short-read fallback
+    "rna004_cnn_k3": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=37, first=100, n=32, lens="mixed", minibatch=32,
+                          dump=[0], override={"cnn_boundaries.polya_cand_k": 3, "cnn_boundaries.fallback_to_llr_short_reads": False}),
+    "rna004_cnn_k1": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=38, first=200, n=24, lens="mixed", minibatch=24,
+                          dump=[0], override={"cnn_boundaries.polya_cand_k": 1}),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
@@ -69,6 +97,37 @@ CASES = {
     "rna004_cnn_200k": dict(chem="RNA004", primary="cnn", max_obs_trace=200000, seed=27,
                             first=2000, n=12, lens="mixed200cnn", minibatch=12, dump=[0, 2]),
 }
+
+
+def apply_quantise(sig, case):
+    """case["quantise"]: every sample rounded to a multiple of this many pA (float32 arithmetic, NaN padding kept)"""
+    q = case.get("quantise")
+    if not q:
+        return sig
+    import numpy as np
+
+    q = np.float32(q)
+    np.divide(sig, q, out=sig)
+    np.round(sig, out=sig)
+    np.multiply(sig, q, out=sig)
+    return sig
+
+
+def apply_extra(sig, lens, case):
+    """case["blips_at"] = "adapter_end": 3-sample 260 pA spikes around where the synthetic adapter ends and into the poly(A) tail
+    (reads differ: read i gets them at 2400 + 137 i mod 2600 and 40 / 400 samples further);
+    case["start_blips"]: a 12-sample 230 pA block in the first 2000 samples of every third read (flagged open pores of K1)"""
+    if case.get("blips_at") == "adapter_end":
+        for i in range(sig.shape[0]):
+            p = 2400 + (137 * i) % 2600
+            for d in (0, 40, 400):
+                if p + d + 3 < sig.shape[1]:
+                    sig[i, p + d: p + d + 3] = 260.0
+    if case.get("start_blips"):
+        for i in range(0, sig.shape[0], 3):
+            p = 10 * (30 + (7 * i) % 150)
+            sig[i, p: p + 12] = 230.0
+    return sig
 
 
 def apply_blips(sig, case):
@@ -100,6 +159,8 @@ def resolve_lens(spec, n, m):
         return [m] * n
     if spec == "mixed200":
         pat = ["m", "m+5000", 150000, "m", 60000, "m", 9000, "m", 1012, "m"]
+    elif spec == "mixed200b":  # RNA002: min_obs_adapter = 2000, ds = 20
+        pat = ["m", "m+5000", 150000, "m", 60000, 9000, "m", 2025]
     elif spec == "long200":  # every read long enough for a start-peak row (a None row turns the whole minibatch into TypeErrors)
         pat = ["m", "m+5000", 150000, "m", 60000, "m", 30000, "m", 21000, "m"]
     elif spec == "mixed200cnn":

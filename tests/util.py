@@ -7,7 +7,7 @@ import numpy as np
 
 from adapted_amd import synth
 from adapted_amd.config import get_chemistry_specific_config
-from golden_cases import CASES, apply_blips, apply_overrides, resolve_lens
+from golden_cases import CASES, apply_blips, apply_extra, apply_overrides, apply_quantise, resolve_lens
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -50,6 +50,8 @@ def load_case(name):
     assert list(lens) == resolve_lens(case["lens"], case["n"], m)
     sig, _ = synth.synth_batch(case["seed"], case["first"], case["n"], m, lens)
     apply_blips(sig, case)
+    apply_extra(sig, lens, case)
+    apply_quantise(sig, case)
     return case, spc, sig, lens, g["rows"]
 
 
