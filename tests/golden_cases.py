@@ -89,6 +89,35 @@ CASES = {
                           dump=[0], override={"cnn_boundaries.polya_cand_k": 3, "cnn_boundaries.fallback_to_llr_short_reads": False}),
     "rna004_cnn_k1": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=38, first=200, n=24, lens="mixed", minibatch=24,
                           dump=[0], override={"cnn_boundaries.polya_cand_k": 1}),
+    # odd moving windows, other window lengths everywhere, a tighter outlier clip
+    "rna004_llr_windows": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=41, first=0, n=48, lens="mixed", minibatch=48, dump=[],
+                               override={"mvs_polya.pA_var_window": 101, "mvs_polya.pA_mean_window": 21, "mvs_polya.polyA_window": 250,
+                                         "mvs_polya.median_shift_window": 1500, "mvs_polya.search_window": 700,
+                                         "real_range.mean_window": 250, "real_range.max_obs_local_range": 3000,
+                                         "core.sig_norm_outlier_thresh": 3.0}),
+    # the whole signal scaled and shifted (x * 0.9 - 30): other medians, range gates that fail, values near zero
+    "rna004_llr_affine": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=42, first=0, n=32, lens="mixed", minibatch=32, dump=[0],
+                              affine=(0.9, -30.0)),
+    # constant stretches: zero variances inside the LLR (log 0 = -inf, inf - inf = NaN in the traces), ties in every statistic
+    "rna004_llr_flat": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=43, first=0, n=32, lens="full", minibatch=32, dump=[0, 1],
+                            flat=True),
+    # minibatches of one and two reads
+    "rna004_llr_tiny": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=44, first=0, n=3, lens="full", minibatch=2, dump=[]),
+    # tighter real-range gates: other failure reasons
+    "rna004_llr_gates": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=45, first=0, n=64, lens="mixed", minibatch=64, dump=[],
+                             override={"real_range.local_range": (12.0, 25.0), "real_range.adapter_mad_range": (4.0, 9.0),
+                                       "real_range.mean_start_range": (60.0, 95.0), "med_shift.detect_med_shift": True,
+                                       "med_shift.med_shift_range": (12.0, None)}),
+    # start-peak primary with other offsets and a low open-pore level (many flagged reads); and on the RNA002 preset
+    "rna004_start_peak_params": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=46, first=0, n=32, lens="full",
+                                     minibatch=32, dump=[], mvs_detect_check=False, detect_med_shift=True,
+                                     override={"rna_start_peak.offset1": 5, "rna_start_peak.offset2": 50,
+                                               "rna_start_peak.start_peak_max_idx": 120, "rna_start_peak.open_pore_pa": 118.0}),
+    "rna002_start_peak": dict(chem="RNA002", primary="start_peak", max_obs_trace=None, seed=47, first=0, n=24, lens="full",
+                              minibatch=24, dump=[], mvs_detect_check=False, detect_med_shift=True),
+    # CNN primary with a shorter adapter range (the arg-max window, the fallback's length threshold) and a longer min_obs_polya
+    "rna004_cnn_adapter_range": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=48, first=300, n=32, lens="mixed", minibatch=32,
+                                     dump=[0], override={"core.max_obs_adapter": 4000, "core.min_obs_polya": 300}),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
@@ -123,6 +152,23 @@ def apply_extra(sig, lens, case):
             for d in (0, 40, 400):
                 if p + d + 3 < sig.shape[1]:
                     sig[i, p + d: p + d + 3] = 260.0
+    if case.get("affine"):
+        import numpy as np
+
+        a, b = case["affine"]
+        np.multiply(sig, np.float32(a), out=sig)
+        np.add(sig, np.float32(b), out=sig)
+    if case.get("flat"):
+        for i in range(sig.shape[0]):
+            k = i % 4
+            if k == 0:
+                sig[i, 1000:1600] = sig[i, 1000]           # constant right behind min_obs_adapter: zero head variances
+            elif k == 1:
+                sig[i, 2000:2000 + 40 * (i + 1)] = 80.0    # a plateau inside the adapter
+            elif k == 2:
+                sig[i, -3000:] = sig[i, -3000]             # constant tail: zero tail variances, RNA statistics full of ties
+            else:
+                sig[i, 4000:9000] = 108.0                  # a constant poly(A)-like stretch
     if case.get("start_blips"):
         for i in range(0, sig.shape[0], 3):
             p = 10 * (30 + (7 * i) % 150)
