@@ -118,6 +118,11 @@ CASES = {
     # CNN primary with a shorter adapter range (the arg-max window, the fallback's length threshold) and a longer min_obs_polya
     "rna004_cnn_adapter_range": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=48, first=300, n=32, lens="mixed", minibatch=32,
                                      dump=[0], override={"core.max_obs_adapter": 4000, "core.min_obs_polya": 300}),
+    # mvs_polya.pA_mean_range is derived PER READ from that read's adapter median: validate_boundaries works on a deep copy of the
+    # config (combined.py:359) -- read 0 scaled by 1.10 so that a range kept from it (1.3 x 88 pA) would fail the other reads' poly(A)
+    # means (108 pA): it does not
+    "rna004_llr_first_read_range": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=51, first=0, n=64, lens="full", minibatch=32,
+                                        dump=[], first_read_scale=1.10),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
@@ -152,6 +157,10 @@ def apply_extra(sig, lens, case):
             for d in (0, 40, 400):
                 if p + d + 3 < sig.shape[1]:
                     sig[i, p + d: p + d + 3] = 260.0
+    if case.get("first_read_scale"):
+        import numpy as np
+
+        np.multiply(sig[0], np.float32(case["first_read_scale"]), out=sig[0])
     if case.get("affine"):
         import numpy as np
 
