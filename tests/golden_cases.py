@@ -123,6 +123,30 @@ CASES = {
     # means (108 pA): it does not
     "rna004_llr_first_read_range": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=51, first=0, n=64, lens="full", minibatch=32,
                                         dump=[], first_read_scale=1.10),
+    # min_obs_adapter and max_obs_trace that are no multiples of the pooling factor; extreme pooling factors
+    "rna004_llr_minobs1005": dict(chem="RNA004", primary="llr", max_obs_trace=15555, seed=52, first=0, n=32, lens="mixed_b", minibatch=32,
+                                  dump=[0], override={"core.min_obs_adapter": 1005}),
+    "rna004_llr_ds3": dict(chem="RNA004", primary="llr", max_obs_trace=7000, seed=53, first=0, n=24, lens="mixed", minibatch=24, dump=[0],
+                           override={"core.downscale_factor": 3}),
+    "rna004_llr_ds32": dict(chem="RNA004", primary="llr", max_obs_trace=40000, seed=54, first=0, n=16, lens="mixed_b", minibatch=16, dump=[0],
+                            override={"core.downscale_factor": 32}),
+    # every MVS range given explicitly, with lower AND upper bounds
+    "rna004_llr_ranges": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=55, first=0, n=64, lens="mixed", minibatch=64, dump=[],
+                              override={"mvs_polya.pA_mean_range": (100.0, 116.0), "mvs_polya.pA_var_range": (2.0, 15.0),
+                                        "mvs_polya.median_shift_range": (15.0, 40.0), "mvs_polya.polyA_local_range": (1.0, 12.0),
+                                        "mvs_polya.polyA_med_range": (100.0, 115.0)}),
+    # the MVS check off, the median-shift check on
+    "rna004_llr_no_mvs": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=56, first=0, n=48, lens="mixed", minibatch=48, dump=[],
+                              mvs_detect_check=False, detect_med_shift=True),
+    # CNN primary with neither pA_mean_range nor its adapter-median scale given: "pA_mean_range is not specified" per read
+    "rna004_cnn_no_mean_range": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=57, first=0, n=16, lens="mixed", minibatch=16,
+                                     dump=[0], override={"mvs_polya.pA_mean_adapter_med_scale_range": (None, None)}),
+    # a narrower adapter peak (width 400 samples)
+    "rna004_llr_peak_width": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=58, first=0, n=48, lens="mixed", minibatch=48, dump=[0],
+                                  override={"llr_boundaries.adapter_peak_width": 400}),
+    # NaN holes INSIDE reads (the loader never makes them; numpy's NaN rules everywhere)
+    "rna004_llr_nan_holes": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=59, first=0, n=24, lens="full", minibatch=24, dump=[],
+                                 nan_holes=True),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
@@ -157,6 +181,19 @@ def apply_extra(sig, lens, case):
             for d in (0, 40, 400):
                 if p + d + 3 < sig.shape[1]:
                     sig[i, p + d: p + d + 3] = 260.0
+    if case.get("nan_holes"):
+        import numpy as np
+
+        for i in range(sig.shape[0]):
+            k = i % 6
+            if k == 1:
+                sig[i, 5003:5011] = np.nan            # inside the RNA part, inside the LLR window
+            elif k == 2:
+                sig[i, 1500:1504] = np.nan            # inside the adapter
+            elif k == 3:
+                sig[i, 17000:17003] = np.nan          # behind max_obs_trace
+            elif k == 4:
+                sig[i, 400:402] = np.nan              # in front of min_obs_adapter
     if case.get("first_read_scale"):
         import numpy as np
 
@@ -214,6 +251,8 @@ def resolve_lens(spec, n, m):
         return [m] * n
     if spec == "mixed200":
         pat = ["m", "m+5000", 150000, "m", 60000, "m", 9000, "m", 1012, "m"]
+    elif spec == "mixed_b":  # like "mixed" without the reads that leave no pooled block behind a larger min_obs_adapter / pooling factor
+        pat = ["m", "m+5000", 30000, "m", 8000, "m", 3000, 1500, "m", 1100, 600000, 5400, "m", 12345]
     elif spec == "mixed200b":  # RNA002: min_obs_adapter = 2000, ds = 20
         pat = ["m", "m+5000", 150000, "m", 60000, 9000, "m", 2025]
     elif spec == "long200":  # every read long enough for a start-peak row (a None row turns the whole minibatch into TypeErrors)
