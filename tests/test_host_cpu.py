@@ -93,7 +93,8 @@ def _results_from_golden(name):
     return out
 
 
-@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k"])
+@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k",
+                                  "rna004_start_peak_blips", "rna004_llr_quantised", "rna004_llr_nan_holes"])
 def test_csv_text_equals_reference(tmp_path, name):
     from adapted_amd.output import CSV_COLUMNS, save_detected_boundaries
 
