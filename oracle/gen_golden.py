@@ -127,6 +127,9 @@ def run_single_case(name, case):
     n = case["n"]
     lens = np.asarray(resolve_lens(case["lens"], n, m), dtype=np.int32)
     sig, lens = synth.synth_batch(case["seed"], case["first"], n, m, lens)
+    apply_blips(sig, case)
+    apply_extra(sig, lens, case)
+    apply_quantise(sig, case)
     rows = []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -147,6 +147,24 @@ CASES = {
     # NaN holes INSIDE reads (the loader never makes them; numpy's NaN rules everywhere)
     "rna004_llr_nan_holes": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=59, first=0, n=24, lens="full", minibatch=24, dump=[],
                                  nan_holes=True),
+    # the single-read operator, the mvs_detect_overwrite branch and the start-peak primary on quantised samples / NaN holes / constant stretches
+    "rna004_llr_single_quantised": dict(chem="RNA004", primary="llr_single", max_obs_trace=None, seed=61, first=0, n=32, lens="mixed",
+                                        minibatch=1, dump=[], quantise=0.18),
+    "rna004_llr_single_nan": dict(chem="RNA004", primary="llr_single", max_obs_trace=None, seed=62, first=0, n=18, lens="full",
+                                  minibatch=1, dump=[], nan_holes=True),
+    "rna004_llr_mvs_overwrite_quantised": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=63, first=0, n=48, lens="mixed",
+                                               minibatch=48, dump=[], quantise=0.18, override={"mvs_polya.mvs_detect_overwrite": True}),
+    "rna004_llr_mvs_overwrite_flat": dict(chem="RNA004", primary="llr", max_obs_trace=None, seed=64, first=0, n=32, lens="full",
+                                          minibatch=32, dump=[], flat=True, override={"mvs_polya.mvs_detect_overwrite": True}),
+    "rna002_llr_mvs_overwrite": dict(chem="RNA002", primary="llr", max_obs_trace=None, seed=65, first=0, n=40, lens="mixed002",
+                                     minibatch=40, dump=[], override={"mvs_polya.mvs_detect_overwrite": True}),
+    "rna004_start_peak_nan": dict(chem="RNA004", primary="start_peak", max_obs_trace=None, seed=66, first=0, n=24, lens="full",
+                                  minibatch=24, dump=[], mvs_detect_check=False, detect_med_shift=True, nan_holes=True),
+    "rna004_llr_200k_windows": dict(chem="RNA004", primary="llr", max_obs_trace=200000, seed=67, first=0, n=8, lens="mixed200", minibatch=8,
+                                    dump=[], override={"mvs_polya.pA_var_window": 101, "mvs_polya.pA_mean_window": 21,
+                                                       "mvs_polya.median_shift_window": 1500, "real_range.max_obs_local_range": 3000}),
+    "rna004_cnn_200k_k3": dict(chem="RNA004", primary="cnn", max_obs_trace=200000, seed=68, first=4000, n=6, lens="mixed200cnn", minibatch=6,
+                               dump=[0], override={"cnn_boundaries.polya_cand_k": 3}),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),

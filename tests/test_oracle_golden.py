@@ -135,6 +135,9 @@ def test_single_read_api_vs_golden(oracle_mod, name):
     lens = np.asarray(g["lens"], dtype=np.int32)
     assert list(lens) == resolve_lens(case["lens"], case["n"], m)
     sig, _ = synth.synth_batch(case["seed"], case["first"], case["n"], m, lens)
+    from golden_cases import apply_blips, apply_extra, apply_quantise
+
+    apply_blips(sig, case); apply_extra(sig, lens, case); apply_quantise(sig, case)
     bad = []
     for i, w in enumerate(g["rows"]):
         have = min(int(lens[i]), m)
