@@ -165,6 +165,13 @@ CASES = {
                                                        "mvs_polya.median_shift_window": 1500, "real_range.max_obs_local_range": 3000}),
     "rna004_cnn_200k_k3": dict(chem="RNA004", primary="cnn", max_obs_trace=200000, seed=68, first=4000, n=6, lens="mixed200cnn", minibatch=6,
                                dump=[0], override={"cnn_boundaries.polya_cand_k": 3}),
+    # the CNN primary on quantised samples, constant stretches and NaN holes (C1's medians with ties, scores of odd inputs, argmax ties)
+    "rna004_cnn_quantised": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=71, first=0, n=32, lens="mixed", minibatch=32,
+                                 dump=[0, 3], quantise=0.18),
+    "rna004_cnn_flat": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=72, first=0, n=24, lens="full", minibatch=24,
+                            dump=[0, 1, 2, 3], flat=True),
+    "rna004_cnn_nan_holes": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=73, first=0, n=24, lens="full", minibatch=24,
+                                 dump=[1, 2], nan_holes=True),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
