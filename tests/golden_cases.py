@@ -169,7 +169,7 @@ CASES = {
     "rna004_cnn_quantised": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=71, first=0, n=32, lens="mixed", minibatch=32,
                                  dump=[0, 3], quantise=0.18),
     "rna004_cnn_flat": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=72, first=0, n=24, lens="full", minibatch=24,
-                            dump=[0, 1, 2, 3], flat=True),
+                            dump=[0, 1, 2, 3, 7, 11, 15, 19, 23], flat=True),
     "rna004_cnn_nan_holes": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=73, first=0, n=24, lens="full", minibatch=24,
                                  dump=[1, 2], nan_holes=True),
     # CNN primary with the shipped weights (default window)
