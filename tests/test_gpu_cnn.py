@@ -44,22 +44,46 @@ def test_prepare_scores_preds(setup):
             assert sc[k].shape == st["scores_%d" % k].shape
             assert np.max(np.abs(sc[k] - st["scores_%d" % k])) < 1e-4, (conv, k)  # C2
         preds = cnn.cnn_detect(s["sig"], s["model"], spc.cnn_boundaries, spc.core, spc=spc, engine=s["eng"], conv=conv)
-        flips = np.flatnonzero((preds != st["preds"]).any(axis=1))
-        assert flips.size == 0, (conv, "reads whose CNN indices differ from the CPU reference", flips, preds[flips], st["preds"][flips])
+        flips = [int(i) for i in np.flatnonzero((preds != st["preds"]).any(axis=1)) if not _pure_tie(st, spc, preds, int(i))]
+        assert not flips, (conv, "reads whose CNN indices differ from the CPU reference", flips, preds[flips], st["preds"][flips])
+
+
+def _pure_tie(st, spc, preds, i):
+    """The device's candidates of read i differ from the reference's only WITHIN a set of exactly equal score heights: find_peaks(distance
+    = 5) ranks peaks by an unstable np.argsort (reference adapted/detect/cnn.py:140 -> scipy's _select_by_peak_distance), so which of
+    several equally high peaks survive is undefined -- it depends on numpy's sort kernel (SIMD width) -- while everything that IS
+    defined must agree: the adapter end, the number of candidates, the multiset of candidate heights (read from the REFERENCE's
+    scores).  A constant stretch gives the stride-3 net exactly periodic scores: hundreds of equal maxima (rna004_cnn_flat)."""
+    key = "scores_%d" % i
+    if key not in st.files:
+        return False
+    sc = st[key][1]
+    off, ds = spc.core.min_obs_adapter, spc.core.downscale_factor
+    ref, dev = st["preds"][i], preds[i]
+    if ref[0] != dev[0] or np.count_nonzero(ref[1:]) != np.count_nonzero(dev[1:]):
+        return False
+    h = lambda row: sorted(float(sc[(int(p) - off) // ds]) for p in row[1:] if p)
+    same = h(ref) == h(dev)
+    if same:
+        print("read %d: a permutation among exactly tied peak heights (undefined order in the reference)" % i, ref, dev)
+    return same
 
 
 def test_cnn_rows_vs_golden(setup):
     from adapted_amd.detect.combined import combined_detect_cnn
 
     s = setup
+    st = load_stages(s["name"])
+    preds = s["cnn"].cnn_detect(s["sig"], s["model"], s["spc"].cnn_boundaries, s["spc"].core, spc=s["spc"], engine=s["eng"])
+    tied = {int(i) for i in np.flatnonzero((preds != st["preds"]).any(axis=1)) if _pure_tie(st, s["spc"], preds, int(i))}
     for model in (s["model"], None):  # (None: the weights named in the config, loaded without PyTorch)
         got = combined_detect_cnn(s["sig"], s["lens"], model, s["spc"])
-        bad = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) for d in row_diffs(g, w, float_rel=1e-5)]
+        bad = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) if i not in tied for d in row_diffs(g, w, float_rel=1e-5)]
         assert not bad, bad[:10]
     got_t = combined_detect_cnn(s["sig"], s["lens"], s["model"], s["spc"], conv="torch")
-    bad = [(i, d) for i, (g, w) in enumerate(zip(got_t, s["want"])) for d in row_diffs(g, w, float_rel=1e-5)]
+    bad = [(i, d) for i, (g, w) in enumerate(zip(got_t, s["want"])) if i not in tied for d in row_diffs(g, w, float_rel=1e-5)]
     assert not bad, bad[:10]
-    inexact = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) for d in row_diffs(g, w, float_rel=0.0)]
+    inexact = [(i, d) for i, (g, w) in enumerate(zip(got, s["want"])) if i not in tied for d in row_diffs(g, w, float_rel=0.0)]
     print("cnn rows: %d float fields differ in the last bits" % len(inexact), inexact[:5])
 
 
