@@ -308,6 +308,90 @@ static __device__ void partition_stats(X sig, int S, long long start, long long 
     rw.set(c_len + 4, (double)mad);
 }
 
+// ---------------------------------------------------------------- NaN samples inside a slice
+// The loaders never produce them (calibrated int16), the hot kernels assume there are none -- their recurrences would
+// carry a NaN forever --, but the operators accept any float32 array and bottleneck counts NaN samples out of the window
+// (a window with fewer than `window` valid samples yields NaN; later windows are clean again), so a slice with a NaN takes
+// these single-lane restatements of bottleneck/src/move_template.c instead, and np.nanmedian over what they return.
+static __device__ __noinline__ void bn_move_mean_nan(RowF32 a, int n, int w, float *out_)
+{
+    GLB float *out = (GLB float *)out_;
+    const float qnan = __builtin_nanf("");
+    float asum = 0.f;
+    int count = 0;
+    for (int i = 0; i < w; i++) { const float ai = a[i]; if (ai == ai) { asum += ai; count++; } }
+    out[0] = count >= w ? asum / (float)count : qnan;
+    float inv = (float)(1.0 / (double)count);
+    for (int i = w; i < n; i++) {
+        const float ai = a[i], aold = a[i - w];
+        if (ai == ai) {
+            if (aold == aold) asum += ai - aold;
+            else { asum += ai; count++; inv = (float)(1.0 / (double)count); }
+        } else if (aold == aold) { asum -= aold; count--; inv = (float)(1.0 / (double)count); }
+        out[i - w + 1] = count >= w ? asum * inv : qnan;
+    }
+}
+
+static __device__ __noinline__ void bn_move_var_nan(RowF32 a, int n, int w, float *out_)
+{
+    GLB float *out = (GLB float *)out_;
+    const float qnan = __builtin_nanf("");
+    float amean = 0.f, assqdm = 0.f;
+    int count = 0;
+    for (int i = 0; i < w; i++) {
+        const float ai = a[i];
+        if (ai == ai) { count++; const float delta = ai - amean; amean += delta / (float)count; assqdm += delta * (ai - amean); }
+    }
+    if (count >= w) { if (assqdm < 0) assqdm = 0; out[0] = assqdm / (float)count; }
+    else out[0] = qnan;
+    float inv = (float)(1.0 / (double)count);
+    for (int i = w; i < n; i++) {
+        float ai = a[i], aold = a[i - w];
+        if (ai == ai) {
+            if (aold == aold) {
+                const float delta = ai - aold;
+                aold -= amean; amean += delta * inv; ai -= amean;
+                assqdm += (ai + aold) * delta;
+            } else {
+                count++; inv = (float)(1.0 / (double)count);
+                const float delta = ai - amean;
+                amean += delta * inv;
+                assqdm += delta * (ai - amean);
+            }
+        } else if (aold == aold) {
+            count--; inv = (float)(1.0 / (double)count);
+            if (count > 0) { const float delta = aold - amean; amean -= delta * inv; assqdm -= delta * (aold - amean); }
+            else { amean = 0.f; assqdm = 0.f; }
+        }
+        if (count >= w) { if (assqdm < 0) assqdm = 0; out[i - w + 1] = assqdm * inv; }
+        else out[i - w + 1] = qnan;
+    }
+}
+
+// any NaN in x[0..n)?  (the same answer in every lane; int16 rows have none)
+template <class X>
+static __device__ __forceinline__ bool wave_has_nan(X x, int n)
+{
+    if constexpr (std::is_same<X, RowI16>::value) return false;
+    else {
+        bool bad = false;
+        for (int i = lane_id(); i < n; i += 64) { const float v = x[i]; bad |= v != v; }
+        return __any(bad);
+    }
+}
+
+// np.nanmedian(s[0..n))
+static __device__ __noinline__ float wave_nanmedian(const float *s, int n, LDS WaveScratch *ws)
+{
+    int cnt = 0;
+    for (int i = lane_id(); i < n; i += 64) cnt += s[i] == s[i];
+    cnt = wave_sum(cnt);
+    if (cnt <= 0) return __builtin_nanf("");
+    float vk, vkm1;
+    wave_select2_skipnan(s, n, cnt / 2, 0, 0.f, ws, vk, vkm1);
+    return (cnt & 1) ? vk : (vkm1 + vk) / 2.0f;
+}
+
 struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 
 // shift_cache: the median shift across the adapter end is the same for every candidate of a read (value, flag)
@@ -333,7 +417,14 @@ static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, lon
     } else {
     // the two sequential recurrences run side by side in lanes 0 and 1
     __syncthreads();
-    if (pre_mean) { scr_mean = const_cast<float *>(pre_mean); scr_var = const_cast<float *>(pre_var); }
+    const bool nanx = wave_has_nan(x, n);
+    if (nanx) {
+        if constexpr (!std::is_same<X, RowI16>::value) {
+            if (lane_id() == 0 && wvar) bn_move_var_nan(x, n, cfg.pA_var_window, scr_var);
+            if (lane_id() == 1 && wmean) bn_move_mean_nan(x, n, cfg.pA_mean_window, scr_mean);
+        }
+        __threadfence_block();
+    } else if (pre_mean) { scr_mean = const_cast<float *>(pre_mean); scr_var = const_cast<float *>(pre_var); }
     else {
         if (cfg.pA_var_window <= MV_HIST && cfg.pA_mean_window <= MV_HIST) {
             wave_move_series(x, n, cfg.pA_var_window, cfg.pA_mean_window, wvar, wmean, scr_var, scr_mean, ws);
@@ -351,9 +442,9 @@ static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, lon
     __syncthreads();
     if (sc && lane_id() == 0) sc->n = 0; // the scratch series were rewritten: drop any mirror of them
     __syncthreads();
-    if (wvar) fvar = wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws, sc);
+    if (wvar) fvar = nanx ? wave_nanmedian(scr_var, n - cfg.pA_var_window + 1, ws) : wave_median(scr_var, n - cfg.pA_var_window + 1, 0, 0.f, ws, sc);
     else fvar = wave_np_var(x, n, ws, nullptr);
-    if (wmean) fmean = wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws, sc);
+    if (wmean) fmean = nanx ? wave_nanmedian(scr_mean, n - cfg.pA_mean_window + 1, ws) : wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws, sc);
     else fmean = wave_np_mean(x, n, ws);
     fmed = wave_median(x, n, 0, 0.f, ws, sc);
     lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws, sc) - wave_percentile(x, n, 15.0, ws, sc) : (double)__builtin_nanf("");
@@ -400,7 +491,12 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(X sig, int S, long long 
     if (wm < 1 || wv < 1) { o.exc = ADP_F_EXC_MOVE_WINDOW; return o; } // (windows longer than the slice cannot occur)
     __syncthreads();
     // the series hold the outputs from index window-1 on (the first window-1 are NaN in bottleneck: never in range)
-    if (wv <= MV_HIST && wm <= MV_HIST) wave_move_series(x, n, wv, wm, true, true, scr_var, scr_mean, ws);
+    if (wave_has_nan(x, n)) {
+        if constexpr (!std::is_same<X, RowI16>::value) {
+            if (lane_id() == 0) bn_move_var_nan(x, n, wv, scr_var);
+            if (lane_id() == 1) bn_move_mean_nan(x, n, wm, scr_mean);
+        }
+    } else if (wv <= MV_HIST && wm <= MV_HIST) wave_move_series(x, n, wv, wm, true, true, scr_var, scr_mean, ws);
     else {
         if constexpr (std::is_same<X, RowI16>::value) {
             if (lane_id() == 0) bn_move_slim(x, n, wv, scr_var, true);
@@ -473,7 +569,11 @@ __global__ void __launch_bounds__(64) k_mvs_series(SIG sigs, const int32_t *__re
     float *smean = series + (size_t)r * 2 * cap, *svar = smean + cap;
     if (wvar) bn_move_var(x, n, cfg.pA_var_window, svar);
     if (wmean) bn_move_mean(x, n, cfg.pA_mean_window, smean);
-    have[r] = 1;
+    // a NaN sample stays in these recurrences to the end: such a read is k_validate's business (bn_move_*_nan)
+    bool clean = true;
+    if (wvar) { const float t = svar[n - cfg.pA_var_window]; clean &= t == t; }
+    if (wmean) { const float t = smean[n - cfg.pA_mean_window]; clean &= t == t; }
+    have[r] = clean ? 1 : 0;
 }
 
 // The same series for LONG slices (the CNN path's candidates at wide windows: up to the whole preload).  The chains are
@@ -571,7 +671,8 @@ static __device__ __forceinline__ void ms_var4(const float (&a)[4], const float 
 
 template <bool VAR>
 static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LDS int32_t *a_of, const LDS int32_t *n_of,
-                                 int r0, int n_reads, int w, float *__restrict__ series, int cap, LDS float *buf, LDS float *out)
+                                 int r0, int n_reads, int w, float *__restrict__ series, int cap, LDS float *buf, LDS float *out,
+                                 int8_t *__restrict__ have)
 {
     const int ln = lane_id();
     const int RB = ms_ring(w), S = RB + 4, SO = MS_CHUNK + 4, MASK = RB - 1;
@@ -687,6 +788,8 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
     }
     ws_sync();
     if (nmax > 0) store_chunk((nmax - 1) / MS_CHUNK * MS_CHUNK, out + (par ^ 1) * MS_G * SO);
+    // a NaN sample stays in the chain to its end: such a read's series are withdrawn (k_validate: bn_move_*_nan)
+    if (chain && n > 0 && (VAR ? assqdm != assqdm : asum != asum)) have[r] = 0;
 }
 
 // grid = ceil(n_reads / MS_G); block = 128 (wave 0: MS_G moving variances, wave 1: MS_G moving means); dynamic LDS
@@ -725,8 +828,8 @@ __global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict
     const int Sv = ms_ring(cfg.pA_var_window) + 4, Sm = ms_ring(cfg.pA_mean_window) + 4;
     LDS float *base = (LDS float *)ms_raw;
     LDS float *buf_v = base, *out_v = buf_v + MS_G * Sv, *buf_m = out_v + 2 * MS_G * (MS_CHUNK + 4), *out_m = buf_m + MS_G * Sm; // (out: two halves)
-    if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_var_window, series, cap, buf_v, out_v);
-    else ms_chains<false>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_mean_window, series, cap, buf_m, out_m);
+    if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_var_window, series, cap, buf_v, out_v, have);
+    else ms_chains<false>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_mean_window, series, cap, buf_m, out_m, have);
 }
 
 static __device__ void row_clear(adp_row *row)
@@ -1278,8 +1381,7 @@ __global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int3
 // nanmedian / MAD of the pooled values, (x - med) / mad, NaN -> -5.0 (torch.nan_to_num: +-inf ->
 // +-FLT_MAX).  Two kernels: k_cnn_pool (a 256-thread block per read; every wave pools tiles of 64 blocks staged in LDS with
 // coalesced 16-byte loads, numpy's summation order -- sp_pooled_tile; lane-strided scalar loads ran at 1.8 TB/s) and
-// k_cnn_prepare (a wave per read: the two medians and the scaling of the pooled values, in place).  Pooled NaNs form a tail
-// (minibatch layout B0).
+// k_cnn_prepare (a wave per read: the two medians and the scaling of the pooled values, in place).
 __global__ void __launch_bounds__(256) k_cnn_pool(const float *__restrict__ sigs, int n_reads, int m, int off, int ds, int Lc,
                                                    float *__restrict__ out, int32_t *__restrict__ nan_cnt)
 {
@@ -1308,8 +1410,22 @@ __global__ void __launch_bounds__(64) k_cnn_prepare(int n_reads, int Lc, float *
     float *o = out + (size_t)r * Lc;
     const int n = Lc - nan_cnt[r];
     LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
-    float med = wave_median(o, n, 0, 0.f, ws);
-    float mad = wave_median(o, n, 1, med, ws);
+    // NaNs after the last valid block (a short read) leave o[0..n) NaN-free; NaNs inside the read (NaN samples in
+    // the signal) are stepped over by the selection instead: np.nanmedian either way
+    bool tail = true;
+    for (int j = n + ln; j < Lc; j += 64) tail &= o[j] != o[j];
+    tail = __all(tail) || n <= 0;
+    float med, mad;
+    if (tail) {
+        med = wave_median(o, n, 0, 0.f, ws);
+        mad = wave_median(o, n, 1, med, ws);
+    } else {
+        float vk, vkm1;
+        wave_select2_skipnan(o, Lc, n / 2, 0, 0.f, ws, vk, vkm1);
+        med = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+        wave_select2_skipnan(o, Lc, n / 2, 1, med, ws, vk, vkm1);
+        mad = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+    }
     __syncthreads();
     for (int j = ln; j < Lc; j += 64) {
         float v = (o[j] - med) / mad;

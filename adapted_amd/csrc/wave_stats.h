@@ -57,20 +57,23 @@ static __device__ __forceinline__ float ws_xform(float x, int mode, float c)
 // One pass for the smallest and largest key, then an MSB-first radix select over d = key - min, 8 bits of the
 // SPAN per pass (a segment spanning 1.5 octaves of pA needs 3 passes, a constant one none): the digits are spread
 // over the bins whatever the level of the signal, so plain LDS atomics do.
-template <class P>
+// SKIPNAN: NaN entries are left out altogether (np.nanmedian's view of the array): k counts among the others.
+template <class P, bool SKIPNAN = false>
 static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                                          float &vk, float &vkm1)
 {
     const int ln = lane_id();
+    constexpr int UN = SKIPNAN ? 2 : 8; // loads in flight per lane (the NaN-skipping variant is a rare path: few registers)
     uint32_t mn = 0xffffffffu, mx = 0u;
     bool has_nan = false;
-    for (int base = 0; base < n; base += 512) {
-        float v[8];
+    for (int base = 0; base < n; base += 64 * UN) {
+        float v[UN];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = ld_or_first(x, i, i < n); }
+        for (int u = 0; u < UN; u++) { int i = base + u * 64 + ln; v[u] = ld_or_first(x, i, i < n); }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < UN; u++) {
             const float xf = ws_xform(v[u], mode, c);
+            if (SKIPNAN && xf != xf) continue;
             has_nan |= xf != xf;
             uint32_t key = f2key(xf); mn = key < mn ? key : mn; mx = key > mx ? key : mx;
         }
@@ -88,16 +91,17 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
         const int shift = rb - w;
         for (int i = ln; i < 256; i += 64) ws->hist[i] = 0;
         ws_sync();
-        for (int base = 0; base < n; base += 512) {
-            float v[8];
+        for (int base = 0; base < n; base += 64 * UN) {
+            float v[UN];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int i = base + u * 64 + ln; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
+            for (int u = 0; u < UN; u++) { int i = base + u * 64 + ln; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < UN; u++) {
                 const int i = base + u * 64 + ln;
-                const uint32_t d = f2key(ws_xform(v[u], mode, c)) - mn;
+                const float xf = ws_xform(v[u], mode, c);
+                const uint32_t d = f2key(xf) - mn;
                 const uint32_t top = (rb >= 32) ? 0u : (d >> rb);
-                if (i < n) {
+                if (i < n && !(SKIPNAN && xf != xf)) {
                     if (top == prefix) __hip_atomic_fetch_add(&ws->hist[(d >> shift) & ((1u << w) - 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else if (shift == 0 && top < prefix && d + 1u > below) below = d + 1u;
                 }
@@ -158,6 +162,12 @@ static __device__ __noinline__ void wave_select2_global(X x, int n, int k, int m
                                                         LDS WaveScratch *ws, float &vk, float &vkm1)
 {
     wave_select2_impl<X>(x, n, k, mode, c, ws, vk, vkm1);
+}
+// x_(k), x_(k-1) of the non-NaN entries of x[0..n); 0 <= k < their count
+static __device__ __noinline__ void wave_select2_skipnan(const float *x, int n, int k, int mode, float c,
+                                                         LDS WaveScratch *ws, float &vk, float &vkm1)
+{
+    wave_select2_impl<RowF32, true>(as_row(x), n, k, mode, c, ws, vk, vkm1);
 }
 static __device__ __noinline__ void wave_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS WaveScratch *ws,
                                                      float &vk, float &vkm1)

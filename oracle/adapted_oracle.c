@@ -727,15 +727,22 @@ long orc_polya_peak(const double *g, long n)
 
 /* move_mean / move_var (float32, NaN-free input), outputs for i >= window-1 only:
  * out[k] = value at index window-1+k, k in [0, n-window] */
+/* NaN samples are counted out of the window; a window with fewer than w valid samples yields NaN
+ * (min_count = window) -- bottleneck/src/move_template.c move_mean / move_var, every intermediate in float32 */
 static void bn_move_mean_f32(const float *a, long n, long w, float *out)
 {
     float asum = 0.f;
-    for (long i = 0; i < w; i++) asum += a[i];
-    out[0] = asum / (float)w;
-    float inv = (float)(1.0 / (double)w);
+    long count = 0;
+    for (long i = 0; i < w; i++) { float ai = a[i]; if (ai == ai) { asum += ai; count++; } }
+    out[0] = count >= w ? asum / (float)count : NAN;
+    float inv = (float)(1.0 / (double)count);
     for (long i = w; i < n; i++) {
-        asum += a[i] - a[i - w];
-        out[i - w + 1] = asum * inv;
+        float ai = a[i], aold = a[i - w];
+        if (ai == ai) {
+            if (aold == aold) asum += ai - aold;
+            else { asum += ai; count++; inv = (float)(1.0 / (double)count); }
+        } else if (aold == aold) { asum -= aold; count--; inv = (float)(1.0 / (double)count); }
+        out[i - w + 1] = count >= w ? asum * inv : NAN;
     }
 }
 
@@ -745,23 +752,43 @@ static void bn_move_var_f32(const float *a, long n, long w, float *out)
     long count = 0;
     for (long i = 0; i < w; i++) {
         float ai = a[i];
-        count++;
-        float delta = ai - amean;
-        amean += delta / (float)count;
-        assqdm += delta * (ai - amean);
+        if (ai == ai) {
+            count++;
+            float delta = ai - amean;
+            amean += delta / (float)count;
+            assqdm += delta * (ai - amean);
+        }
     }
-    if (assqdm < 0) assqdm = 0;
-    out[0] = assqdm / (float)count;
+    if (count >= w) { if (assqdm < 0) assqdm = 0; out[0] = assqdm / (float)count; }
+    else out[0] = NAN;
     float ddof_inv = (float)(1.0 / (double)count), count_inv = (float)(1.0 / (double)count);
     for (long i = w; i < n; i++) {
         float ai = a[i], aold = a[i - w];
-        float delta = ai - aold;
-        aold -= amean;
-        amean += delta * count_inv;
-        ai -= amean;
-        assqdm += (ai + aold) * delta;
-        if (assqdm < 0) assqdm = 0;
-        out[i - w + 1] = assqdm * ddof_inv;
+        if (ai == ai) {
+            if (aold == aold) {
+                float delta = ai - aold;
+                aold -= amean;
+                amean += delta * count_inv;
+                ai -= amean;
+                assqdm += (ai + aold) * delta;
+            } else {
+                count++;
+                count_inv = ddof_inv = (float)(1.0 / (double)count);
+                float delta = ai - amean;
+                amean += delta * count_inv;
+                assqdm += delta * (ai - amean);
+            }
+        } else if (aold == aold) {
+            count--;
+            count_inv = ddof_inv = (float)(1.0 / (double)count);
+            if (count > 0) {
+                float delta = aold - amean;
+                amean -= delta * count_inv;
+                assqdm -= delta * (aold - amean);
+            } else { amean = 0.f; assqdm = 0.f; }
+        }
+        if (count >= w) { if (assqdm < 0) assqdm = 0; out[i - w + 1] = assqdm * ddof_inv; }
+        else out[i - w + 1] = NAN;
     }
 }
 

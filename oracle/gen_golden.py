@@ -260,6 +260,46 @@ def gen_bottleneck():
     np.savez_compressed(os.path.join(GOLD, "bn_move.npz"), **arrs)
 
 
+def gen_bottleneck_nan():
+    """move_mean / move_var of float32 series WITH NaN samples (single ones, runs, a run longer than the window, NaNs in
+    the first window and at the end) -- the real library's counting of valid samples."""
+    import bottleneck as bn
+
+    if not hasattr(bn, "__version__"):
+        raise RuntimeError("real bottleneck required")
+    rng = np.random.default_rng(15)
+    arrs = {}
+    for t in range(8):
+        n = int(rng.integers(260, 1800))
+        a = rng.normal(108, 2.5, n).astype(np.float32)
+        if t == 0:
+            a[150] = np.nan
+        elif t == 1:
+            a[120:128] = np.nan
+            a[700:703] = np.nan
+        elif t == 2:
+            a[130:250] = np.nan  # longer than both windows
+        elif t == 3:
+            a[3] = np.nan        # inside the first window
+            a[200:204] = np.nan
+        elif t == 4:
+            a[n - 2:] = np.nan
+            a[0] = np.nan
+        elif t == 5:
+            a[rng.integers(0, n, 12)] = np.nan
+        elif t == 6:
+            a[140:150] = np.nan
+            a[rng.integers(0, n, 3)] += np.float32(60)
+        else:
+            a[:] = np.nan
+        arrs["a_%d" % t] = a
+        arrs["mean20_%d" % t] = bn.move_mean(a, window=20)
+        arrs["var100_%d" % t] = bn.move_var(a, window=100)
+        arrs["var5_%d" % t] = bn.move_var(a, window=5)
+    arrs["version"] = np.array([int(x) for x in bn.__version__.split(".")[:3]])
+    np.savez_compressed(os.path.join(GOLD, "bn_move_nan.npz"), **arrs)
+
+
 def export_weights():
     """The reference's trained CNN parameters (a data asset, CC BY-NC 4.0, (c) W. K. van der Toorn) as a
     neutral .npz with the same state-dict keys."""
@@ -276,6 +316,10 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "llr"
     only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None  # e.g. llr rna004_llr_mvs_overwrite: just these cases
     os.makedirs(GOLD, exist_ok=True)
+    if what == "bottleneck":
+        gen_bottleneck()
+        gen_bottleneck_nan()
+        return
     ref_harness.install(need_torch=(what == "cnn"))
     if what == "llr" and only:
         for name in sorted(only):
@@ -290,6 +334,7 @@ def main():
         return
     if what == "llr":
         gen_bottleneck()
+        gen_bottleneck_nan()
         for name, case in CASES.items():
             if case["primary"] == "cnn":
                 continue

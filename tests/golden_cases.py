@@ -172,6 +172,12 @@ CASES = {
                             dump=[0, 1, 2, 3, 7, 11, 15, 19, 23], flat=True),
     "rna004_cnn_nan_holes": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=73, first=0, n=24, lens="full", minibatch=24,
                                  dump=[1, 2], nan_holes=True),
+    # NaN pairs around the adapter end and inside the poly(A) tail of every read: the moving mean / variance of the MVS check
+    # and of the mvs_detect_overwrite scan over slices WITH NaN samples (bottleneck counts them out of the window)
+    "rna004_cnn_nan_polya": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=74, first=0, n=32, lens="mixed", minibatch=32,
+                                 dump=[1], nan_holes="polya"),
+    "rna004_cnn_nan_polya_overwrite": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=75, first=0, n=32, lens="mixed",
+                                           minibatch=32, dump=[1], nan_holes="polya", override={"mvs_polya.mvs_detect_overwrite": True}),
     # CNN primary with the shipped weights (default window)
     "rna004_cnn_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=17,
                                first=0, n=48, lens="mixed", minibatch=48, dump=[0, 1]),
@@ -206,7 +212,15 @@ def apply_extra(sig, lens, case):
             for d in (0, 40, 400):
                 if p + d + 3 < sig.shape[1]:
                     sig[i, p + d: p + d + 3] = 260.0
-    if case.get("nan_holes"):
+    if case.get("nan_holes") == "polya":
+        import numpy as np
+
+        for i in range(sig.shape[0]):
+            p = 2400 + (137 * i) % 2600
+            for d in (60, 460) if i % 3 else (460,):
+                if p + d + 2 < min(int(lens[i]), sig.shape[1]):
+                    sig[i, p + d: p + d + 2] = np.nan
+    elif case.get("nan_holes"):
         import numpy as np
 
         for i in range(sig.shape[0]):

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 # both windows the reference was run at: the preset's (m = 17 500) and configs[2]'s (m = 201 500, Lc = 20 050: 12 reads incl.
 # ones short enough for the LLR fallback, one that raises) -- tests/golden/rna004_cnn_{default,200k}.*; and polya_cand_k = 3
 # without the fallback, polya_cand_k = 1 (no find_peaks, no row compaction: cnn.py:160)
-@pytest.fixture(scope="module", params=["rna004_cnn_default", "rna004_cnn_200k", "rna004_cnn_k3", "rna004_cnn_k1", "rna004_cnn_adapter_range", "rna004_cnn_no_mean_range", "rna004_cnn_200k_k3", "rna004_cnn_quantised", "rna004_cnn_flat", "rna004_cnn_nan_holes"])
+@pytest.fixture(scope="module", params=["rna004_cnn_default", "rna004_cnn_200k", "rna004_cnn_k3", "rna004_cnn_k1", "rna004_cnn_adapter_range", "rna004_cnn_no_mean_range", "rna004_cnn_200k_k3", "rna004_cnn_quantised", "rna004_cnn_flat", "rna004_cnn_nan_holes",
+                                        "rna004_cnn_nan_polya", "rna004_cnn_nan_polya_overwrite"])
 def setup(request):
     import torch
 

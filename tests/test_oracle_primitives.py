@@ -103,6 +103,25 @@ def test_bottleneck_golden(oracle_mod):
         assert np.array_equal(out[: n - 99], z["var100_%d" % t][99:])
 
 
+def test_bottleneck_nan_golden(oracle_mod):
+    """NaN samples inside the series: the real library counts them out of the window (tests/golden/bn_move_nan.npz)"""
+    from oracle import bn_shim
+
+    L = oracle_mod.lib()
+    z = np.load(os.path.join(GOLD, "bn_move_nan.npz"))
+    for t in range(8):
+        a = np.ascontiguousarray(z["a_%d" % t])
+        n = a.size
+        out = np.zeros(n, dtype=np.float32)
+        L.orc_bn_move_mean_f32(_fp(a), C.c_long(n), C.c_long(20), _fp(out))
+        assert np.array_equal(out[: n - 19], z["mean20_%d" % t][19:], equal_nan=True), t
+        for w in (100, 5):
+            L.orc_bn_move_var_f32(_fp(a), C.c_long(n), C.c_long(w), _fp(out))
+            assert np.array_equal(out[: n - w + 1], z["var%d_%d" % (w, t)][w - 1:], equal_nan=True), (t, w)
+            assert np.array_equal(bn_shim.move_var(a, w), z["var%d_%d" % (w, t)], equal_nan=True), (t, w)
+        assert np.array_equal(bn_shim.move_mean(a, 20), z["mean20_%d" % t], equal_nan=True), t
+
+
 def test_bn_shim_matches_golden():
     """the pure-python shim used when the reference is run under the torch interpreter"""
     import sys
