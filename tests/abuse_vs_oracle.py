@@ -32,6 +32,13 @@ def main():
     a = -base.copy(); cases["negative signal"] = a
     a = base.copy(); a[7, 4000:9000] = f(95.0); a[8, :] = f(100.0); cases["constant stretches and a constant read"] = a
     a = base.copy(); a[10, 6000:6100] = np.nan; a[11, 0:50] = np.nan; cases["NaN holes inside reads"] = a
+    a = base.copy()
+    for i in range(n):  # (bottleneck counts NaN samples out of its moving windows: the MVS check on slices WITH NaNs)
+        p = 2400 + (137 * i) % 2600
+        a[i, p + 460: p + 462] = np.nan
+        if i % 3:
+            a[i, p + 60: p + 62] = np.nan
+    cases["NaN pairs around the adapter end of every read"] = a
     a = base.copy(); a[:, 1::2] = a[:, 0::2][:, : a[:, 1::2].shape[1]]; cases["every sample twice"] = a
     a = np.round(base.copy()); cases["integers"] = a.astype(np.float32)
     total = 0
@@ -83,6 +90,15 @@ def abuse_cnn():
     a = -base.copy(); cases["cnn: negative signal"] = a
     a = base.copy(); a[7, 8000:39000] = f(95.0); a[8, :] = f(100.0); cases["cnn: constant stretches and a constant read"] = a
     a = base.copy(); a[10, 16000:16100] = np.nan; a[11, 5000:5050] = np.nan; cases["cnn: NaN holes inside reads"] = a
+    a = base.copy()
+    for i in range(n):
+        p = 2400 + (137 * i) % 2600
+        a[i, p + 460: p + 462] = np.nan
+        if i % 3:
+            a[i, p + 60: p + 62] = np.nan
+        if i % 5 == 0:
+            a[i, p + 2000: p + 2300] = np.nan  # a hole longer than both windows
+    cases["cnn: NaN pairs around the adapter end of every read"] = a
     a = np.round(base.copy()); cases["cnn: integers"] = a.astype(np.float32)
     total = 0
     for name, sig in cases.items():

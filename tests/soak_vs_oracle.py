@@ -226,7 +226,7 @@ def main():
         elif sp_primary:
             rows = eng.detect_start_peak_rows(sig, lens, n, mbn)
             mbs = np.zeros(2, dtype=np.int32)
-            got = lib.rows_to_results(rows, "start_peak")
+            got = lib.open_pore_float_column(lib.rows_to_results(rows, "start_peak"))  # (one operator call = one DataFrame)
             want = oracle.detect_start_peak(sig, lens, spc)
         else:
             rows, mbs = eng.detect_llr_rows(sig, lens, n, mbn, with_start_peak=True, tails_nan=bool(it % 2))
