@@ -215,6 +215,13 @@ def main():
                 jit = rng.integers(-400, 1500, n)
                 col = np.where(pe > 0, np.maximum(pe + jit * (c > 0), 0), 0)
                 bounds[:, 1 + c] = np.where(rng.random(n) < (0.9 if c == 0 else 0.6), col, 0)
+            if it % 4 == 3:  # NaN samples inside the validated slices (bottleneck counts them out of its windows)
+                sig = sig.copy()
+                for i in range(0, n, 2):
+                    for _ in range(int(rng.integers(1, 4)) if ae[i] > 0 else 0):
+                        p, w = int(ae[i] + rng.integers(-300, 3000)), int(rng.integers(1, 150))
+                        if p >= 0 and p + w < min(int(lens[i]), m):
+                            sig[i, p:p + w] = np.nan
             spc.cnn_boundaries.cnn_detect, spc.llr_boundaries.llr_detect = True, False
             spc.cnn_boundaries.fallback_to_llr_short_reads = False
             spc.update_primary_method()
