@@ -683,6 +683,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         __syncthreads();
         o.med = bs->bcast[1]; o.mad = bs->bcast[2];
         __syncthreads();
+        phase(14);
         return o;
     }
     // ---- pass A: mean + bucket histogram --------------------------------------------------

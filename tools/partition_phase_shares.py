@@ -26,8 +26,8 @@ eng.detect_llr_rows(sig.data_ptr(), ln.data_ptr(), R, mb, with_start_peak=True, 
 c1 = eng.debug_counters(24).astype(np.int64)
 d = c1 - c0
 print("tallies", d[:8])
-ph = d[8:14].astype(float)
-print("phase share: passA %.1f%%  find/predict %.1f%%  passB %.1f%%  median %.1f%%  mad-select %.1f%%  mad-fallback %.1f%%" % tuple(100 * ph / ph.sum()))
+ph = np.concatenate([d[8:14], d[22:23]]).astype(float)
+print("phase share: passA %.1f%%  find/predict %.1f%%  passB %.1f%%  median %.1f%%  mad-select %.1f%%  mad-fallback %.1f%%  small-segment path %.1f%%" % tuple(100 * ph / ph.sum()))
 r = np.zeros(R, dtype=lib.ROW_DTYPE); eng.d2h(r, rows.data_ptr())
 C = {name: i for i, name in enumerate(lib.COLS)}
 col = r["col"]; ok = r["success"] == 1
