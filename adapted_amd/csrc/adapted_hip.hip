@@ -10,9 +10,12 @@
 #include <vector>
 
 #include "adapted_hip.h"
-__device__ int g_ablate = 0;
-__device__ unsigned long long g_dbg[24] = {0};
 #include "common.h"
+__device__ int g_ablate = 0;
+__device__ unsigned long long g_dbg[ADP_NDBG] = {0};
+// k_partition_stats' tallies (slots 0-4 of what = 8), spread over ADP_NTALLY cache lines by workgroup: every workgroup adding to ONE
+// address serialises device-wide -- 2 x 96 000 same-address atomics were 7.7 ms of the kernel's 13 at the default window
+__device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "llr_stream.h"
 #include "n1_select.h"
 #include "n1_fused.h"
@@ -1704,8 +1707,13 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     case 5: src = h->polya_idx.p; break;
     case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
     case 7: src = h->t1.p; break;
-    case 8: { if (bytes < 64 || bytes > sizeof(unsigned long long) * 24) return ADP_ERR_INVALID;
-              HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost)); return ADP_OK; }
+    case 8: { if (bytes < 64 || bytes > sizeof(unsigned long long) * ADP_NDBG) return ADP_ERR_INVALID;
+              HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost));
+              static unsigned long long tally[ADP_NTALLY][8];
+              HIPCHK(hipMemcpyFromSymbol(tally, HIP_SYMBOL(g_bs_tally), sizeof(tally), 0, hipMemcpyDeviceToHost));
+              unsigned long long *o = (unsigned long long *)host_out;
+              for (int j = 0; j < 5; j++) { o[j] = 0; for (int i = 0; i < ADP_NTALLY; i++) o[j] += tally[i][j]; }
+              return ADP_OK; }
     default: return ADP_ERR_INVALID;
     }
     // (the stage buffers belong to the plain pipeline: a grouped call keeps them in its lanes, a handle that has not run the LLR path has none)

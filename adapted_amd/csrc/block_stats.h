@@ -36,7 +36,8 @@
 
 // (defined in adapted_hip.hip) timing experiments only (ADP_ABLATE); results are wrong when non-zero
 extern __device__ int g_ablate;
-extern __device__ unsigned long long g_dbg[24]; // debug tallies (adp_debug_fetch what=8): 0-4 here, 5-7 N1, 8-15 phase cycles here
+extern __device__ unsigned long long g_bs_tally[ADP_NTALLY][8];
+extern __device__ unsigned long long g_dbg[ADP_NDBG]; // debug tallies (adp_debug_fetch what=8): 0-4 here, 5-7 N1, 8-15 phase cycles here
 
 // 16-byte load from a 4-byte aligned address (segments start anywhere): gfx950 global loads need dword alignment only
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -229,11 +230,23 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     uint32_t aux = 0, aux2 = 0;
     float total = 0.0f; // meaningful in wave 0
     int s = 0;
+#ifdef ADP_PHASE_TIMING
+    long long tph = clock64();
+    auto phase = [&](int slot) { // (debug build) 25 + 4 * SIDE: whole chunks, then the ragged part's side effects, its leaves and tree, the epilogue
+        long long t = clock64();
+        if (tid == 0 && n >= 8192) atomicAdd(&g_dbg[slot + 4 * SIDE], (unsigned long long)(t - tph));
+        tph = t;
+    };
+#else
+    auto phase = [](int) {};
+#endif
     // Each WAVE owns whole numpy chunks (8192 samples; wave w takes chunks w, w+4, ...): it streams the chunk in eight
     // slabs of 1024 samples (8 leaves), stages each slab in its own LDS rows, runs the 8 x 8 accumulator chains, folds
     // them by shuffles and keeps the slab sums in lanes 0..7; a last butterfly over those lanes is the top of numpy's
     // balanced tree.  No block-wide barrier inside the stream: the chunk sums meet once, in order, at the end.
-    const int w = tid >> 6, ln = tid & 63;
+    // (the wave that owns chunk 0 rotates with the workgroup: a segment of one or two chunks keeps ONE wave busy, and the
+    // same wave index of every workgroup on a CU sits on the same SIMD)
+    const int w = ((tid >> 6) + (int)(blockIdx.x & 3)) & 3, ln = tid & 63;
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
     const int nchunk = n / 8192;
     const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
@@ -306,6 +319,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     if (tid == 0) for (int ch = 0; ch < nchunk; ch++) total += bs->chunk_sum[ch]; // numpy adds the chunk sums in sequence
     s = nchunk * 8192;
     __syncthreads();
+    phase(25);
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
         { // the side effects of the ragged part: eight loads in flight per thread (one by one, each waited for its own round trip)
@@ -318,6 +332,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
                 for (int u = 0; u < 8; u++) if (base + u * BS_THREADS + tid < tail) bs_side<SIDE>(v[u], param, bs, aux, aux2);
             }
         }
+        phase(26);
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
         bs_tail_leaves(tail, bs);
         const int nleaf = bs->nleaf;
@@ -370,6 +385,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
         }
         __syncthreads();
         if (tid < 64) total += bs_tail_tree(bs); // (lane 0 holds the root)
+        phase(27);
     }
     __syncthreads();
     if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }
@@ -389,6 +405,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     r.aux = bs->below;
     r.aux2 = bs->cntb;
     __syncthreads();
+    phase(28);
     return r;
 }
 
@@ -683,7 +700,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         __syncthreads();
         o.med = bs->bcast[1]; o.mad = bs->bcast[2];
         __syncthreads();
-        phase(14);
+        phase(16);
         return o;
     }
     // ---- pass A: mean + bucket histogram --------------------------------------------------
@@ -748,7 +765,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
                                               : block_np_sum<SIDE_COLLECT>(x, n, 2, o.mean, bs, sp);
     o.sd = sqrtf(p2.sum / (float)n);
     phase(2);
-    if (have_medmad || (g_ablate & (2048 | 8192))) { o.med = med_in; o.mad = mad_in; return o; }
+    if (have_medmad || (g_ablate & (2048 | 8192 | 131072))) { o.med = med_in; o.mad = mad_in; return o; }
     if (fallback_med) {
         __syncthreads();
         if (tid < 64) { float m_ = wave_median(x, n, 0, 0.f, &bs->u.ws); if (tid == 0) bs->bcast[1] = m_; }
@@ -772,9 +789,13 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
     } else {
         uint32_t below_key = 0;
         if ((n & 1) == 0 && rk == 0) below_key = bs_max_key_below(x, n, (wlo + (uint32_t)bin) << BS_KSH, bs); // (rare)
+#ifdef ADP_PHASE_TIMING
+        { long long t = clock64(); if (tid == 0) { atomicAdd(&g_dbg[37], (unsigned long long)(t - tph)); if ((n & 1) == 0 && rk == 0) atomicAdd(&g_dbg[38], 1ull); atomicAdd(&g_dbg[39], (unsigned long long)bs->ncollect); } }
+#endif
         o.med = bs_median_from_bucket(bs, bs_collect(bs), bs->ncollect, n, rk, below_key);
     }
     phase(3);
+    if (g_ablate & 32768) { o.mad = 0.f; return o; }
     // ---- MAD inside the bracket, if it can be proven ---------------------------------------------
     bool done = false;
     if (predicted && !fallback_med) {
@@ -804,12 +825,13 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
                                  atomicAdd(&g_dbg[16], (unsigned long long)bs->nmad); atomicAdd(&g_dbg[17], (unsigned long long)bs->ncollect);
                                  if (bs->nmad > 2048) atomicAdd(&g_dbg[18], 1ull); if (bs->nmad > 3072) atomicAdd(&g_dbg[19], 1ull); }
 #endif
-    if (tid == 0 && n >= 8192) { // tallies for the large segments only
-        atomicAdd(&g_dbg[0], 1ull);
-        if (done) atomicAdd(&g_dbg[1], 1ull);
-        if (fallback_med) atomicAdd(&g_dbg[2], 1ull);
-        if (!predicted) atomicAdd(&g_dbg[3], 1ull);
-        if (predicted && !done && bs->nmad > BS_MADCAP) atomicAdd(&g_dbg[4], 1ull);
+    if (tid == 0 && n >= 8192 && !(g_ablate & 262144)) { // tallies for the large segments only
+        unsigned long long *tl = g_bs_tally[blockIdx.x & (ADP_NTALLY - 1)]; // (a line of its own per 1 / ADP_NTALLY of the workgroups)
+        atomicAdd(&tl[0], 1ull);
+        if (done) atomicAdd(&tl[1], 1ull);
+        if (fallback_med) atomicAdd(&tl[2], 1ull);
+        if (!predicted) atomicAdd(&tl[3], 1ull);
+        if (predicted && !done && bs->nmad > BS_MADCAP) atomicAdd(&tl[4], 1ull);
     }
     phase(4);
     if (!done) o.mad = bs_mad_two_pass(x, n, bs, o.med, o.sd);

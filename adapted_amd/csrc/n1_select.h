@@ -37,7 +37,7 @@
 
 enum { N1_ALWAYS = 0, N1_IF_BAD = 1, N1_IF_NOT_DONE = 2 };
 
-extern __device__ unsigned long long g_dbg[24];
+extern __device__ unsigned long long g_dbg[ADP_NDBG];
 
 // transform: mode 0 -> x ; mode 1 -> |x - med| (float32, as numpy computes np.abs(signal - med))
 static __device__ __forceinline__ float n1_xform(float x, int mode, float med) { return mode ? fabsf(x - med) : x; }

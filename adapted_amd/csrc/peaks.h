@@ -20,7 +20,7 @@
 
 #define DBLMAX 1.7976931348623157e308
 extern __device__ int g_ablate;
-extern __device__ unsigned long long g_dbg[24]; // (debug tallies; 16-23: k_polya_peak in a -DADP_PHASE_TIMING build)
+extern __device__ unsigned long long g_dbg[ADP_NDBG]; // (debug tallies; 16-23: k_polya_peak in a -DADP_PHASE_TIMING build)
 
 struct TraceView {
     const double *x;     // trace of one read (full-trace coordinates)
