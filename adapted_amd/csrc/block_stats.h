@@ -22,6 +22,7 @@
 // a half chunk (4096 samples) is staged in LDS with coalesced loads, 256 threads each run one
 // accumulator chain of 16 samples, xor-shuffles fold the 8 accumulators and then the 64 leaves.
 #pragma once
+#include <cstddef>
 #include "common.h"
 #include "wave_stats.h"
 
@@ -244,9 +245,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     // slabs of 1024 samples (8 leaves), stages each slab in its own LDS rows, runs the 8 x 8 accumulator chains, folds
     // them by shuffles and keeps the slab sums in lanes 0..7; a last butterfly over those lanes is the top of numpy's
     // balanced tree.  No block-wide barrier inside the stream: the chunk sums meet once, in order, at the end.
-    // (the wave that owns chunk 0 rotates with the workgroup: a segment of one or two chunks keeps ONE wave busy, and the
-    // same wave index of every workgroup on a CU sits on the same SIMD)
-    const int w = ((tid >> 6) + (int)(blockIdx.x & 3)) & 3, ln = tid & 63;
+    const int w = tid >> 6, ln = tid & 63;
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
     const int nchunk = n / 8192;
     const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
@@ -407,6 +406,62 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     __syncthreads();
     phase(28);
     return r;
+}
+
+// A SHORT segment (the poly(A) slice, the adapter) is read from global memory ONCE, into LDS; its sums and selections run there.
+// BS_SMALLCAP: the staging rows and the histogram storage taken together (they are adjacent in BlockScratch).
+#define BS_SMALLCAP (32 * BS_LEAF_STRIDE + BS_BINS)
+static_assert(offsetof(BlockScratch, hist) == offsetof(BlockScratch, u) + 32 * BS_LEAF_STRIDE * 4, "the histogram's storage must follow the staging rows");
+template <class X>
+static __device__ __forceinline__ void bs_copy_to_lds(X x, int n, LDS float *cp)
+{
+    const int tid = threadIdx.x;
+    for (int base = 0; base < n; base += BS_THREADS * 8) { // eight loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; if (i < n) cp[i] = v[u]; }
+    }
+}
+// numpy-ordered sum of xf(cp[0..n)), n < 8192 (one ragged numpy chunk: the leaves of bs_tail_leaves, 8 accumulators each, the
+// balanced tree above them -- exactly the ragged part of block_np_sum, read from LDS instead of staged from global memory).
+// All threads return the sum.  The caller has a barrier between its writes of cp and this call.
+static __device__ __noinline__ float bs_lds_np_sum(const LDS float *cp, int n, int mode, float c, LDS BlockScratch *bs)
+{
+    const int tid = threadIdx.x;
+    bs_tail_leaves(n, bs);
+    const int nleaf = bs->nleaf;
+    for (int g0 = 0; g0 < nleaf; g0 += 32) {
+        const int ll = tid >> 3, j = tid & 7; // accumulator chain j of leaf g0 + ll
+        const int l = g0 + ll;
+        const bool have = l < nleaf;
+        const int len = have ? bs->leaf_len[l] : 0;
+        const LDS float *q = cp + (have ? bs->leaf_off[l] : 0);
+        float r = 0.0f;
+        if (len >= 8) {
+            r = bs_x2(q[j], mode, c);
+            const int lim = len - (len % 8);
+            for (int i = 8; i < lim; i += 8) r += bs_x2(q[i + j], mode, c);
+        }
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        if (j == 0 && have) {
+            float res;
+            if (len >= 8) { res = r; for (int i = len - (len % 8); i < len; i++) res += bs_x2(q[i], mode, c); }
+            else { res = 0.0f; for (int i = 0; i < len; i++) res += bs_x2(q[i], mode, c); }
+            bs->tleaf[bs->leaf_slot[l]] = res;
+        }
+    }
+    __syncthreads();
+    float total = 0.0f;
+    if (tid < 64) total = bs_tail_tree(bs); // (lane 0 holds the root)
+    if (tid == 0) bs->bcast[0] = total;
+    __syncthreads();
+    const float out = bs->bcast[0];
+    __syncthreads();
+    return out;
 }
 
 // window start (in buckets of 2^SH keys): half an octave below the pivot's octave
@@ -680,27 +735,49 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
 #endif
     SideParam sp; sp.key = 0; sp.c = 0.f; sp.P = 0.f; sp.Q = 0.f; sp.do_mad = 0;
     if (!have_medmad && n <= BS_BINS) {
-        // a segment that fits the histogram's storage (the poly(A) slice): two plain numpy-ordered sums, then the exact
-        // median and MAD by direct selection on an LDS copy -- none of the bucket / bracket machinery
-        SumAux s1 = block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp);
-        o.mean = s1.sum / (float)n;
-        SumAux s2 = block_np_sum<SIDE_NONE>(x, n, 2, o.mean, bs, sp);
-        o.sd = sqrtf(s2.sum / (float)n);
+        // a segment that fits the histogram's storage (the poly(A) slice): ONE read into LDS, the two numpy-ordered sums and the
+        // exact median and MAD by direct selection there -- none of the bucket / bracket machinery
+#ifdef ADP_PHASE_TIMING
+        long long tq = clock64();
+        auto sub = [&](int slot) { long long t = clock64(); if (tid == 0) atomicAdd(&g_dbg[slot], (unsigned long long)(t - tq)); tq = t; };
+#else
+        auto sub = [](int) {};
+#endif
         LDS float *cp = (LDS float *)bs->hist;
         __syncthreads();
-        for (int i = tid; i < n; i += BS_THREADS) cp[i] = x[i];
+        bs_copy_to_lds(x, n, cp);
         __syncthreads();
+        sub(42);
+        o.mean = bs_lds_np_sum(cp, n, 0, 0.f, bs) / (float)n;
+        sub(40);
+        o.sd = sqrtf(bs_lds_np_sum(cp, n, 2, o.mean, bs) / (float)n);
+        sub(41);
         if (tid < 64) {
             float vk, vkm1;
             wave_select2_lds(cp, n, k1, 0, 0.f, &bs->u.ws, vk, vkm1);
             const float med = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+            sub(43);
             wave_select2_lds(cp, n, k1, 1, med, &bs->u.ws, vk, vkm1);
+            sub(44);
             if (tid == 0) { bs->bcast[1] = med; bs->bcast[2] = (n & 1) ? vk : (vkm1 + vk) / 2.0f; }
         }
         __syncthreads();
         o.med = bs->bcast[1]; o.mad = bs->bcast[2];
         __syncthreads();
         phase(16);
+        return o;
+    }
+    if (have_medmad && n <= BS_SMALLCAP) {
+        // the adapter (its median and MAD come from k_validate): one read into LDS, the two sums there
+        LDS float *cp = (LDS float *)bs->u.stage; // (runs on into the histogram's storage)
+        __syncthreads();
+        bs_copy_to_lds(x, n, cp);
+        __syncthreads();
+        o.mean = bs_lds_np_sum(cp, n, 0, 0.f, bs) / (float)n;
+        if (o.mean != o.mean) { // (a NaN or infinities of both signs: np.std is NaN either way)
+            o.sd = __builtin_nanf("");
+        } else o.sd = sqrtf(bs_lds_np_sum(cp, n, 2, o.mean, bs) / (float)n);
+        o.med = med_in; o.mad = mad_in;
         return o;
     }
     // ---- pass A: mean + bucket histogram --------------------------------------------------

@@ -33,6 +33,7 @@ for side, name in ((0, "plain sums"), (1, "pass A (histogram)"), (2, "pass B (co
     q = d[25 + 4 * side: 29 + 4 * side].astype(float)
     print("  np_sum %-20s cycles per read: whole chunks %.0f  ragged side effects %.0f  leaves + tree %.0f  epilogue %.0f" % ((name,) + tuple(q / R)))
 print("  median phase: up to the bucket select %.0f cycles per read; lower-median passes %d of %d; mean bucket count %.1f" % (d[37] / R, d[38], R, d[39] / max(R, 1)))
+print("  small-segment path, cycles per read: first sum %.0f  second sum %.0f  LDS copy %.0f  median select %.0f  MAD select %.0f" % tuple(d[40:45] / R))
 ns = (d[25:29] + d[29:33] + d[33:37]).astype(float)
 print("inside the summing passes of the large segments (both passes): whole chunks %.1f%%  ragged part's side effects %.1f%%  its leaves + tree %.1f%%  epilogue %.1f%%  (= %.1f%% of all phases)"
       % (tuple(100 * ns / ns.sum()) + (100 * ns.sum() / ph.sum(),)))
