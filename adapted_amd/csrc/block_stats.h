@@ -408,6 +408,118 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     return r;
 }
 
+// x_(k) and x_(k-1) of xform(x[0..n)) for an LDS array of at most BSEL_CAP elements, by ALL 256 threads (the semantics of
+// wave_select2_impl: NaN if any element is NaN; MSB-first radix select over key - min, 8 bits of the span per pass).  A thread
+// keeps its <= 12 keys in registers; a pass is one histogram of LDS atomics and two barriers (two histograms in turn), every
+// wave locates the bin for itself.  One wave doing the same on its own (wave_select2_lds) took 40-46 k cycles for the 1470 samples
+// of a poly(A) slice and 30-60 k for the few dozen of a median bucket / MAD bracket: a quarter of this kernel's time at short windows.
+// Scratch: the head of the staging rows (x lives in the histogram's storage).  All threads return the values.
+#define BSEL_CAP 3072
+static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS BlockScratch *bs,
+                                                      float &vk, float &vkm1)
+{
+    const int tid = threadIdx.x, ln = tid & 63;
+    LDS uint32_t *sc = (LDS uint32_t *)bs->u.stage; // [0, 512): two histograms; 512: min key, 513: max key, 514: below, 515: NaN seen
+    uint32_t key[BSEL_CAP / BS_THREADS];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    bool has_nan = false;
+#pragma unroll
+    for (int u = 0; u < BSEL_CAP / BS_THREADS; u++) {
+        const int i = tid + u * BS_THREADS;
+        key[u] = 0u;
+        if (i < n) {
+            const float xf = ws_xform(x[i], mode, c);
+            has_nan |= xf != xf;
+            const uint32_t kk = f2key(xf);
+            key[u] = kk; mn = kk < mn ? kk : mn; mx = kk > mx ? kk : mx;
+        }
+    }
+    if (tid < 4) sc[512 + tid] = tid == 0 ? 0xffffffffu : 0u;
+    __syncthreads();
+    mn = wave_min(mn); mx = wave_max(mx);
+    const bool wnan = __any(has_nan);
+    if (ln == 0) {
+        __hip_atomic_fetch_min(&sc[512], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(&sc[513], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wnan) sc[515] = 1u;
+    }
+    __syncthreads();
+    mn = sc[512]; mx = sc[513];
+    if (sc[515]) { vk = __builtin_nanf(""); vkm1 = vk; __syncthreads(); return; }
+    const uint32_t span = mx - mn;
+    int rb = span ? 32 - __clz(span) : 0; // bits of d = key - min still unresolved
+    uint32_t prefix = 0, krem = (uint32_t)k, below = 0;
+    int lowbin = -1, lastw = 0, par = 0;
+    while (rb > 0) {
+        const int w = rb < 8 ? rb : 8;
+        const int shift = rb - w;
+        LDS uint32_t *hist = sc + par * 256;
+        hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < BSEL_CAP / BS_THREADS; u++) {
+            const int i = tid + u * BS_THREADS;
+            const uint32_t d = key[u] - mn;
+            const uint32_t top = (rb >= 32) ? 0u : (d >> rb);
+            if (i < n) {
+                if (top == prefix) __hip_atomic_fetch_add(&hist[(d >> shift) & ((1u << w) - 1u)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else if (shift == 0 && top < prefix && d + 1u > below) below = d + 1u;
+            }
+        }
+        __syncthreads();
+        // the bin of rank krem: each lane owns 4 consecutive bins (every wave for itself: no third barrier)
+        const uint32_t h0 = hist[4 * ln], h1 = hist[4 * ln + 1], h2 = hist[4 * ln + 2], h3 = hist[4 * ln + 3];
+        const int s = (int)(h0 + h1 + h2 + h3);
+        const int incl = wave_scan_incl(s);
+        const int excl = incl - s;
+        const bool mine = (int)krem >= excl && (int)krem < incl;
+        int bin = 0, before = 0;
+        if (mine) {
+            int cacc = excl;
+            if ((int)krem < cacc + (int)h0) { bin = 4 * ln; before = cacc; }
+            else { cacc += h0;
+                if ((int)krem < cacc + (int)h1) { bin = 4 * ln + 1; before = cacc; }
+                else { cacc += h1;
+                    if ((int)krem < cacc + (int)h2) { bin = 4 * ln + 2; before = cacc; }
+                    else { cacc += h2; bin = 4 * ln + 3; before = cacc; } } }
+        }
+        const unsigned long long mm = __ballot(mine);
+        const int src = __ffsll((long long)mm) - 1;
+        bin = __shfl(bin, src);
+        before = __shfl(before, src);
+        if (shift == 0) {
+            int cand = -1; // largest non-empty bin below `bin` among this lane's four
+            if (4 * ln < bin && h0) cand = 4 * ln;
+            if (4 * ln + 1 < bin && h1) cand = 4 * ln + 1;
+            if (4 * ln + 2 < bin && h2) cand = 4 * ln + 2;
+            if (4 * ln + 3 < bin && h3) cand = 4 * ln + 3;
+            lowbin = wave_max(cand);
+            lastw = w;
+        }
+        prefix = (prefix << w) | (uint32_t)bin;
+        krem -= (uint32_t)before;
+        rb = shift;
+        par ^= 1;
+    }
+    vk = key2f(mn + prefix);
+    vkm1 = vk;
+    if (krem == 0 && k > 0) { // first of its key: the value before it is the largest key below
+        below = wave_max(below);
+        if (ln == 0 && below) __hip_atomic_fetch_max(&sc[514], below, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        below = sc[514];
+        uint32_t d0 = below ? below - 1u : 0u;
+        bool have = below != 0;
+        if (span && lowbin >= 0) {
+            uint32_t da = (prefix & ~((1u << lastw) - 1u)) | (uint32_t)lowbin;
+            if (!have || da > d0) d0 = da;
+            have = true;
+        }
+        if (have) vkm1 = key2f(mn + d0);
+    }
+    __syncthreads();
+}
+
 // A SHORT segment (the poly(A) slice, the adapter) is read from global memory ONCE, into LDS; its sums and selections run there.
 // BS_SMALLCAP: the staging rows and the histogram storage taken together (they are adjacent in BlockScratch).
 #define BS_SMALLCAP (32 * BS_LEAF_STRIDE + BS_BINS)
@@ -509,22 +621,15 @@ struct SegStats { float mean, sd, med, mad; };
 static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs, const LDS float *buf, int cnt, int n, int rk,
                                                            uint32_t below_key)
 {
-    const int tid = threadIdx.x;
     __syncthreads();
-    if (tid < 64) {
-        float vk, vkm1;
-        wave_select2_lds(buf, cnt, rk, 0, 0.f, &bs->u.ws, vk, vkm1);
-        float res = vk;
-        if ((n & 1) == 0) {
-            float lo = (rk >= 1) ? vkm1 : key2f(below_key);
-            res = (lo + vk) / 2.0f;
-        }
-        if (tid == 0) bs->bcast[1] = res;
+    float vk, vkm1;
+    block_select2_lds(buf, cnt, rk, 0, 0.f, bs, vk, vkm1); // (cnt <= BS_MEDCAP)
+    float res = vk;
+    if ((n & 1) == 0) {
+        float lo = (rk >= 1) ? vkm1 : key2f(below_key);
+        res = (lo + vk) / 2.0f;
     }
-    __syncthreads();
-    float r = bs->bcast[1];
-    __syncthreads();
-    return r;
+    return res;
 }
 
 // largest key below `key_lo` among x[0..n) (0 if none) -- all threads return it
@@ -752,18 +857,13 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         sub(40);
         o.sd = sqrtf(bs_lds_np_sum(cp, n, 2, o.mean, bs) / (float)n);
         sub(41);
-        if (tid < 64) {
-            float vk, vkm1;
-            wave_select2_lds(cp, n, k1, 0, 0.f, &bs->u.ws, vk, vkm1);
-            const float med = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
-            sub(43);
-            wave_select2_lds(cp, n, k1, 1, med, &bs->u.ws, vk, vkm1);
-            sub(44);
-            if (tid == 0) { bs->bcast[1] = med; bs->bcast[2] = (n & 1) ? vk : (vkm1 + vk) / 2.0f; }
-        }
-        __syncthreads();
-        o.med = bs->bcast[1]; o.mad = bs->bcast[2];
-        __syncthreads();
+        float vk, vkm1;
+        block_select2_lds(cp, n, k1, 0, 0.f, bs, vk, vkm1);
+        o.med = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+        sub(43);
+        block_select2_lds(cp, n, k1, 1, o.med, bs, vk, vkm1);
+        o.mad = (n & 1) ? vk : (vkm1 + vk) / 2.0f;
+        sub(44);
         phase(16);
         return o;
     }
@@ -881,9 +981,9 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         const bool need_prev = (n & 1) == 0;
         __syncthreads();
         if (M <= BS_MADCAP && rel >= (need_prev ? 1 : 0) && rel < M) {
+            float vk, vkm1;
+            block_select2_lds((const LDS float *)bs->hist, M, rel, 1, o.med, bs, vk, vkm1); // (M <= BS_MADCAP)
             if (tid < 64) {
-                float vk, vkm1;
-                wave_select2_lds((const LDS float *)bs->hist, M, rel, 1, o.med, &bs->u.ws, vk, vkm1);
                 const float lo = need_prev ? vkm1 : vk;
                 // |x - med| and |x - c| differ by at most |med - c|: a selected value that far (plus slack) inside
                 // [P, Q] cannot be overtaken by a sample counted as "closer" or dropped as "farther"
