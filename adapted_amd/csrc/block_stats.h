@@ -321,16 +321,6 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     phase(25);
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
-        { // the side effects of the ragged part: eight loads in flight per thread (one by one, each waited for its own round trip)
-            const X xs = x + s;
-            for (int base = 0; base < tail; base += BS_THREADS * 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; v[u] = ld_if(xs, i, i < tail); }
-#pragma unroll
-                for (int u = 0; u < 8; u++) if (base + u * BS_THREADS + tid < tail) bs_side<SIDE>(v[u], param, bs, aux, aux2);
-            }
-        }
         phase(26);
         // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
         bs_tail_leaves(tail, bs);
@@ -354,11 +344,12 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
                 va[q] = xt[off + (ln < last ? ln : last)];
                 vb[q] = xt[off + (ln + 64 < last ? ln + 64 : last)];
             }
+            // (the side effects of the ragged part ride on these loads: the leaves cover every sample of it exactly once)
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 LDS float *dst = bs->u.stage + (w * 8 + q) * BS_LEAF_STRIDE;
-                if (ln < lens[q]) dst[ln] = bs_x2(va[q], mode, c);
-                if (ln + 64 < lens[q]) dst[ln + 64] = bs_x2(vb[q], mode, c);
+                if (ln < lens[q]) { dst[ln] = bs_x2(va[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(va[q], param, bs, aux, aux2); }
+                if (ln + 64 < lens[q]) { dst[ln + 64] = bs_x2(vb[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(vb[q], param, bs, aux, aux2); }
             }
             __syncthreads();
             // thread (leaf = tid >> 3, j = tid & 7): accumulator chain j of numpy's 8-accumulator leaf
