@@ -248,8 +248,11 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     const int w = tid >> 6, ln = tid & 63;
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
     const int nchunk = n / 8192;
-    const int myslabs = nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0; // slabs this wave streams
-    auto slab_off = [&](int q) { return (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
+    // fewer chunks than waves (a short RNA part): the SLABS go round the waves instead -- wave w takes slabs w, w + 4, ... of the
+    // 8 * nchunk -- so that all four stream; the slab sums then meet in LDS (bs->tleaf, free until the ragged part) for the chunks' trees
+    const bool slabwise = nchunk < 4;
+    const int myslabs = slabwise ? 2 * nchunk : (nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0); // slabs this wave streams
+    auto slab_off = [&](int q) { return slabwise ? (long long)(w + 4 * q) * 1024 : (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
     // software pipeline: the loads of the next PF slabs fly (as raw samples) while this one is summed
     constexpr int PF = X::PREFETCH;
     typename X::Raw4 pf[PF][4];
@@ -304,6 +307,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
         r = r + __shfl_xor(r, 8);   // the slab's 8 leaves: three levels of numpy's balanced tree
         r = r + __shfl_xor(r, 16);
         r = r + __shfl_xor(r, 32);
+        if (slabwise) { if (ln == 0) bs->tleaf[w + 4 * q] = r; continue; }
         if (ln == (q & 7)) slabsum = r;
         if ((q & 7) == 7) { // chunk complete: the top three levels over its 8 slab sums (lanes 0..7)
             float cs = slabsum;
@@ -315,6 +319,13 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
         }
     }
     __syncthreads();
+    if (slabwise && nchunk > 0) {
+        if (tid < nchunk) {
+            const LDS float *t = bs->tleaf + 8 * tid;
+            bs->chunk_sum[tid] = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        __syncthreads();
+    }
     if (tid == 0) for (int ch = 0; ch < nchunk; ch++) total += bs->chunk_sum[ch]; // numpy adds the chunk sums in sequence
     s = nchunk * 8192;
     __syncthreads();
