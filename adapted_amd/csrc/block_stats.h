@@ -250,7 +250,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     const int nchunk = n / 8192;
     // fewer chunks than waves (a short RNA part): the SLABS go round the waves instead -- wave w takes slabs w, w + 4, ... of the
     // 8 * nchunk -- so that all four stream; the slab sums then meet in LDS (bs->tleaf, free until the ragged part) for the chunks' trees
-    const bool slabwise = nchunk < 4;
+    const bool slabwise = nchunk <= 16; // (tleaf holds 128 slab sums)
     const int myslabs = slabwise ? 2 * nchunk : (nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0); // slabs this wave streams
     auto slab_off = [&](int q) { return slabwise ? (long long)(w + 4 * q) * 1024 : (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
     // software pipeline: the loads of the next PF slabs fly (as raw samples) while this one is summed
