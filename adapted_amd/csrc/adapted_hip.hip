@@ -517,7 +517,10 @@ static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch
     dim3 sg(sb, n_mb);
     const double thr = h->cfg.sig_norm_outlier_thresh;
     // big minibatches: both statistics from ONE pass (n1_fused.h); whatever it cannot verify is left to the passes below
-    const long long fused_min = getenv("ADP_N1_FUSED_MIN") ? atoll(getenv("ADP_N1_FUSED_MIN")) : (1ll << 24);
+    // (2^22 samples: the reference's defaults -- 1000 reads per minibatch at the preset's 16 000-sample window, 1.6e7 -- lie just
+    // under 2^24, where this threshold stood until the end of round 3: the preset ran the three-pass path, 5.3 instead of 3.0 ms per
+    // 96 000 reads.  A bracket that misses on a small minibatch costs the fused pass and falls through to those passes.)
+    const long long fused_min = getenv("ADP_N1_FUSED_MIN") ? atoll(getenv("ADP_N1_FUSED_MIN")) : (1ll << 22);
     if ((long long)minibatch * T >= fused_min && T >= 64) {
         if (h->cbuf.ensure((size_t)n_mb * N1_CB_CAP * 4) || h->fz.ensure((size_t)n_mb * sizeof(N1Fused)) ||
             h->fcnt.ensure((size_t)n_mb * 8 * N1F_NCNT) || h->n1heavy.ensure((size_t)n_mb * N1H_WORDS * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
