@@ -691,6 +691,8 @@ def main():
         for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=3, warmup=1)),
                          ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
                          ("pareto", dict(lens="pareto", steps=4, warmup=1)),
+                         # the reference's own defaults: the preset's 16 000-sample window, 1000 reads per minibatch
+                         ("llr_default_window", dict(max_obs_trace=16000, steps=4, warmup=1)),
                          ("int16", dict(int16=True, steps=4, warmup=1)),
                          # the headline cut into groups of minibatches software-pipelined over three internal streams
                          # (adp_detect_llr's opt-in grouped execution): the cross-phase overlap experiment, kept as a measurement
