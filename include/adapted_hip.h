@@ -324,7 +324,11 @@ int adp_kernel_times(adp_handle *h, const char **names_out, float *ms_out, int c
 /* Debug/inspection of intermediate stages of the last LLR call (tests only).
  * what: 0 norm params double[4*n_minibatch]; 1 n_valid int32[n]; 2 pooled float32[n*Lp];
  *       3 trace float64[n*Lp] (pass-2 trace after a full call); 4 adapter idx int32[n];
- *       5 polya idx int32[n]; 6 Lp (int32[1]) */
+ *       5 polya idx int32[n]; 6 Lp (int32[1]); 7 the T1 pairs int32[2*n];
+ *       8 process-wide tallies uint64[8..48] (cumulative): 0 large S1 segments, 1 MAD brackets that held, 2 generic median
+ *         selections, 3 MADs not predicted, 4 MAD bracket overflows (0-4 are kept on 256 cache lines by workgroup and summed
+ *         here: per-workgroup device atomics on one address serialise chip-wide), 5 single-pass N1 attempts, 6 / 7 their
+ *         median / MAD misses, 22 / 23 N1 heavy keys / samples; the rest: phase cycles of -DADP_PHASE_TIMING builds */
 int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes);
 /* Run the LLR pipeline only up to a stage (1 N1, 2 pool, 3 cumsum, 4 gains1, 5 adapter, 6 gains2, 7 polya) */
 int adp_debug_llr_upto(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
