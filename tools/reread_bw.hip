@@ -6,15 +6,18 @@
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-template <int THREADS, int UNROLL, bool NT2>
+// REV: the second pass walks the row from its END (what pass 1 read last is what a cache still holds)
+template <int THREADS, int UNROLL, bool NT2, bool REV = false>
 __global__ void __launch_bounds__(THREADS) k_twice(const float *__restrict__ x, int m, int T, int passes, float *out, int lds_pad)
 {
     extern __shared__ float pad[]; // occupancy limiter
     const f4 *row = reinterpret_cast<const f4 *>(x + (size_t)blockIdx.x * m);
     f4 acc = {0, 0, 0, 0};
+    const int nrounds = (T / 4) / (UNROLL * THREADS);
     for (int p = 0; p < passes; p++) {
-        int i = threadIdx.x;
-        for (; i + (UNROLL - 1) * THREADS < T / 4; i += UNROLL * THREADS) {
+        for (int rd = 0; rd < nrounds; rd++) {
+            const int rr = (REV && p == passes - 1) ? nrounds - 1 - rd : rd;
+            const int i = rr * UNROLL * THREADS + threadIdx.x;
             f4 v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++)
@@ -58,6 +61,10 @@ int main()
         run("1024 u2", k_twice<1024, 2, false>, 1024, 1, passes);
         run("1024 nt2", k_twice<1024, 4, true>, 1024, 1, passes);
         run("512 nt2", k_twice<512, 4, true>, 512, 2, passes);
+        run("256 rev", k_twice<256, 4, false, true>, 256, 5, passes);
+        run("256 rev nt2", k_twice<256, 4, true, true>, 256, 5, passes);
+        run("256 rev", k_twice<256, 4, false, true>, 256, 2, passes);
+        run("1024 rev", k_twice<1024, 4, false, true>, 1024, 1, passes);
     }
     return 0;
 }
