@@ -31,7 +31,12 @@ __global__ void __launch_bounds__(THREADS) k_twice(const float *__restrict__ x, 
     if (s == 123.456f) { out[0] = s; pad[lds_pad] = s; }
 }
 
-int main()
+__global__ void k_fill(float *x, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += 65536ull * 256ull) { unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; x[i] = 60.0f + (float)(h & 0xffff) * 0.001f; }
+}
+
+int main(int argc, char **)
 {
     const int m = 201500, T = 200000;
     const size_t bytes = (size_t)24 << 30;
@@ -39,6 +44,10 @@ int main()
     float *d, *o;
     if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&o, 4) != hipSuccess) return 1;
     (void)hipMemset(d, 0, bytes);
+    if (argc > 1) { // non-zero, non-uniform contents (a zero-filled buffer could flatter a cache or the memory controller)
+        hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, d, bytes / 4);
+        (void)hipDeviceSynchronize();
+    }
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     auto run = [&](const char *name, auto kern, int threads, int per_cu, int passes) {
         const int lds = 160 * 1024 / per_cu - 512; // so that exactly per_cu workgroups fit a CU
