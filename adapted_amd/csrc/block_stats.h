@@ -139,10 +139,9 @@ template <int SIDE>
 static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BlockScratch *bs, uint32_t &aux, uint32_t &aux2)
 {
     if (SIDE == SIDE_HIST) {
-        uint32_t kb = f2key(v) >> BS_KSH;
-        if (kb < p.key) aux++;
-        else if (kb - p.key < (uint32_t)BS_BINS)
-            __hip_atomic_fetch_add(&bs->hist[kb - p.key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t d = (f2key(v) >> BS_KSH) - p.key; // wraps for buckets below the window
+        const uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS + (d >> 31); // (as bs_side4)
+        __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t key = f2key(v);
         uint32_t kb = key >> BS_KSH;
@@ -174,10 +173,10 @@ static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, fl
         const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            uint32_t kb = f2key(vv[i]) >> BS_KSH;
-            uint32_t d = kb - p.key;                    // wraps for kb < p.key
-            aux += (kb < p.key) ? 1u : 0u;
-            uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS; // dump cell
+            const uint32_t d = (f2key(vv[i]) >> BS_KSH) - p.key; // wraps for buckets below the window (20-bit buckets: bit 31 set)
+            // two dump cells behind the window's bins: BS_BINS for samples above it, BS_BINS + 1 for those below -- the count
+            // the bucket search needs, read once after the pass instead of a compare and an add per sample
+            const uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS + (d >> 31);
             __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
@@ -392,8 +391,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }
     __syncthreads();
     if (SIDE == SIDE_HIST) {
-        uint32_t w = (uint32_t)wave_sum((int)aux);
-        if ((tid & 63) == 0 && w) __hip_atomic_fetch_add(&bs->below, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid == 0) bs->below = bs->hist[BS_BINS + 1]; // samples in buckets below the window (the second dump cell)
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t w = wave_max(aux);
         if ((tid & 63) == 0 && w) __hip_atomic_fetch_max(&bs->below, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -890,7 +888,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         { const uint32_t kb = f2key(pivot) >> BS_KSH; wlo = kb >= BS_BINS / 2 ? kb - BS_BINS / 2 : 0u; } // centred on the pivot
     }
     __syncthreads();
-    for (int i = tid; i < BS_BINS; i += BS_THREADS) bs->hist[i] = 0;
+    for (int i = tid; i < BS_BINS + 4; i += BS_THREADS) bs->hist[i] = 0; // (the bins and the dump cells behind them)
     __syncthreads();
     sp.key = wlo;
     SumAux p1 = (have_medmad || (g_ablate & 2048)) ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, sp);
