@@ -49,7 +49,7 @@ struct BlockScratch {
         float stage[32 * BS_LEAF_STRIDE];
         WaveScratch ws; // generic wave-level fallbacks reuse the staging area
     } u;
-    uint32_t hist[BS_BINS + 4]; // (+ dump cell for out-of-window samples) pass A histogram; pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
+    uint32_t hist[BS_BINS + 4]; // pass A: below-window cell, BS_BINS bins, above-window cell (bs_bins); pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
     float chunk_sum[BS_MAXCHUNK]; // sums of the whole numpy chunks of the segment under way
     float tleaf[128]; // leaf sums of a ragged chunk, by tree slot
     int scan[8];
@@ -64,6 +64,15 @@ struct BlockScratch {
 
 // samples of the median's bucket: behind the MAD bracket's in the histogram's storage (BS_MADCAP + BS_MEDCAP <= BS_BINS)
 static __device__ __forceinline__ LDS float *bs_collect(LDS BlockScratch *bs) { return (LDS float *)bs->hist + BS_MADCAP; }
+// pass A's histogram: hist[0] counts the samples in buckets BELOW the window, hist[1 .. BS_BINS] are the window's bins, hist[BS_BINS + 1]
+// counts those above -- so that a sample's cell is ONE signed clamp of (bucket - window start) to [-1, BS_BINS] (v_med3_i32) plus 1
+static __device__ __forceinline__ LDS uint32_t *bs_bins(LDS BlockScratch *bs) { return bs->hist + 1; }
+static __device__ __forceinline__ int bs_cell(float v, uint32_t wlo)
+{
+    const int d = (int)((f2key(v) >> BS_KSH) - wlo); // (20-bit buckets: the difference fits an int; negative below the window)
+    const int lo = d < -1 ? -1 : d;
+    return lo > BS_BINS ? BS_BINS : lo;
+}
 
 static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
 {
@@ -139,9 +148,7 @@ template <int SIDE>
 static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BlockScratch *bs, uint32_t &aux, uint32_t &aux2)
 {
     if (SIDE == SIDE_HIST) {
-        const uint32_t d = (f2key(v) >> BS_KSH) - p.key; // wraps for buckets below the window
-        const uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS + (d >> 31); // (as bs_side4)
-        __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&bs_bins(bs)[bs_cell(v, p.key)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t key = f2key(v);
         uint32_t kb = key >> BS_KSH;
@@ -173,11 +180,9 @@ static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, fl
         const float vv[4] = {v0, v1, v2, v3};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint32_t d = (f2key(vv[i]) >> BS_KSH) - p.key; // wraps for buckets below the window (20-bit buckets: bit 31 set)
-            // two dump cells behind the window's bins: BS_BINS for samples above it, BS_BINS + 1 for those below -- the count
-            // the bucket search needs, read once after the pass instead of a compare and an add per sample
-            const uint32_t cell = d < (uint32_t)BS_BINS ? d : (uint32_t)BS_BINS + (d >> 31);
-            __hip_atomic_fetch_add(&bs->hist[cell], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (the cells on either side of the window's bins take the samples outside it: the count below the window, which the
+            // bucket search needs, is read once after the pass instead of a compare and an add per sample)
+            __hip_atomic_fetch_add(&bs_bins(bs)[bs_cell(vv[i], p.key)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -391,7 +396,7 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     if (tid == 0) { bs->bcast[0] = total; bs->below = 0; bs->cntb = 0; }
     __syncthreads();
     if (SIDE == SIDE_HIST) {
-        if (tid == 0) bs->below = bs->hist[BS_BINS + 1]; // samples in buckets below the window (the second dump cell)
+        if (tid == 0) bs->below = bs->hist[0]; // samples in buckets below the window (the cell in front of the bins)
     } else if (SIDE == SIDE_COLLECT) {
         uint32_t w = wave_max(aux);
         if ((tid & 63) == 0 && w) __hip_atomic_fetch_max(&bs->below, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -801,7 +806,7 @@ static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_
     for (int i = tid; i < BS_BINS; i += BS_THREADS) dh[i] = 0;
     __syncthreads();
     for (int i = tid; i < BS_BINS; i += BS_THREADS) {
-        uint32_t h = bs->hist[i];
+        uint32_t h = bs_bins(bs)[i];
         if (h) {
             float xc = key2f(((wlo + (uint32_t)i) << BS_KSH) + (1u << (BS_KSH - 1)));
             float d = fabsf(xc - c) / w0;
@@ -912,7 +917,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
     int bin = 0, rk = 0;
     float c = 0.f, w0 = 0.f, P = 0.f, Q = 0.f, hw = 0.f;
     if (!have_medmad) {
-        block_find_bin<BS_BINS>(bs, bs->hist, k1, (int)p1.aux);
+        block_find_bin<BS_BINS>(bs, bs_bins(bs), k1, (int)p1.aux);
         fallback_med = bs->flag != 0;
         bin = bs->bin; rk = k1 - bs->before;
         __syncthreads();
