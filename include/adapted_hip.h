@@ -186,7 +186,10 @@ int adp_synchronize(adp_handle *h);
  * or partition statistics, its neighbour runs the float64 gains and the peak picking on its pooled trace; ADP_STAGGER=bits
  * orders phase p (bit 0 streaming-in, 1 gains, 2 validation) of consecutive groups.  Minibatches are independent of each
  * other, so the rows are the same bytes whatever the grouping (tests/test_gpu_grouped.py).  The default is one group: on
- * MI355X the overlap buys no time (profiles/r03_overlap_*), a smaller workspace is what grouping is for. */
+ * MI355X the overlap buys no time (profiles/r03_overlap_*), a smaller workspace is what grouping is for.
+ * N1 (the minibatch's median / MAD): minibatches of at least ADP_N1_FUSED_MIN samples (default 2^22 = minibatch x max_obs_trace;
+ * the reference's defaults are 1000 x 16 000) take ONE verified pass over the signal, smaller ones three or four; the values are
+ * the exact np.nanmedian / MAD either way. */
 int adp_detect_llr(adp_handle *h, const float *signals, const int32_t *full_len, int n_reads, int m,
                    int minibatch, int flags, adp_row *rows_out, int32_t *mb_status);
 
