@@ -7,8 +7,8 @@
 //   G1  c_llr_trace -> _gains(0, n-1, c, c2, 5, 5)      adapted/detect/_c_llr.pyx:202-236, 67-88
 //   G2  c_llr_trace_gains -> _gains(a, n-1, c, c2, 1, 1) adapted/detect/_c_llr.pyx:176-199
 //       var_c                                            adapted/detect/_c_llr.pyx:23-37
-//       (the reference's libc log is replaced by log_cr.h: correctly rounded in practice, 2x cheaper than
-//       the device library's)
+//       (the reference's libc log is replaced by log_cr.h's log_1ulp_fast: < 1 ULP like glibc's, 20 float64 operations
+//       against ~75 of the device library's; the correctly rounded log_cr_fast, 45, stays for the whole-window term and the trace API)
 //
 // np.cumsum is a strictly sequential float64 recurrence and the pass-2 trace next to the
 // adapter boundary is pure cumulative-sum rounding noise, so the recurrence is kept bit-exact:
@@ -400,7 +400,11 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
                     double vh = var_seg(b, c2s, a, cs, lh_len);
                     double vt = var_seg(te.y, b, te.x, a, lt_len);
                     // both logarithms side by side (independent instruction streams), exceptions patched afterwards
+#ifdef ADP_GAINS_LOG_CR
                     double lh = log_cr_fast(vh, lt), ll = log_cr_fast(vt, lt);
+#else
+                    double lh = log_1ulp_fast(vh, lt), ll = log_1ulp_fast(vt, lt); // (< 1 ULP in 20 operations: log_cr.h)
+#endif
                     if (!(log_cr_ok(vh) && log_cr_ok(vt))) {
                         if (!log_cr_ok(vh)) lh = gains_log_slow(vh);
                         if (!log_cr_ok(vt)) ll = gains_log_slow(vt);

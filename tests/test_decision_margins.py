@@ -1,8 +1,10 @@
 """Margin analysis of the threshold decisions that sit on float64 values the device does not compute in the reference's
 exact operation order:
 
-  * `log` of the gains: the device's table-driven logarithm is correctly rounded, glibc's misrounds a few per cent of its
-    arguments by one ulp -> LLR trace values differ from the reference's by ~1e-15 relative (test bar 1e-9);
+  * `log` of the gains: the batch path's table-driven logarithm is accurate to < 1 ulp (log_1ulp_fast, 20 float64
+    operations; glibc's, which the reference uses, is specified to < 1 ulp as well): a trace point is a difference of terms
+    `len * log(var)` of the order of 1e5, so it moves by up to ~2e-11 ABSOLUTE -- 1e-16 of the terms, up to 1e-13 of a
+    typical gain (test bar on the trace: 1e-9 relative);
   * `np.nanstd` of the clipped trace (threshold of P1, llr.py:204-224): one-pass float64 moments on the device instead of
     numpy's two passes -> the threshold `prominence * nanstd` differs by ~1e-15 relative;
   * the regression sums of P4 (llr.py:467-479): sequential float64 sums instead of a BLAS dot product.
@@ -12,8 +14,9 @@ Every one of them only feeds a comparison: `g > 0` (T1, llr.py:135-142), `promin
 sides to agree to ~12 significant digits.  This test measures, on the reference-exact traces of the CPU oracle (which equals
 the reference bit for bit on the golden stage vectors), how close the golden reads and 400 more synthetic reads -- both
 presets, two window lengths -- actually come: the smallest relative margin of every comparison is asserted to be above 1e-7,
-five orders of magnitude more than the perturbation.  A 1-ulp perturbation of the traces (np.nextafter on every value, both
-directions) is also pushed through the same decisions and must leave every index unchanged."""
+five orders of magnitude more than the perturbation.  Perturbed traces are also pushed through the same decisions and must leave
+every index unchanged: one ulp up / down on every value (np.nextafter), and independent random ABSOLUTE errors of 1e-15 of
+the trace's largest magnitude on every point (ten times what two < 1 ulp logarithms of 20 000-sample segments can add)."""
 import numpy as np
 import pytest
 from scipy.signal import find_peaks, peak_prominences, peak_widths
@@ -129,6 +132,18 @@ def test_threshold_decisions_have_margin(oracle_mod, chem, max_obs_trace, seed, 
             flips += f2 != first
             if st["cand"] >= 0 and g2.size:
                 flips += _p4_margins(np.where(g2 != 0.0, np.nextafter(g2, sgn), g2))[1] != res4
+        # ... and independent random absolute errors of 1e-15 of the largest magnitude of the trace on every computed point
+        rng = np.random.default_rng(1000 * seed + i)
+        for g, kind in ((g1, 1), (g2, 2)):
+            if kind == 2 and not (st["cand"] >= 0 and g2.size):
+                continue
+            finite = np.isfinite(g)
+            mag = float(np.max(np.abs(g[finite]), initial=1.0))
+            noisy = np.where((g != 0.0) & finite, g + rng.uniform(-1.0, 1.0, g.size) * 1e-15 * mag, g)
+            if kind == 1:
+                flips += _p1_margins(noisy, spc.llr_boundaries.adapter_peak_prominence, W, spc.llr_boundaries.adapter_peak_rel_height)[2] != first
+            else:
+                flips += _p4_margins(noisy)[1] != res4
     print("smallest relative margins (%s, T=%s): %s" % (chem, max_obs_trace, {k: "%.3g" % v for k, v in worst.items()}))
     assert flips == 0
     assert worst["p1"] > BAR and worst["p4"] > BAR and worst["t1"] > 1e-9, worst

@@ -20,15 +20,17 @@ def host_log(tmp_path_factory):
     d = tmp_path_factory.mktemp("logcr")
     src = d / "lg.cpp"
     src.write_text('#include "log_cr.h"\nextern "C" void log_cr_array(const double *x, double *y, long n) '
-                   "{ for (long i = 0; i < n; i++) y[i] = log_cr_host(x[i]); }\n")
+                   "{ for (long i = 0; i < n; i++) y[i] = log_cr_host(x[i]); }\n"
+                   'extern "C" void log_1ulp_array(const double *x, double *y, long n) '
+                   "{ for (long i = 0; i < n; i++) y[i] = log_1ulp_host(x[i]); }\n")
     so = d / "liblg.so"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, "-o", str(so), str(src)])
     lib = ctypes.CDLL(str(so))
 
-    def f(x):
+    def f(x, which="log_cr_array"):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty_like(x)
-        lib.log_cr_array(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(x.size))
+        getattr(lib, which)(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(x.size))
         return y
     return f
 
@@ -69,6 +71,27 @@ def test_log_cr_is_correctly_rounded_on_samples(host_log):
             worst = max(worst, float(abs(mp.mpf(float(yi)) - t) / mp.mpf(math.ulp(cr))))
     assert worst < 0.5001, worst
     assert wrong <= 2, wrong  # (none seen in 2e5 samples; the bound allows for a hard case)
+
+
+def test_log_1ulp_stays_below_one_ulp(host_log):
+    """the 17-operation form used by the batch path's gains kernels (log_1ulp_fast)"""
+    mp = pytest.importorskip("mpmath")
+    mp.mp.prec = 200
+    x = _inputs(4000, seed=13)
+    y = host_log(x, "log_1ulp_array")
+    worst = worst_near_one = 0.0
+    for xi, yi in zip(x, y):
+        t = mp.log(mp.mpf(float(xi)))
+        cr = float(t)
+        if cr != 0.0:
+            e = float(abs(mp.mpf(float(yi)) - t) / mp.mpf(math.ulp(cr)))
+            worst = max(worst, e)
+            if abs(xi - 1.0) < 2e-2:
+                worst_near_one = max(worst_near_one, e)
+    assert worst < 1.001, worst
+    assert worst_near_one < 0.75, worst_near_one
+    sp = host_log(np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 1.0]), "log_1ulp_array")
+    assert sp[0] == -np.inf and np.isnan(sp[1]) and sp[2] == np.inf and np.isnan(sp[3]) and sp[4] == math.log(5e-324) and sp[5] == 0.0
 
 
 def test_log_cr_specials_and_libm_agreement(host_log):
