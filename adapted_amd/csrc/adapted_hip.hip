@@ -24,6 +24,7 @@ __device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "validate.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
+#include "cnn_conv_split.h"
 #include "trace_api.h"
 #include "wave_stats.h"
 
@@ -85,6 +86,12 @@ struct adp_handle {
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
+    // conv stack: 1 = split float16 MFMA (cnn_conv_split.h, the default), 0 = exact float32 MFMA (cnn_conv.h; ADP_CNN_CONV=f32).
+    // cnn_redo_f32: the split kernels met an activation outside the float16 range in this call -- it is being repeated in float32
+    int cnn_mode = 1, cnn_act_kind = -1;
+    bool cnn_redo_f32 = false;
+    DevBuf cnn_wsp;          // split B fragments of layers 1 and 2
+    float cnn_sw[2] = {1.f, 1.f};
     // grouped execution of the LLR path (llr_grouped): child handles ("lanes") with their own streams and a workspace for ONE
     // group of minibatches; consecutive groups go to alternating lanes so that the phases of neighbouring groups overlap
     adp_handle *lane[ADP_MAX_LANES] = {};
@@ -248,6 +255,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
         hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; g_err = "hipStreamCreate failed"; return ADP_ERR_HIP; }
     if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) { adp_destroy(h); g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
+    { const char *cv = getenv("ADP_CNN_CONV"); if (cv && !strcmp(cv, "f32")) h->cnn_mode = 0; } // the exact-float32 conv stack (cnn_conv.h)
     *out = h;
     return ADP_OK;
 }
@@ -261,7 +269,7 @@ int adp_destroy(adp_handle *h)
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
-    DevBuf *all[] = {&h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -406,16 +414,21 @@ static int env_int(const char *name, int dflt)
 static int arena_begin(adp_handle *h)
 {
     if (h->op_used.ensure(8) || (h->op_arena.cap == 0 && h->op_arena.ensure((size_t)65536 * 4))) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-    HIPCHK(hipMemsetAsync(h->op_used.p, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->op_used.p, 0, 8, h->stream)); // [0] arena words wanted, [1] the split conv stack's out-of-range flag
     return 0;
 }
 // -> 0 done, 1 run the call again (arena grown), < 0 error
-static int arena_end(adp_handle *h)
+// (cnn: the call ran the conv stack -- its out-of-range flag is read with the counter; set = repeat the call on the float32 kernels)
+static int arena_end(adp_handle *h, bool cnn = false)
 {
-    if (!h->cfg.detect_open_pores) { h->op_last_used = 0; return 0; }
-    unsigned int used = 0;
-    HIPCHK(hipMemcpyAsync(&used, h->op_used.p, 4, hipMemcpyDeviceToHost, h->stream));
+    const bool conv_flag = cnn && h->cnn_mode == 1 && !h->cnn_redo_f32;
+    if (!h->cfg.detect_open_pores && !conv_flag) { h->op_last_used = 0; return 0; }
+    unsigned int w[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(w, h->op_used.p, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (conv_flag && w[1]) { h->cnn_redo_f32 = true; return 1; }
+    if (!h->cfg.detect_open_pores) { h->op_last_used = 0; return 0; }
+    const unsigned int used = w[0];
     h->op_last_used = used;
     if ((size_t)used * 4 <= h->op_arena.cap) return 0;
     if (h->op_arena.ensure((size_t)used * 8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
@@ -799,7 +812,7 @@ static int llr_grouped(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
             if (rc) { for (int i = 0; i < n_lanes; i++) (void)hipStreamSynchronize(lanes[i]->stream); return rc; }
         }
         for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamSynchronize(lanes[i]->stream));
-        rc = arena_end(h);
+        rc = arena_end(h, true);
         if (rc < 0) return rc;
         if (rc == 0) break;
         for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
@@ -1251,6 +1264,23 @@ int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const f
     memcpy(&all[CNN_W2], w2, sizeof(float) * CNN_C * CNN_C * CNN_K); memcpy(&all[CNN_B2], b2, sizeof(float) * CNN_C);
     memcpy(&all[CNN_W3], w3, sizeof(float) * CNN_C * 2 * CNN_K); memcpy(&all[CNN_B3], b3, sizeof(float) * 2);
     HIPCHK(hipMemcpyAsync(h->cnn_w.p, all.data(), (size_t)CNN_WTOTAL * 4, hipMemcpyHostToDevice, h->stream));
+    // the 64 -> 64 layers once more as split float16 B fragments (cnn_conv_split.h), scaled by a power of two per layer so that the
+    // largest weight lands in [2^13, 2^14)
+    if (h->cnn_wsp.ensure((size_t)2 * CNS_WSP_LAYER * 2)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    for (int layer = 0; layer < 2; layer++) {
+        const float *wl = &all[layer ? CNN_W2 : CNN_W1];
+        float mx = 0.f;
+        for (int i = 0; i < CNN_C * CNN_C * CNN_K; i++) { const float a = fabsf(wl[i]); if (a > mx && a < INFINITY) mx = a; }
+        int e = 0;
+        if (mx > 0.f) (void)frexpf(mx, &e); // mx = f 2^e, f in [0.5, 1)
+        int se = 14 - e;
+        if (se > 100) se = 100;
+        if (se < -100) se = -100;
+        h->cnn_sw[layer] = ldexpf(1.0f, se);
+        hipLaunchKernelGGL(k_cns_split_weights, dim3((2 * CNS_KSTEPS * 64 + 255) / 256), dim3(256), 0, h->stream,
+                           h->cnn_w.as<float>() + (layer ? CNN_W2 : CNN_W1), h->cnn_sw[layer], h->cnn_wsp.as<_Float16>() + (size_t)layer * CNS_WSP_LAYER);
+    }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->cnn_have_w = true;
     return ADP_OK;
@@ -1270,6 +1300,66 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 }
 } // extern "C++"
 
+extern "C++" {
+template <int NT>
+static int launch_conv64s(adp_handle *h, const _Float16 *in, _Float16 *out, const _Float16 *wsp, const float *b, float sw, int n, int L1,
+                          int Lrows, int tiles, int32_t *flag)
+{
+    const size_t lds = (size_t)2 * (((size_t)(64 * NT + 6) * CNS_ROWB + 1023) / 1024 * 1024);
+    const unsigned bit = 64u << (NT - 2);
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
+    long long total = (long long)n * tiles;
+    if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64s"; return ADP_ERR_UNSUPPORTED; }
+    int grid = (int)(total < h->n_cu ? total : h->n_cu);
+    hipLaunchKernelGGL(k_cnn_conv64s<NT>, dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
+    return 0;
+}
+} // extern "C++"
+
+// the conv stack on split float16 operands (cnn_conv_split.h); the out-of-range flag is the second word of the call's arena counter
+static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepared, int n_reads, int Lc, int L1, int Lo, int NT, float *scores_out)
+{
+    const int PB = 64 * NT, tiles = (L1 + PB - 1) / PB, Lrows = CNS_FRONT + tiles * PB + 4;
+    const size_t per_read = (size_t)Lrows * CNS_ROWB;
+    size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
+    if (cap_reads < 1) cap_reads = 1;
+    int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
+    if (h->cnn_act_kind != 1 || h->cnn_Lpad != Lrows || h->cnn_L1 != L1 || h->cnn_chunk < C) {
+        for (int k = 0; k < 2; k++) {
+            if (h->cnn_act[k].ensure((size_t)C * per_read + CNS_SLACK)) { g_err = "device allocation failed"; return ADP_ERR_HIP; } // (+ what the tile DMAs read past the last read's rows)
+            HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding rows are never written again
+        }
+        h->cnn_act_kind = 1; h->cnn_Lpad = Lrows; h->cnn_L1 = L1; h->cnn_chunk = (int)((h->cnn_act[0].cap - CNS_SLACK) / per_read);
+    }
+    C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
+    if (wh->op_used.ensure(8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    int32_t *flag = wh->op_used.as<int32_t>() + 1;
+    const float *W = wh->cnn_w.as<float>();
+    const _Float16 *wsp = wh->cnn_wsp.as<_Float16>();
+    _Float16 *A = h->cnn_act[0].as<_Float16>(), *B = h->cnn_act[1].as<_Float16>();
+    for (int s0 = 0; s0 < n_reads; s0 += C) {
+        const int n = n_reads - s0 < C ? n_reads - s0 : C;
+        const float *x = prepared + (size_t)s0 * Lc;
+        float *sc = scores_out + (size_t)s0 * 2 * Lo;
+        { Scope s(h, "k_cnn_conv_in");
+          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P - 1) / CNS_IN_P, n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
+        for (int layer = 0; layer < 2; layer++) {
+            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
+            const _Float16 *in = layer ? B : A; _Float16 *out = layer ? A : B;
+            const _Float16 *w = wsp + (size_t)layer * CNS_WSP_LAYER;
+            const float *b = W + (layer ? CNN_B2 : CNN_B1);
+            const float sw = wh->cnn_sw[layer];
+            int rc = NT == 4 ? launch_conv64s<4>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
+                   : NT == 3 ? launch_conv64s<3>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
+                             : launch_conv64s<2>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag);
+            if (rc) return rc;
+        }
+        { Scope s(h, "k_cnn_conv_out");
+          hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, h->stream, A, L1, Lrows, Lo, W + CNN_W3, W + CNN_B3, sc); }
+    }
+    return 0;
+}
+
 // the conv stack over device buffers, asynchronous on the handle's stream
 static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, int Lc, float *scores_out)
 {
@@ -1278,17 +1368,18 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
     const int L1 = (Lc + 2 * 3 - CNN_K) / 3 + 1, Lo = (L1 - 1) * 3 - 2 * 3 + CNN_K;
     // positions per workgroup step: the NT (32-position tiles per wave) that wastes least of the last step
     int NT = 4; { long long best = -1; for (int nt = 4; nt >= 2; nt--) { const long long pb = 64 * nt, cover = (L1 + pb - 1) / pb * pb; if (best < 0 || cover < best) { best = cover; NT = nt; } } }
+    if (wh->cnn_mode == 1 && !wh->cnn_redo_f32) return cnn_forward_split(h, wh, prepared, n_reads, Lc, L1, Lo, NT, scores_out);
     const int PB = 64 * NT, tiles = (L1 + PB - 1) / PB, Lpad = tiles * PB + 8;
     size_t per_read = (size_t)CNN_C * Lpad * 4;
     size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
     if (cap_reads < 1) cap_reads = 1;
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
-    if (h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
+    if (h->cnn_act_kind != 0 || h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
         for (int k = 0; k < 2; k++) {
             if (h->cnn_act[k].ensure((size_t)C * per_read)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
             HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding columns are never written again
         }
-        h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read);
+        h->cnn_act_kind = 0; h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read);
     }
     C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
     const float *W = wh->cnn_w.as<float>();
@@ -1319,10 +1410,20 @@ int adp_cnn_forward(adp_handle *h, const float *prepared, int n_reads, int Lc, f
     if (!h || !prepared || !scores_out || n_reads < 1 || Lc < 1) { g_err = "bad argument"; return ADP_ERR_INVALID; }
     HIPCHK(hipSetDevice(h->device));
     h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
-    int rc = cnn_forward_dev(h, prepared, n_reads, Lc, scores_out);
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    h->cnn_redo_f32 = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (h->op_used.ensure(8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+        HIPCHK(hipMemsetAsync(h->op_used.as<int32_t>() + 1, 0, 4, h->stream));
+        int rc = cnn_forward_dev(h, prepared, n_reads, Lc, scores_out);
+        if (rc) return rc;
+        HIPCHK(hipGetLastError());
+        int32_t flag = 0;
+        if (h->cnn_mode == 1 && !h->cnn_redo_f32) HIPCHK(hipMemcpyAsync(&flag, h->op_used.as<int32_t>() + 1, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (!flag) break;
+        h->cnn_redo_f32 = true; // an activation left the float16 range: once more on the float32 kernels
+        h->prof.clear(); h->ev_used = 0;
+    }
     return ADP_OK;
 }
 
@@ -1413,6 +1514,7 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
     h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     if (m <= h->cfg.min_obs_adapter) { g_err = "preload shorter than min_obs_adapter"; return ADP_ERR_INVALID; }
     if (!h->cnn_have_w) { g_err = "adp_cnn_set_weights has not been called"; return ADP_ERR_INVALID; }
+    h->cnn_redo_f32 = false;
     const float *dsig; const int32_t *dlen;
     int rc = stage_inputs(h, signals, full_len, n_reads, m, flags, &dsig, &dlen);
     if (rc) return rc;
@@ -1446,7 +1548,7 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
                          bounds_out, hipMemcpyDeviceToHost);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
-        rc = arena_end(h);
+        rc = arena_end(h, true);
         if (rc < 0) return rc;
         if (rc == 0) break;
         h->prof.clear(); h->ev_used = 0; h->last_grouped = false;

@@ -1,0 +1,317 @@
+// cnn_conv_split.h -- C2 on the float16 matrix cores at float32 accuracy (the default conv stack; cnn_conv.h is the exact-float32 one).
+//
+// reference adapted/detect/cnn.py:16-52 (BoundariesCNN), :85-98 (cnn_score): float32 throughout.  gfx950 has no fast float32
+// matrix path (v_mfma_f32_32x32x2_f32 runs at the vector rate, 1/16 of the float16 rate), so the two 64 -> 64 layers -- 98 % of the
+// arithmetic -- are computed from SPLIT operands instead: every float32 value v is carried as two float16 numbers
+//       hi = RN16(v),   lo = RN16((v - hi) * 2^11)            v = hi + lo 2^-11 (1 + e),  |e| <= 2^-11  ->  22 significant bits
+// (the residual is scaled so that it stays a normal float16 whatever v's magnitude), and a product of two such values is
+//       a w = a.hi w.hi + (a.hi w.lo + a.lo w.hi) 2^-11 + O(2^-22 |a w|)
+// three v_mfma_f32_32x32x16_f16 per 16 k-values, float16 products exact in the float32 accumulators, the cross terms in an
+// accumulator of their own that is folded in once per tile.  Error per product <= 3 * 2^-22 = 7e-7 relative (random in sign),
+// the same order as the rounding of a float32 fmaf chain over K = 448 terms; measured against torch float32 in
+// tests/test_gpu_cnn.py beside the exact-float32 kernels.  3 MFMAs x 32 cycles per 32 x 32 x 16 block against 8 x 64 for the float32
+// instruction: 5.3 x the matrix rate -- the layers become HBM-bound (1.8 MB read + 1.8 MB written per read and layer).
+//
+// Values outside the float16 range: activations are kept unscaled (|a| < 32768 asked for); a kernel that produces a larger or
+// non-finite activation anywhere raises the CALL's flag (a word beside the open-pore arena counter, read with it at the end of the
+// call: no extra host round trip), and the call is repeated on the float32 kernels of cnn_conv.h -- inputs like 1e30 pA or infinities
+// give the rows the float32 stack gives.  Weights are scaled per layer by a power of two (largest |w| s in [2^13, 2^14)); the factor
+// leaves with the bias in the epilogue.
+//
+// Layout: activations in HBM are CHANNEL-LAST rows, one per position: 64 hi | 64 lo | 8 pad float16 = 272 bytes, CNS_FRONT zero
+// rows in front of position 0 and zero rows behind L1 (the "same" padding is read, not branched on).  A workgroup step covers
+// PB = 64 NT positions x 64 channels: its input tile (PB + 6 rows) is ONE contiguous byte range, copied by LDS-DMA into the second
+// LDS buffer while the first is computed on.  The 272-byte row pitch shifts consecutive rows by 4 banks, so the A fragment of a
+// k-step -- one ds_read_b128 per lane and plane: 8 consecutive channels of one position and tap -- is conflict-free.
+// GEMM: M = output channels (A = weights, 2 planes x 28 k-steps x 4 VGPRs resident in registers), N = positions (B = activations
+// from LDS), K = (tap, channel).
+#pragma once
+#include "cnn_conv.h"
+
+typedef _Float16 cnn_h8 __attribute__((ext_vector_type(8)));
+#ifndef CNS_ABL
+#define CNS_ABL 0 // (development: 1 = no MFMAs, 2 = no epilogue stores)
+#endif
+
+#define CNS_ROW 136          // float16 per position row
+#define CNS_ROWB 272         // bytes
+#define CNS_FRONT 4          // zero rows in front of position 0
+#define CNS_KSTEPS 28        // 7 taps x 4 groups of 16 channels
+#define CNS_LIMIT 32768.0f   // activations at or beyond it (or non-finite) send the read to the float32 kernels
+#define CNS_SLACK 65536      // bytes behind the last read's rows that a tile DMA may read (k_cnn_conv_out_s: up to 130 rows from a row below L1)
+#define CNS_WSP_LAYER (2 * CNS_KSTEPS * 2 * 64 * 8) // float16 per layer in the split-weight buffer
+
+static __device__ __forceinline__ void cns_split(float y, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)y;
+    lo = (_Float16)((y - (float)hi) * 2048.0f);
+}
+static __device__ __forceinline__ float cns_join(_Float16 hi, _Float16 lo) { return __builtin_fmaf((float)lo, 1.0f / 2048.0f, (float)hi); }
+
+// ---------------------------------------------------------------- weights of a 64 -> 64 layer as B fragments
+// wsp [mh 2][k-step 28][plane 2][lane 64][8]: lane l of channel half mh holds W[o = 32 mh + (l & 31)][c = 16 cg + 8 (l >> 5) + e][t],
+// k-step = 4 t + cg, scaled by sw and split.
+__global__ void k_cns_split_weights(const float *__restrict__ w /* [64][64][7] */, float sw, _Float16 *__restrict__ wsp)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * CNS_KSTEPS * 64) return;
+    const int lane = idx & 63, k = (idx >> 6) % CNS_KSTEPS, mh = idx / (64 * CNS_KSTEPS);
+    const int t = k >> 2, cg = k & 3, o = 32 * mh + (lane & 31), c0 = 16 * cg + 8 * (lane >> 5);
+    _Float16 *dh = wsp + ((size_t)((mh * CNS_KSTEPS + k) * 2 + 0) * 64 + lane) * 8;
+    _Float16 *dl = wsp + ((size_t)((mh * CNS_KSTEPS + k) * 2 + 1) * 64 + lane) * 8;
+    for (int e = 0; e < 8; e++) {
+        const float v = w[((size_t)o * CNN_C + c0 + e) * CNN_K + t] * sw;
+        _Float16 hi, lo;
+        cns_split(v, hi, lo);
+        dh[e] = hi; dl[e] = lo;
+    }
+}
+
+// ---------------------------------------------------------------- layer 0: Conv1d(1 -> 64, k 7, stride 3, pad 3) + ReLU, split rows out
+// grid = (ceil(L1 / 128), n); block = 256: 128 positions, two threads per position (32 channels each: the float32 fmaf chain of
+// k_cnn_conv_in).  The rows are put together in LDS (272-byte pitch: conflict-free 16-byte writes) and leave as one contiguous,
+// fully coalesced copy -- written from the threads directly, a wave's store would touch 64 different rows.
+#define CNS_IN_P 128
+__global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__ x, int Lc, int L1, int Lrows,
+                                                        const float *__restrict__ w /* [64][1][7] */, const float *__restrict__ b,
+                                                        _Float16 *__restrict__ out, int32_t *__restrict__ flag)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 rows_[CNS_IN_P * CNS_ROW];
+    LDS _Float16 *rows = (LDS _Float16 *)rows_;
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * CNS_IN_P;
+    const int pl = threadIdx.x & (CNS_IN_P - 1), half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+    const int p = p0 + pl;
+    const float *row = x + (size_t)n * Lc;
+    float v[CNN_K];
+#pragma unroll
+    for (int t = 0; t < CNN_K; t++) { const int i = 3 * p + t - 3; v[t] = (i >= 0 && i < Lc) ? row[i] : 0.f; }
+    bool bad = false;
+    LDS _Float16 *o = rows + pl * CNS_ROW + 32 * half;
+    const float *wq = w + 32 * half * CNN_K, *bq = b + 32 * half;
+#pragma unroll 2
+    for (int c8 = 0; c8 < 4; c8++) {
+        cnn_h8 hh, ll;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int c = c8 * 8 + e;
+            float acc = bq[c];
+#pragma unroll
+            for (int t = 0; t < CNN_K; t++) acc = __builtin_fmaf(wq[c * CNN_K + t], v[t], acc);
+            bad |= p < L1 && !(__builtin_fabsf(acc) < CNS_LIMIT);
+            const float y = acc > 0.f ? acc : 0.f;
+            _Float16 hi, lo;
+            cns_split(y, hi, lo);
+            hh[e] = hi; ll[e] = lo;
+        }
+        *reinterpret_cast<LDS cnn_h8 *>(o + c8 * 8) = hh;
+        *reinterpret_cast<LDS cnn_h8 *>(o + 64 + c8 * 8) = ll;
+    }
+    __syncthreads();
+    // 17 16-byte pieces per row (the last one is the row's padding: stays as it is), rows at or beyond L1 stay zero
+    const int nrows = L1 - p0 < CNS_IN_P ? L1 - p0 : CNS_IN_P;
+    cnn_h8 *dst = reinterpret_cast<cnn_h8 *>(out + ((size_t)n * Lrows + CNS_FRONT + p0) * CNS_ROW);
+    const LDS cnn_h8 *src = reinterpret_cast<const LDS cnn_h8 *>(rows);
+    for (int i = threadIdx.x; i < nrows * 17; i += 256)
+        if (i % 17 != 16) __builtin_nontemporal_store(src[i], dst + i);
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------- layers 1, 2: Conv1d(64 -> 64, k 7, pad 3) + ReLU, split float16 MFMA
+// grid = persistent (one workgroup per CU); block = 256 = 4 waves = 2 channel halves (mh) x 2 position halves (ph);
+// dynamic LDS = 2 tiles of (64 NT + 6) rows, each rounded up to whole 1 KB DMA instructions.
+// GEMM orientation: M = output channels (A = weights), N = positions (B = activations), so D has the POSITION on the lane and four
+// consecutive channels in four consecutive registers: a lane stores 8 bytes (4 float16) per plane and channel group.
+// Synchronisation per step: the tile's DMA is the OLDEST of the wave's outstanding vector-memory operations (it was issued before
+// the previous step's stores), so a counted s_waitcnt leaves those stores in flight; every store of the epilogue is issued
+// unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
+typedef _Float16 cnn_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 cnn_h2 __attribute__((ext_vector_type(2)));
+typedef float cnn_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
+template <int NT>
+__global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
+                                                        const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
+                                                        float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
+                                                        int32_t *__restrict__ flag)
+{
+    constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
+    constexpr int NSTORE = 8 * NT; // vector-memory instructions of one epilogue
+    extern __shared__ float cns_lds_raw[];
+    LDS char *lds = (LDS char *)cns_lds_raw;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mh = wave & 1, ph = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // A fragments: lane l holds W[o = 32 mh + (l & 31)][c = 16 cg + 8 (l >> 5) + e][t] of k-step 4 t + cg, e = 0..7
+    cnn_h8 wh[CNS_KSTEPS], wl[CNS_KSTEPS];
+    {
+        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(wsp) + (size_t)(mh * CNS_KSTEPS) * 2 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < CNS_KSTEPS; k++) { wh[k] = wp[(size_t)(k * 2) * 64]; wl[k] = wp[(size_t)(k * 2 + 1) * 64]; }
+    }
+    // D layout: column = lane & 31 (position), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel inside the wave's 32)
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * sw;
+
+    const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
+    auto dma = [&](int tix, int b) {
+        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
+        // rows (position tile * PB - 3) ... of read n: one contiguous range (the instructions of the last KB read a little past it,
+        // into the next rows or the buffer's slack)
+        const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * PB) * CNS_ROWB + lane * 16;
+        for (int inst = wave; inst < NDMA; inst += 4)
+            __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + b * TILE_B + inst * 1024), 16, 0, 0);
+    };
+    int it = blockIdx.x;
+    int buf = 0;
+    // out of range = a float16 hi part of 32768 or more (or infinite), looked for as the largest bit pattern seen: the values are
+    // non-negative behind the ReLU, so patterns order like values.  (Rows at or beyond L1 of a read's last tile take part; they
+    // hold what real neighbours hold, and a needless flag only costs the float32 repeat.)
+    cnn_us2 hmax = {0, 0};
+    const float cx = inv_sw * (1.0f / 2048.0f);
+    if (it < total) dma(it, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; it < total; it += gridDim.x) {
+        // every wave has waited for its own share of tile `it` (before the loop / at the end of the previous step) and has
+        // finished reading the other buffer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        // B fragment of k-step (t, cg), position tile j: row ph * 32 NT + 32 j + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
+        const LDS char *tb = lds + buf * TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
+        cnn_f32x16 am[NT], ax[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am[j][r] = bs[r]; ax[j][r] = 0.f; }
+        cnn_h8 fh[2][NT], fl[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            fh[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB);
+            fl[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB + 128);
+        }
+#pragma unroll
+        for (int k = 0; k < CNS_KSTEPS; k++) {
+            if (k + 1 < CNS_KSTEPS) {
+                const int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    fh[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32);
+                    fl[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32 + 128);
+                }
+            }
+#if !(CNS_ABL & 1)
+#pragma unroll
+            for (int j = 0; j < NT; j++) am[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1][j], am[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; j++) ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], fh[k & 1][j], ax[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; j++) ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1][j], ax[j], 0, 0, 0);
+#else
+#pragma unroll
+            for (int j = 0; j < NT; j++) { am[j][k & 15] += (float)fh[k & 1][j][0] * (float)wh[k][0]; ax[j][k & 15] += (float)fl[k & 1][j][0] * (float)wl[k][0]; }
+#endif
+            asm volatile("" ::: "memory");
+        }
+        const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
+        _Float16 *obase = out + (size_t)n * Lrows * CNS_ROW + 32 * mh + 4 * lh;
+        const int p0 = tile * PB + ph * (NT * 32) + l31;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int p = p0 + 32 * j;
+            const bool valid = p < L1;
+            _Float16 *orow = obase + (size_t)(valid ? CNS_FRONT + p : 0) * CNS_ROW;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                // two values per instruction where the hardware has a packed form (v_pk_mul / v_pk_fma / v_cvt_pk_f16_f32 / v_pk_add):
+                // one wave per SIMD -- nothing hides the epilogue's vector instructions
+                cnn_h2 hq[2], lq[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const cnn_f2 a2 = {am[j][4 * g + 2 * q], am[j][4 * g + 2 * q + 1]}, x2 = {ax[j][4 * g + 2 * q], ax[j][4 * g + 2 * q + 1]};
+                    cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
+                    v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f}); // (a NaN becomes 0, as `v > 0 ? v : 0` makes it in k_cnn_conv64)
+                    const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
+                    const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+                    hq[q] = hi; lq[q] = __builtin_convertvector(rs, cnn_h2);
+                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+                }
+                const cnn_h4 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1]};
+#if (CNS_ABL & 2)
+                if (hh[0] == (_Float16)12345.f && ll[1] == (_Float16)77.f)
+#endif
+                *reinterpret_cast<cnn_h4 *>(orow + 8 * g) = hh; // (no streaming hint: a row's 16 pieces come from four instructions of
+#if (CNS_ABL & 2)
+                if (hh[0] == (_Float16)12345.f && ll[1] == (_Float16)77.f)
+#endif
+                *reinterpret_cast<cnn_h4 *>(orow + 64 + 8 * g) = ll; //  two waves and have to meet in the L2 -- with it: 4 x slower)
+            }
+        }
+        // the DMA issued at the top of this step is older than these NSTORE stores
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+        buf ^= 1;
+    }
+    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------- layer 3: ConvTranspose1d(64 -> 2, k 7, stride 3, pad 3) from split rows
+// the arithmetic of k_cnn_conv_out on a = hi + lo 2^-11; thread j makes the outputs 3 j, 3 j + 1, 3 j + 2 of both channels.
+// grid = (ceil(L1 / 128), n); block = 128: the 130 rows of the block are one contiguous range, brought into LDS by LDS-DMA
+// (coalesced) and read from there row by row (272-byte pitch: conflict-free 16-byte reads).
+#define CNS_OUT_P 128
+#define CNS_OUT_LDS (((CNS_OUT_P + 2) * CNS_ROWB + 1023) / 1024 * 1024)
+__global__ void __launch_bounds__(CNS_OUT_P) k_cnn_conv_out_s(const _Float16 *__restrict__ h, int L1, int Lrows, int Lo,
+                                                               const float *__restrict__ w /* [64][2][7] */, const float *__restrict__ b,
+                                                               float *__restrict__ scores /* [n][2][Lo] */)
+{
+    __shared__ __attribute__((aligned(16))) char rows_[CNS_OUT_LDS];
+    LDS char *rows = (LDS char *)rows_;
+    const int n = blockIdx.y;
+    const int j0 = blockIdx.x * CNS_OUT_P;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    {
+        const GLB char *src = (const GLB char *)h + ((size_t)n * Lrows + CNS_FRONT + j0 - 1) * CNS_ROWB + lane * 16;
+        for (int inst = wave; inst < CNS_OUT_LDS / 1024; inst += CNS_OUT_P / 64)
+            __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(rows + inst * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int j = j0 + threadIdx.x;
+    if (j >= L1) return;
+    const LDS char *hr = rows + (threadIdx.x + 1) * CNS_ROWB;
+    float y[2][3];
+#pragma unroll
+    for (int o = 0; o < 2; o++) { y[o][0] = b[o]; y[o][1] = b[o]; y[o][2] = b[o]; }
+#pragma unroll 2
+    for (int c8 = 0; c8 < CNN_C / 8; c8++) {
+        const cnn_h8 mh_ = *reinterpret_cast<const LDS cnn_h8 *>(hr - CNS_ROWB + c8 * 16), ml_ = *reinterpret_cast<const LDS cnn_h8 *>(hr - CNS_ROWB + 128 + c8 * 16);
+        const cnn_h8 zh_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + c8 * 16), zl_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + 128 + c8 * 16);
+        const cnn_h8 ph_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + c8 * 16), pl_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + 128 + c8 * 16);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float hm = cns_join(mh_[e], ml_[e]), h0 = cns_join(zh_[e], zl_[e]), hp = cns_join(ph_[e], pl_[e]);
+            const float *wc = w + (c8 * 8 + e) * 2 * CNN_K;
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                const float *wo = wc + o * CNN_K;
+                y[o][0] = __builtin_fmaf(hm, wo[6], y[o][0]);
+                y[o][0] = __builtin_fmaf(h0, wo[3], y[o][0]);
+                y[o][0] = __builtin_fmaf(hp, wo[0], y[o][0]);
+                y[o][1] = __builtin_fmaf(h0, wo[4], y[o][1]);
+                y[o][1] = __builtin_fmaf(hp, wo[1], y[o][1]);
+                y[o][2] = __builtin_fmaf(h0, wo[5], y[o][2]);
+                y[o][2] = __builtin_fmaf(hp, wo[2], y[o][2]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        float *so = scores + ((size_t)n * 2 + o) * Lo + 3 * j;
+#pragma unroll
+        for (int d = 0; d < 3; d++) if (3 * j + d < Lo) so[d] = y[o][d];
+    }
+}

@@ -278,12 +278,17 @@ def test_device_topk_behind_given_argmaxes():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("conv", ["split", "f32"])
 @pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4)])
-def test_hip_conv_stack_equals_torch(Lc, n):
-    """C2: the hand-written conv stack (adp_cnn_forward, float32 matrix cores) against torch's float32 conv1d /
-    conv_transpose1d on the same device with the shipped weights.  Both are float32 sums of the same 448 products per
-    output in different orders: tolerance 2e-5 relative to the score scale (the golden test pins the scores themselves)."""
+def test_hip_conv_stack_equals_torch(Lc, n, conv, monkeypatch):
+    """C2: the hand-written conv stacks (adp_cnn_forward) against torch's float32 conv1d / conv_transpose1d on the same device
+    with the shipped weights -- "split": the default, float16 matrix cores on split operands (cnn_conv_split.h); "f32": the exact
+    float32 matrix-core kernels (cnn_conv.h, ADP_CNN_CONV=f32).  The float32 stack and torch are float32 sums of the same 448
+    products per output in different orders, the split stack carries 22 bits per operand: tolerance 2e-5 relative to the score
+    scale for both (the golden test pins the scores themselves)."""
     import torch
+
+    monkeypatch.setenv("ADP_CNN_CONV", conv)
 
     from adapted_amd import lib
     from adapted_amd.detect import cnn
@@ -315,3 +320,94 @@ def test_hip_conv_stack_equals_torch(Lc, n):
     eng.cnn_forward(xt.data_ptr(), n, Lc, got2.data_ptr())
     assert torch.equal(got, got2)
     eng.close()
+
+
+def _conv_engine(monkeypatch, conv, spc, n, m):
+    from adapted_amd import lib
+
+    monkeypatch.setenv("ADP_CNN_CONV", conv)  # read by adp_create
+    return lib.Engine(spc, n, m, device=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window,n", [(None, 3000), (200000, 360)])
+def test_split_conv_gives_the_float32_stack_rows(window, n, monkeypatch):
+    """The default conv stack (split float16 operands) against the exact-float32 one on synthetic reads, through the whole CNN
+    path: the scores differ in their last bits (reported), every index and every other field of every row must not.  A read whose
+    rows differ would be reported with its candidates' score margins instead of loosening anything."""
+    from adapted_amd import lib, synth
+    from adapted_amd.config import get_chemistry_specific_config
+    from adapted_amd.detect import cnn
+
+    spc = get_chemistry_specific_config("RNA004")
+    if window:
+        spc.core.max_obs_trace = window
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m = spc.sig_preload_size
+    lens = np.array([m if i % 4 else synth.pareto_length(7, i) for i in range(n)], dtype=np.int32)
+    out = {}
+    for conv in ("split", "f32"):
+        eng = _conv_engine(monkeypatch, conv, spc, n, m)
+        dsig, dlen = eng.dev_alloc(n * m * 4), eng.dev_alloc(n * 4)
+        eng.h2d(dlen, lens)
+        eng.synth_fill(dsig, dlen, n, seed=11, first_read=0)
+        cnn.ensure_weights(eng, None, spc)
+        rows, bounds = eng.detect_cnn_rows(dsig, dlen, n, min(n, 1000), device_ptrs=True)
+        out[conv] = (rows.tobytes(), np.array(bounds))
+        eng.dev_free(dsig)
+        eng.dev_free(dlen)
+        eng.close()
+    differing = np.flatnonzero((out["split"][1] != out["f32"][1]).any(axis=1))
+    assert differing.size == 0, ("reads whose CNN indices differ between the conv stacks", differing[:20], out["split"][1][differing[:5]], out["f32"][1][differing[:5]])
+    assert out["split"][0] == out["f32"][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["huge", "inf", "huge_tail"])
+def test_split_conv_leaves_the_float16_range_to_the_float32_kernels(what, monkeypatch):
+    """An activation of 32768 or more (or a non-finite one) anywhere raises the call's flag and the call is repeated on the
+    float32 kernels: the scores are then the float32 stack's, BIT FOR BIT (a split result would differ in its last bits)."""
+    import torch
+
+    from adapted_amd.detect import cnn
+    from golden_cases import CASES
+    from util import make_spc
+
+    torch.cuda.init()
+    spc = make_spc(CASES["rna004_cnn_default"])
+    model = cnn.load_cnn_model(spc.cnn_boundaries.model_name, device=0)
+    n, Lc = 6, 1650
+    rng = np.random.default_rng(3)
+    x = rng.normal(0.0, 1.5, (n, 1, Lc)).astype(np.float32)
+    if what == "huge":
+        x[2, 0, 700:710] = 1e7  # layer 0 alone leaves the range
+    elif what == "inf":
+        x[4, 0, 100] = np.inf
+    else:
+        x[5, 0, -3:] = 1e7  # in the last tile of the last read
+    xt = torch.from_numpy(x).cuda()
+    got = {}
+    for conv in ("split", "f32"):
+        eng = _conv_engine(monkeypatch, conv, spc, 8, spc.sig_preload_size)
+        eng.cnn_set_weights({k: v for k, v in model.state_dict().items()})
+        L1 = (Lc - 1) // 3 + 1
+        sc = torch.full((n, 2, 3 * L1 - 2), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.cnn_forward(xt.data_ptr(), n, Lc, sc.data_ptr())
+        got[conv] = sc.cpu().numpy()
+        if conv == "split":  # the handle is back on the split kernels for the next, ordinary call
+            x2 = torch.from_numpy(rng.normal(0.0, 1.5, (n, 1, Lc)).astype(np.float32)).cuda()
+            sc2 = torch.empty_like(sc)
+            eng.cnn_forward(x2.data_ptr(), n, Lc, sc2.data_ptr())
+            with torch.no_grad():
+                ref2 = model(x2)
+            assert float((ref2 - sc2).abs().max()) < 1e-4
+            got["split_next"] = (sc2.cpu().numpy(), x2)
+        else:
+            sc2 = torch.empty_like(sc)
+            eng.cnn_forward(got["split_next"][1].data_ptr(), n, Lc, sc2.data_ptr())
+            # ... and there its scores are NOT the float32 stack's bits (so the comparison below does tell the stacks apart)
+            assert not np.array_equal(sc2.cpu().numpy(), got["split_next"][0])
+        eng.close()
+    assert np.array_equal(got["split"], got["f32"], equal_nan=True)
