@@ -16,8 +16,11 @@
  *   adp_detect_cnn          <- combined_detect_cnn(...)          adapted/detect/combined.py:230-250 (up to its short-read
  *                              fallback :251-301 = adp_llr_refine_polya + adp_validate_candidates)
  *   adp_cnn_prepare         <- prepare_data(...)                 adapted/detect/cnn.py:70-82
- *   adp_cnn_forward         <- BoundariesCNN.forward / cnn_score adapted/detect/cnn.py:16-52, 85-98 (hand-written float32
- *                              MFMA conv stack, adapted_amd/csrc/cnn_conv.h; PyTorch is not involved)
+ *   adp_cnn_forward         <- BoundariesCNN.forward / cnn_score adapted/detect/cnn.py:16-52, 85-98 (hand-written conv
+ *                              stack; default: float16 matrix cores on split float32 operands at float32 accuracy,
+ *                              adapted_amd/csrc/cnn_conv_split.h, with the exact float32 MFMA kernels of cnn_conv.h behind
+ *                              it for activations outside the float16 range -- or for every call when the handle was
+ *                              created with ADP_CNN_CONV=f32 in the environment; PyTorch is not involved)
  *   adp_cnn_predict         <- cnn_predict + cnn_detect scaling  adapted/detect/cnn.py:101-182
  *   adp_validate_candidates <- the validate_boundaries loop of combined_detect_cnn
  *                              adapted/detect/combined.py:243-305
