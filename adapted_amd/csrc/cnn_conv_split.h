@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                                                         int32_t *__restrict__ flag)
 {
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
-    constexpr int NSTORE = 8 * NT; // vector-memory instructions of one epilogue
+    constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
     extern __shared__ float cns_lds_raw[];
     LDS char *lds = (LDS char *)cns_lds_raw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -217,13 +217,16 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             asm volatile("" ::: "memory");
         }
         const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
-        _Float16 *obase = out + (size_t)n * Lrows * CNS_ROW + 32 * mh + 4 * lh;
-        const int p0 = tile * PB + ph * (NT * 32) + l31;
+        // EPILOGUE through LDS: the waves lay their split results down in the tile they have just consumed, in the rows' HBM
+        // layout, and the workgroup copies the PB rows out as one contiguous range, 16 bytes per lane (a lane's own 8-byte
+        // pieces reach the L2 as partial 16-byte writes from four instructions of two waves: 0.45 ms of a 2.5 ms layer).
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave has read its last fragment of this buffer
+        asm volatile("" ::: "memory");
+        LDS char *stg = lds + buf * TILE_B;
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const int p = p0 + 32 * j;
-            const bool valid = p < L1;
-            _Float16 *orow = obase + (size_t)(valid ? CNS_FRONT + p : 0) * CNS_ROW;
+            LDS char *srow = stg + (ph * (NT * 32) + 32 * j + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 // two values per instruction where the hardware has a packed form (v_pk_mul / v_pk_fma / v_cvt_pk_f16_f32 / v_pk_add):
@@ -240,14 +243,33 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                     hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
                 }
                 const cnn_h4 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1]};
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 16 * g) = hh;
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 128 + 16 * g) = ll;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            // rows tile * PB .. of read n; pieces of rows at or beyond L1 go to the read's row 0 (which nothing reads), so that
+            // every store is issued and the count below stays exact
+            const int nvalid = (L1 - tile * PB < PB ? L1 - tile * PB : PB) * 17;
+            char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
+            char *obase = rbase + (size_t)(CNS_FRONT + tile * PB) * CNS_ROWB;
+            cnn_h8 piece[NSTORE];
+#pragma unroll
+            for (int c = 0; c < NSTORE; c++) {
+                const int i = c * 256 + (int)threadIdx.x;
+                piece[c] = *reinterpret_cast<const LDS cnn_h8 *>(stg + (i < PB * 17 ? i : 0) * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < NSTORE; c++) {
+                const int i = c * 256 + (int)threadIdx.x;
+                char *dst = i < nvalid ? obase + (size_t)i * 16 : rbase + (i % 17) * 16;
 #if (CNS_ABL & 2)
-                if (hh[0] == (_Float16)12345.f && ll[1] == (_Float16)77.f)
+                if (piece[c][0] == (_Float16)12345.f && piece[c][1] == (_Float16)77.f)
 #endif
-                *reinterpret_cast<cnn_h4 *>(orow + 8 * g) = hh; // (no streaming hint: a row's 16 pieces come from four instructions of
-#if (CNS_ABL & 2)
-                if (hh[0] == (_Float16)12345.f && ll[1] == (_Float16)77.f)
-#endif
-                *reinterpret_cast<cnn_h4 *>(orow + 64 + 8 * g) = ll; //  two waves and have to meet in the L2 -- with it: 4 x slower)
+                *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
             }
         }
         // the DMA issued at the top of this step is older than these NSTORE stores

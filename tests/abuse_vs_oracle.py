@@ -108,6 +108,20 @@ def abuse_cnn():
         got = lib.rows_to_results(cnn.detect_rows(eng, sig, lens, None, spc), "cnn")
         want = oracle.detect_cnn_from_preds(sig, lens, bounds, spc)
         bad = 0
+        # the default conv stack (split float16 operands; out-of-range activations repeat the call in float32) against the exact
+        # float32 stack: the same predictions on every hostile input
+        os.environ["ADP_CNN_CONV"] = "f32"
+        try:
+            eng32 = lib.Engine(spc, n, m, device=0)
+        finally:
+            del os.environ["ADP_CNN_CONV"]
+        cnn.ensure_weights(eng32, None, spc)
+        _, bounds32 = eng32.detect_cnn_rows(sig, lens, n, n)
+        eng32.close()
+        nd = int((np.asarray(bounds) != np.asarray(bounds32)).any(axis=1).sum())
+        if nd:
+            print("   %d reads whose predictions differ between the split and the float32 conv stack" % nd, flush=True)
+        bad += nd
         for i, (g, w) in enumerate(zip(got, want)):
             d = row_diffs(g, {k: v for k, v in w.items() if not k.startswith("_")})
             if d:
