@@ -483,7 +483,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
         if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
             Scope s(h, "k_cand_stats");
-            int rc = h->m > 32768 ? launch_cand_stats<1024, 12, 8>(h, dsig.base, dlen, n, m, kmax, cap)
+            int rc = h->m > 32768 ? launch_cand_stats<1024, CS_BIG_L0, 8>(h, dsig.base, dlen, n, m, kmax, cap)
                                   : launch_cand_stats<256, 8, 6>(h, dsig.base, dlen, n, m, kmax, cap);
             if (rc) return rc;
         }

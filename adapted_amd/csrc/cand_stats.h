@@ -27,6 +27,17 @@
 // (per 32 000 reads at the 16 k window: 1024 / 12 / 8 54 ms, 256 / 12 / 8 62, 256 / 8 / 6 9.1 with the fifth level wide
 // key spans need; k_validate's own wave-per-read statistics: 12.3).
 #define CS_MAXQ 64
+#ifndef CS_ADAPT_SHAPES
+// which shapes widen their later levels to the histogram's capacity (1 = the 1024-thread one, 2 = the 256-thread one), and the
+// first level of the big shape.  Measured (8000 reads of the 200 k window / 32 000 of the 16 k window, one box): 12 bits, fixed
+// widths 19.9 ms; 12 bits, adaptive 21.0 (one sweep of four less, but a wave's rank scan over 2^11 bins per slot and segment
+// costs more than the sweep); 14 bits 45 ms (histogram atomics over 64 KB, 256 bins per lane in every rank scan); the small
+// shape 9.02 -> 8.44 ms with adaptive widths.  The sweeps are not what bounds the big shape.
+#define CS_ADAPT_SHAPES 2
+#endif
+#ifndef CS_BIG_L0
+#define CS_BIG_L0 12
+#endif
 #define CS_GROUP 10 // candidates per round (6 queries each on the slice itself)
 #define CS_UNROLL 8 // elements a thread requests before it looks at the first (memory-level parallelism of the sweeps)
 
@@ -57,6 +68,7 @@ template <int THREADS, int L0, int LN>
 static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsSharedT<L0, LN> *sh)
 {
     constexpr int CS_THREADS = THREADS, CS_L0_BITS = L0, CS_LN_BITS = LN;
+    constexpr bool CS_ADAPT = CS_ADAPT_SHAPES & (THREADS >= 1024 ? 1 : 2);
     const GLB float *x = (const GLB float *)x_;
     const int tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
     const int nq = sh->nq;
@@ -112,7 +124,11 @@ static __device__ void cs_multi_select(const float *__restrict__ x_, LDS CsShare
 #pragma unroll
     for (int level = 0; level < NLEV; level++) {
         if (rb <= 0) break;
-        const int w = level == 0 ? (rb < CS_L0_BITS ? rb : CS_L0_BITS) : (rb < CS_LN_BITS ? rb : CS_LN_BITS);
+        // a later level is as wide as the histogram words allow for the slots the queries still occupy (their ranks mostly share
+        // a few bins of the level before): 14 + 11 bits settle a 25-bit key span in two sweeps where 12 + 8 + 5 took three
+        int wcap = CS_LN_BITS;
+        if (CS_ADAPT && level > 0) { const int room = (CS_MAXQ << CS_LN_BITS) / nslots; while ((2 << wcap) <= room && wcap < 16) wcap++; }
+        const int w = level == 0 ? (rb < CS_L0_BITS ? rb : CS_L0_BITS) : (rb < wcap ? rb : wcap);
         const int shift = rb - w;
         sft[level] = shift; wid[level] = w;
         for (int i = tid; i < (nslots << w); i += CS_THREADS) sh->hist[i] = 0;
