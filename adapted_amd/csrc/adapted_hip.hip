@@ -1342,7 +1342,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
         { Scope s(h, "k_cnn_conv_in");
-          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P - 1) / CNS_IN_P, n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
+          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
         for (int layer = 0; layer < 2; layer++) {
             Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
             const _Float16 *in = layer ? B : A; _Float16 *out = layer ? A : B;

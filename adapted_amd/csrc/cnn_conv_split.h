@@ -29,6 +29,10 @@
 #include "cnn_conv.h"
 
 typedef _Float16 cnn_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cnn_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 cnn_h2 __attribute__((ext_vector_type(2)));
+typedef float cnn_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
 #ifndef CNS_ABL
 #define CNS_ABL 0 // (development: 1 = no MFMAs, 2 = no epilogue stores)
 #endif
@@ -68,10 +72,14 @@ __global__ void k_cns_split_weights(const float *__restrict__ w /* [64][64][7] *
 }
 
 // ---------------------------------------------------------------- layer 0: Conv1d(1 -> 64, k 7, stride 3, pad 3) + ReLU, split rows out
-// grid = (ceil(L1 / 128), n); block = 256: 128 positions, two threads per position (32 channels each: the float32 fmaf chain of
-// k_cnn_conv_in).  The rows are put together in LDS (272-byte pitch: conflict-free 16-byte writes) and leave as one contiguous,
-// fully coalesced copy -- written from the threads directly, a wave's store would touch 64 different rows.
-#define CNS_IN_P 128
+// grid = (ceil(L1 / 64), n); block = 256: 64 positions, wave q makes channels 16 q .. 16 q + 15 of all of them (weights wave-uniform:
+// scalar operands; the float32 fmaf chain of k_cnn_conv_in, two channels per v_pk_fma_f32).  The rows are put together in LDS
+// (272-byte pitch: conflict-free 16-byte writes) and leave as one contiguous, fully coalesced copy -- written from the threads
+// directly, a wave's store would touch 64 different rows.  17 KB of LDS and 256 threads per block: eight blocks per CU, the
+// copies of some behind the arithmetic of others.
+#define CNS_IN_P 64
+#define CNS_IN_T 4 // position tiles per block (the weights are fetched once per block: as scalar operands they were a chain of
+                   // dependent scalar-cache round trips in front of every tile's arithmetic)
 __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__ x, int Lc, int L1, int Lrows,
                                                         const float *__restrict__ w /* [64][1][7] */, const float *__restrict__ b,
                                                         _Float16 *__restrict__ out, int32_t *__restrict__ flag)
@@ -79,41 +87,59 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
     __shared__ __attribute__((aligned(16))) _Float16 rows_[CNS_IN_P * CNS_ROW];
     LDS _Float16 *rows = (LDS _Float16 *)rows_;
     const int n = blockIdx.y;
-    const int p0 = blockIdx.x * CNS_IN_P;
-    const int pl = threadIdx.x & (CNS_IN_P - 1), half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
-    const int p = p0 + pl;
+    const int pl = threadIdx.x & (CNS_IN_P - 1), qw = threadIdx.x >> 6;
     const float *row = x + (size_t)n * Lc;
-    float v[CNN_K];
-#pragma unroll
-    for (int t = 0; t < CNN_K; t++) { const int i = 3 * p + t - 3; v[t] = (i >= 0 && i < Lc) ? row[i] : 0.f; }
-    bool bad = false;
-    LDS _Float16 *o = rows + pl * CNS_ROW + 32 * half;
-    const float *wq = w + 32 * half * CNN_K, *bq = b + 32 * half;
-#pragma unroll 2
-    for (int c8 = 0; c8 < 4; c8++) {
-        cnn_h8 hh, ll;
+    // the wave's 16 channels as 8 pairs: weights and biases in vector registers (every lane the same values, all loads in flight at once)
+    cnn_f2 wp[8][CNN_K], bp[8];
+    {
+        const float *wq = w + 16 * qw * CNN_K, *bq = b + 16 * qw;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const int c = c8 * 8 + e;
-            float acc = bq[c];
+            bp[e] = (cnn_f2){bq[2 * e], bq[2 * e + 1]};
 #pragma unroll
-            for (int t = 0; t < CNN_K; t++) acc = __builtin_fmaf(wq[c * CNN_K + t], v[t], acc);
-            bad |= p < L1 && !(__builtin_fabsf(acc) < CNS_LIMIT);
-            const float y = acc > 0.f ? acc : 0.f;
-            _Float16 hi, lo;
-            cns_split(y, hi, lo);
-            hh[e] = hi; ll[e] = lo;
+            for (int t = 0; t < CNN_K; t++) wp[e][t] = (cnn_f2){wq[(2 * e) * CNN_K + t], wq[(2 * e + 1) * CNN_K + t]};
         }
-        *reinterpret_cast<LDS cnn_h8 *>(o + c8 * 8) = hh;
-        *reinterpret_cast<LDS cnn_h8 *>(o + 64 + c8 * 8) = ll;
     }
-    __syncthreads();
-    // 17 16-byte pieces per row (the last one is the row's padding: stays as it is), rows at or beyond L1 stay zero
-    const int nrows = L1 - p0 < CNS_IN_P ? L1 - p0 : CNS_IN_P;
-    cnn_h8 *dst = reinterpret_cast<cnn_h8 *>(out + ((size_t)n * Lrows + CNS_FRONT + p0) * CNS_ROW);
-    const LDS cnn_h8 *src = reinterpret_cast<const LDS cnn_h8 *>(rows);
-    for (int i = threadIdx.x; i < nrows * 17; i += 256)
-        if (i % 17 != 16) __builtin_nontemporal_store(src[i], dst + i);
+    cnn_us2 hmax = {0, 0};
+    LDS _Float16 *o = rows + pl * CNS_ROW + 16 * qw;
+    for (int tile = 0; tile < CNS_IN_T; tile++) {
+        const int p0 = (blockIdx.x * CNS_IN_T + tile) * CNS_IN_P;
+        if (p0 >= L1) break;
+        const int p = p0 + pl;
+        float v[CNN_K];
+#pragma unroll
+        for (int t = 0; t < CNN_K; t++) { const int i = 3 * p + t - 3; v[t] = (i >= 0 && i < Lc) ? row[i] : 0.f; }
+#pragma unroll
+        for (int c8 = 0; c8 < 2; c8++) {
+            cnn_h2 hq[4], lq[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                cnn_f2 acc = bp[c8 * 4 + e];
+#pragma unroll
+                for (int t = 0; t < CNN_K; t++) acc = __builtin_elementwise_fma(wp[c8 * 4 + e][t], (cnn_f2){v[t], v[t]}, acc);
+                acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f}); // (a NaN becomes 0, as `acc > 0 ? acc : 0` makes it in k_cnn_conv_in)
+                const cnn_h2 hi = __builtin_convertvector(acc, cnn_h2);
+                const cnn_f2 rs = (acc - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+                hq[e] = hi; lq[e] = __builtin_convertvector(rs, cnn_h2);
+                hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+            }
+            const cnn_h8 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1], hq[2][0], hq[2][1], hq[3][0], hq[3][1]};
+            const cnn_h8 ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1], lq[2][0], lq[2][1], lq[3][0], lq[3][1]};
+            *reinterpret_cast<LDS cnn_h8 *>(o + c8 * 8) = hh;
+            *reinterpret_cast<LDS cnn_h8 *>(o + 64 + c8 * 8) = ll;
+        }
+        __syncthreads();
+        // 17 16-byte pieces per row (the last one is the row's padding: stays as it is), rows at or beyond L1 stay zero
+        const int nrows = L1 - p0 < CNS_IN_P ? L1 - p0 : CNS_IN_P;
+        cnn_h8 *dst = reinterpret_cast<cnn_h8 *>(out + ((size_t)n * Lrows + CNS_FRONT + p0) * CNS_ROW);
+        const LDS cnn_h8 *src = reinterpret_cast<const LDS cnn_h8 *>(rows);
+        for (int i = threadIdx.x; i < nrows * 17; i += 256)
+            if (i % 17 != 16) dst[i] = src[i];
+        __syncthreads();
+    }
+    // out of range: a hi part of 32768 or more, or infinite (the values are non-negative: bit patterns order like values); rows at
+    // or beyond L1 see zeros or real samples like their neighbours -- a needless flag only costs the float32 repeat
+    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
@@ -125,10 +151,6 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // Synchronisation per step: the tile's DMA is the OLDEST of the wave's outstanding vector-memory operations (it was issued before
 // the previous step's stores), so a counted s_waitcnt leaves those stores in flight; every store of the epilogue is issued
 // unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
-typedef _Float16 cnn_h4 __attribute__((ext_vector_type(4)));
-typedef _Float16 cnn_h2 __attribute__((ext_vector_type(2)));
-typedef float cnn_f2 __attribute__((ext_vector_type(2)));
-typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
 template <int NT>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
