@@ -90,6 +90,7 @@ struct adp_handle {
     // cnn_redo_f32: the split kernels met an activation outside the float16 range in this call -- it is being repeated in float32
     int cnn_mode = 1, cnn_act_kind = -1;
     bool cnn_redo_f32 = false;
+    bool cnn_fuse_in = false; // ADP_CNN_FUSE_IN=1: layer 0 computed inside layer 1's kernel (measured: no gain at the 200 k window, see below)
     DevBuf cnn_wsp;          // split B fragments of layers 1 and 2
     float cnn_sw[2] = {1.f, 1.f};
     // grouped execution of the LLR path (llr_grouped): child handles ("lanes") with their own streams and a workspace for ONE
@@ -256,6 +257,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
     if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) { adp_destroy(h); g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     { const char *cv = getenv("ADP_CNN_CONV"); if (cv && !strcmp(cv, "f32")) h->cnn_mode = 0; } // the exact-float32 conv stack (cnn_conv.h)
+    { const char *cv = getenv("ADP_CNN_FUSE_IN"); h->cnn_fuse_in = cv && *cv == '1'; }
     *out = h;
     return ADP_OK;
 }
@@ -1301,17 +1303,18 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 } // extern "C++"
 
 extern "C++" {
-template <int NT>
+template <int NT, bool FIRST>
 static int launch_conv64s(adp_handle *h, const _Float16 *in, _Float16 *out, const _Float16 *wsp, const float *b, float sw, int n, int L1,
-                          int Lrows, int tiles, int32_t *flag)
+                          int Lrows, int tiles, int32_t *flag, const float *x, int Lc, const float *w0, const float *b0)
 {
     const size_t lds = (size_t)2 * (((size_t)(64 * NT + 6) * CNS_ROWB + 1023) / 1024 * 1024);
-    const unsigned bit = 64u << (NT - 2);
-    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
+    const unsigned bit = (FIRST ? 512u : 64u) << (NT - 2);
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
     long long total = (long long)n * tiles;
     if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64s"; return ADP_ERR_UNSUPPORTED; }
     int grid = (int)(total < h->n_cu ? total : h->n_cu);
-    hipLaunchKernelGGL(k_cnn_conv64s<NT>, dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
+    hipLaunchKernelGGL((k_cnn_conv64s<NT, FIRST>), dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag,
+                       x, Lc, w0, b0);
     return 0;
 }
 } // extern "C++"
@@ -1341,17 +1344,30 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
-        { Scope s(h, "k_cnn_conv_in");
-          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
+        // ADP_CNN_FUSE_IN=1 (opt-in): layer 0 inside layer 1 (k_cnn_conv64s<NT, true>), no rows of layer 0 in HBM.  Measured per 2000
+        // reads of the 200 k window: 3.69 ms against 1.33 + 2.25 for the two kernels (the rows cost the single wave per SIMD ~5 us per
+        // step in front of its MFMAs -- scalar weight loads, four dependent row rounds -- as much as the HBM round trip saved);
+        // 0.63 against 0.21 + 0.43 at the default window.
+        const bool fuse_in = wh->cnn_fuse_in;
+        if (!fuse_in) {
+            Scope s(h, "k_cnn_conv_in");
+            hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag);
+        }
         for (int layer = 0; layer < 2; layer++) {
-            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
+            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : (fuse_in ? "k_cnn_conv64 (layers 0 + 1)" : "k_cnn_conv64 (layer 1)"));
             const _Float16 *in = layer ? B : A; _Float16 *out = layer ? A : B;
             const _Float16 *w = wsp + (size_t)layer * CNS_WSP_LAYER;
             const float *b = W + (layer ? CNN_B2 : CNN_B1);
             const float sw = wh->cnn_sw[layer];
-            int rc = NT == 4 ? launch_conv64s<4>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
-                   : NT == 3 ? launch_conv64s<3>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
-                             : launch_conv64s<2>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag);
+            int rc;
+            if (layer == 0 && fuse_in)
+                rc = NT == 4 ? launch_conv64s<4, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0)
+                   : NT == 3 ? launch_conv64s<3, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0)
+                             : launch_conv64s<2, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0);
+            else
+                rc = NT == 4 ? launch_conv64s<4, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr)
+                   : NT == 3 ? launch_conv64s<3, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr)
+                             : launch_conv64s<2, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr);
             if (rc) return rc;
         }
         { Scope s(h, "k_cnn_conv_out");

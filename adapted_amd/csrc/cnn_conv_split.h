@@ -151,11 +151,16 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // Synchronisation per step: the tile's DMA is the OLDEST of the wave's outstanding vector-memory operations (it was issued before
 // the previous step's stores), so a counted s_waitcnt leaves those stores in flight; every store of the epilogue is issued
 // unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
-template <int NT>
+// FIRST: layer 1 with layer 0 inside -- no input rows in HBM at all: the workgroup makes the tile's rows itself, Conv1d(1 -> 64,
+// k 7, stride 3) + ReLU + split from the prepared signal x (the arithmetic of k_cnn_conv_in_s: wave q the channels 16 q .. 16 q + 15,
+// a lane a row), straight into the LDS tile.  Layer 0 as a kernel of its own is bound by the 1.8 MB per read it writes (2.7 TB/s of
+// HBM writes) and layer 1 would read them back.
+template <int NT, bool FIRST>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
-                                                        int32_t *__restrict__ flag)
+                                                        int32_t *__restrict__ flag, const float *__restrict__ x, int Lc,
+                                                        const float *__restrict__ w0 /* [64][1][7] */, const float *__restrict__ b0)
 {
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
@@ -193,15 +198,58 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     // hold what real neighbours hold, and a needless flag only costs the float32 repeat.)
     cnn_us2 hmax = {0, 0};
     const float cx = inv_sw * (1.0f / 2048.0f);
-    if (it < total) dma(it, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // FIRST: rows tile * PB - 3 .. of read n made from x into buffer b (rows outside [0, L1) are the zero padding)
+    auto make_rows = [&](int tix, int b) {
+        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
+        const float *xr = x + (size_t)n * Lc;
+        const float *wq = w0 + 16 * wave * CNN_K, *bq = b0 + 16 * wave;
+        for (int r = lane; r < R; r += 64) {
+            const int p = tile * PB - 3 + r;
+            const bool inside = p >= 0 && p < L1;
+            float v[CNN_K];
+#pragma unroll
+            for (int t = 0; t < CNN_K; t++) { const int i = 3 * p + t - 3; v[t] = (inside && i >= 0 && i < Lc) ? xr[i] : 0.f; }
+            LDS _Float16 *o = (LDS _Float16 *)(lds + b * TILE_B + r * CNS_ROWB) + 16 * wave;
+#pragma unroll
+            for (int c8 = 0; c8 < 2; c8++) {
+                cnn_h2 hq[4], lq[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int c = c8 * 8 + 2 * e;
+                    cnn_f2 acc = {bq[c], bq[c + 1]};
+#pragma unroll
+                    for (int t = 0; t < CNN_K; t++) acc = __builtin_elementwise_fma((cnn_f2){wq[c * CNN_K + t], wq[(c + 1) * CNN_K + t]}, (cnn_f2){v[t], v[t]}, acc);
+                    acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f});
+                    if (!inside) acc = (cnn_f2){0.f, 0.f};
+                    const cnn_h2 hi = __builtin_convertvector(acc, cnn_h2);
+                    const cnn_f2 rs = (acc - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+                    hq[e] = hi; lq[e] = __builtin_convertvector(rs, cnn_h2);
+                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+                }
+                const cnn_h8 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1], hq[2][0], hq[2][1], hq[3][0], hq[3][1]};
+                const cnn_h8 ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1], lq[2][0], lq[2][1], lq[3][0], lq[3][1]};
+                *reinterpret_cast<LDS cnn_h8 *>(o + c8 * 8) = hh;
+                *reinterpret_cast<LDS cnn_h8 *>(o + 64 + c8 * 8) = ll;
+            }
+        }
+    };
+    if (!FIRST) {
+        if (it < total) dma(it, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     for (; it < total; it += gridDim.x) {
         // every wave has waited for its own share of tile `it` (before the loop / at the end of the previous step) and has
         // finished reading the other buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        if (FIRST) {
+            // (one buffer: the staging rows of the step before have left it -- the barrier above -- and nothing is in flight)
+            make_rows(it, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
         // B fragment of k-step (t, cg), position tile j: row ph * 32 NT + 32 j + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
         const LDS char *tb = lds + buf * TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
         cnn_f32x16 am[NT], ax[NT];
@@ -294,9 +342,11 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                 *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
             }
         }
-        // the DMA issued at the top of this step is older than these NSTORE stores
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-        buf ^= 1;
+        if (!FIRST) {
+            // the DMA issued at the top of this step is older than these NSTORE stores
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+            buf ^= 1;
+        }
     }
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
