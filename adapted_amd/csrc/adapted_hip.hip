@@ -814,7 +814,7 @@ static int llr_grouped(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
             if (rc) { for (int i = 0; i < n_lanes; i++) (void)hipStreamSynchronize(lanes[i]->stream); return rc; }
         }
         for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamSynchronize(lanes[i]->stream));
-        rc = arena_end(h, true);
+        rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;
         for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
@@ -1508,7 +1508,7 @@ static int cnn_grouped(adp_handle *h, const float *dsig, const int32_t *dlen, in
             if (rc) { for (int i = 0; i < n_lanes; i++) (void)hipStreamSynchronize(lanes[i]->stream); return rc; }
         }
         for (int i = 0; i < n_lanes; i++) HIPCHK(hipStreamSynchronize(lanes[i]->stream));
-        rc = arena_end(h);
+        rc = arena_end(h, true);
         if (rc < 0) return rc;
         if (rc == 0) break;
         for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }

@@ -412,3 +412,30 @@ def test_split_conv_leaves_the_float16_range_to_the_float32_kernels(what, monkey
             assert not np.array_equal(sc2.cpu().numpy(), got["split_next"][0])
         eng.close()
     assert np.array_equal(got["split"], got["f32"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_out_of_range_call_in_chunks_over_lanes_equals_the_float32_rows(monkeypatch):
+    """The flag of the split conv stack belongs to the CALL: with the call cut into chunks over two lanes (ADP_CNN_GROUPS) a
+    1e7-pA stretch in one read repeats the whole call on the float32 kernels -- rows and predictions are those of a handle that
+    runs the float32 stack from the start."""
+    from adapted_amd import synth
+    from adapted_amd.config import get_chemistry_specific_config
+    from adapted_amd.detect import cnn
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    m, n, mb = spc.sig_preload_size, 96, 16
+    sig, lens = synth.synth_batch(21, 0, n, m, np.full(n, m, dtype=np.int32))
+    sig[70, 9000:9040] = 1e7
+    out = {}
+    for conv, groups in (("split", "3"), ("f32", "1")):
+        monkeypatch.setenv("ADP_CNN_GROUPS", groups)
+        eng = _conv_engine(monkeypatch, conv, spc, n, m)
+        cnn.ensure_weights(eng, None, spc)
+        rows, bounds = eng.detect_cnn_rows(sig, lens, n, mb)
+        out[conv] = (rows.tobytes(), np.array(bounds))
+        eng.close()
+    assert np.array_equal(out["split"][1], out["f32"][1])
+    assert out["split"][0] == out["f32"][0]
