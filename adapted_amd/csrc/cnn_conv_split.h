@@ -12,8 +12,9 @@
 // tests/test_gpu_cnn.py beside the exact-float32 kernels.  3 MFMAs x 32 cycles per 32 x 32 x 16 block against 8 x 64 for the float32
 // instruction: 5.3 x the matrix rate -- the layers become HBM-bound (1.8 MB read + 1.8 MB written per read and layer).
 //
-// Values outside the float16 range: activations are kept unscaled (|a| < 32768 asked for); a kernel that produces a larger or
-// non-finite activation anywhere raises the CALL's flag (a word beside the open-pore arena counter, read with it at the end of the
+// Values outside the float16 range: activations are stored times 2^-4 (real values below 5.2e5 asked for: a 1500-pA artefact in a
+// read normalised by a MAD of 10 stays far inside); a kernel that produces a larger or non-finite activation anywhere raises the
+// CALL's flag (a word beside the open-pore arena counter, read with it at the end of the
 // call: no extra host round trip), and the call is repeated on the float32 kernels of cnn_conv.h -- inputs like 1e30 pA or infinities
 // give the rows the float32 stack gives.  Weights are scaled per layer by a power of two (largest |w| s in [2^13, 2^14)); the factor
 // leaves with the bias in the epilogue.
@@ -41,7 +42,9 @@ typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
 #define CNS_ROWB 272         // bytes
 #define CNS_FRONT 4          // zero rows in front of position 0
 #define CNS_KSTEPS 28        // 7 taps x 4 groups of 16 channels
-#define CNS_LIMIT 32768.0f   // activations at or beyond it (or non-finite) send the read to the float32 kernels
+#define CNS_LIMIT 32768.0f   // a STORED activation at or beyond it (or non-finite) repeats the call on the float32 kernels ...
+#define CNS_ASCALE 0.0625f   // ... and activations are stored times 2^-4: real values up to 5.2e5 stay in range (exact scaling; it
+                             // rides through the 64 -> 64 layers with the bias and leaves in layer 3)
 #define CNS_SLACK 65536      // bytes behind the last read's rows that a tile DMA may read (k_cnn_conv_out_s: up to 130 rows from a row below L1)
 #define CNS_WSP_LAYER (2 * CNS_KSTEPS * 2 * 64 * 8) // float16 per layer in the split-weight buffer
 
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
                 cnn_f2 acc = bp[c8 * 4 + e];
 #pragma unroll
                 for (int t = 0; t < CNN_K; t++) acc = __builtin_elementwise_fma(wp[c8 * 4 + e][t], (cnn_f2){v[t], v[t]}, acc);
-                acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f}); // (a NaN becomes 0, as `acc > 0 ? acc : 0` makes it in k_cnn_conv_in)
+                acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f}) * CNS_ASCALE; // (a NaN becomes 0, as `acc > 0 ? acc : 0` makes it in k_cnn_conv_in)
                 const cnn_h2 hi = __builtin_convertvector(acc, cnn_h2);
                 const cnn_f2 rs = (acc - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
                 hq[e] = hi; lq[e] = __builtin_convertvector(rs, cnn_h2);
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     // D layout: column = lane & 31 (position), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (channel inside the wave's 32)
     float bs[16];
 #pragma unroll
-    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * sw;
+    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE); // (inputs and outputs carry CNS_ASCALE)
 
     const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
     auto dma = [&](int tix, int b) {
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                     cnn_f2 acc = {bq[c], bq[c + 1]};
 #pragma unroll
                     for (int t = 0; t < CNN_K; t++) acc = __builtin_elementwise_fma((cnn_f2){wq[c * CNN_K + t], wq[(c + 1) * CNN_K + t]}, (cnn_f2){v[t], v[t]}, acc);
-                    acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f});
+                    acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f}) * CNS_ASCALE;
                     if (!inside) acc = (cnn_f2){0.f, 0.f};
                     const cnn_h2 hi = __builtin_convertvector(acc, cnn_h2);
                     const cnn_f2 rs = (acc - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
@@ -387,7 +390,8 @@ __global__ void __launch_bounds__(CNS_OUT_P) k_cnn_conv_out_s(const _Float16 *__
         const cnn_h8 ph_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + c8 * 16), pl_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + 128 + c8 * 16);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float hm = cns_join(mh_[e], ml_[e]), h0 = cns_join(zh_[e], zl_[e]), hp = cns_join(ph_[e], pl_[e]);
+            const float hm = cns_join(mh_[e], ml_[e]) * (1.0f / CNS_ASCALE), h0 = cns_join(zh_[e], zl_[e]) * (1.0f / CNS_ASCALE),
+                        hp = cns_join(ph_[e], pl_[e]) * (1.0f / CNS_ASCALE);
             const float *wc = w + (c8 * 8 + e) * 2 * CNN_K;
 #pragma unroll
             for (int o = 0; o < 2; o++) {

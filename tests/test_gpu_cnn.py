@@ -439,3 +439,40 @@ def test_out_of_range_call_in_chunks_over_lanes_equals_the_float32_rows(monkeypa
         eng.close()
     assert np.array_equal(out["split"][1], out["f32"][1])
     assert out["split"][0] == out["f32"][0]
+
+
+@pytest.mark.gpu
+def test_split_conv_keeps_large_in_range_activations(monkeypatch):
+    """Activations are stored times 2^-4: an artefact of 300 normalised units (a 3000-pA excursion at a MAD of 10) drives the layers to
+    tens of thousands and still runs on the split kernels -- scores within the conv-stack tolerance of torch's float32 result, and
+    not the float32 stack's bits (the call was not repeated)."""
+    import torch
+
+    from adapted_amd.detect import cnn
+    from golden_cases import CASES
+    from util import make_spc
+
+    torch.cuda.init()
+    spc = make_spc(CASES["rna004_cnn_default"])
+    model = cnn.load_cnn_model(spc.cnn_boundaries.model_name, device=0)
+    n, Lc = 5, 1650
+    rng = np.random.default_rng(9)
+    x = rng.normal(0.0, 1.5, (n, 1, Lc)).astype(np.float32)
+    x[1, 0, 500:530] = 300.0
+    x[3, 0, 40:44] = -250.0
+    xt = torch.from_numpy(x).cuda()
+    with torch.no_grad():
+        want = model(xt).cpu().numpy()
+    got = {}
+    for conv in ("split", "f32"):
+        eng = _conv_engine(monkeypatch, conv, spc, 8, spc.sig_preload_size)
+        eng.cnn_set_weights({k: v for k, v in model.state_dict().items()})
+        sc = torch.empty((n, 2, want.shape[2]), dtype=torch.float32, device="cuda")
+        eng.cnn_forward(xt.data_ptr(), n, Lc, sc.data_ptr())
+        got[conv] = sc.cpu().numpy()
+        eng.close()
+    scale = float(np.abs(want).max())
+    assert scale > 1000.0  # (the excursion does reach the last layer)
+    for conv in got:
+        assert float(np.abs(got[conv] - want).max()) <= 2e-5 * scale, conv
+    assert not np.array_equal(got["split"], got["f32"])
