@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
         cnn_h8 *dst = reinterpret_cast<cnn_h8 *>(out + ((size_t)n * Lrows + CNS_FRONT + p0) * CNS_ROW);
         const LDS cnn_h8 *src = reinterpret_cast<const LDS cnn_h8 *>(rows);
         for (int i = threadIdx.x; i < nrows * 17; i += 256)
-            if (i % 17 != 16) dst[i] = src[i];
+            dst[i] = src[i]; // (the 17th piece of a row, its padding, goes along: a hole per row would make every line a partial write)
         __syncthreads();
     }
     // out of range: a hi part of 32768 or more, or infinite (the values are non-negative: bit patterns order like values); rows at
