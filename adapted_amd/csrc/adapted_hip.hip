@@ -1345,7 +1345,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
         // ADP_CNN_FUSE_IN=1 (opt-in): layer 0 inside layer 1 (k_cnn_conv64s<NT, true>), no rows of layer 0 in HBM.  Measured per 2000
-        // reads of the 200 k window: 3.69 ms against 1.33 + 2.25 for the two kernels (the rows cost the single wave per SIMD ~5 us per
+        // reads of the 200 k window: 3.69 ms against 1.33 (1.04 since its row copy has no holes) + 2.25 for the two kernels (the rows cost the single wave per SIMD ~5 us per
         // step in front of its MFMAs -- scalar weight loads, four dependent row rounds -- as much as the HBM round trip saved);
         // 0.63 against 0.21 + 0.43 at the default window.
         const bool fuse_in = wh->cnn_fuse_in;

@@ -156,8 +156,7 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
 // FIRST: layer 1 with layer 0 inside -- no input rows in HBM at all: the workgroup makes the tile's rows itself, Conv1d(1 -> 64,
 // k 7, stride 3) + ReLU + split from the prepared signal x (the arithmetic of k_cnn_conv_in_s: wave q the channels 16 q .. 16 q + 15,
-// a lane a row), straight into the LDS tile.  Layer 0 as a kernel of its own is bound by the 1.8 MB per read it writes (2.7 TB/s of
-// HBM writes) and layer 1 would read them back.
+// a lane a row), straight into the LDS tile.  Layer 0 as a kernel of its own writes 1.9 MB per read that layer 1 reads back.
 template <int NT, bool FIRST>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
