@@ -713,6 +713,8 @@ def main():
         sec = {}
         # (24 000 reads per step: the one-wave-per-chain series kernel takes the same ~11 ms for 1000 and for 24 000 reads)
         for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=3, warmup=1)),
+                         # the same step on the exact-float32 MFMA conv stack (cnn_conv.h): the round-2 kernels, 0.75 of the float32 matrix peak
+                         ("cnn_200k_f32_stack", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=2, warmup=1, env={"ADP_CNN_CONV": "f32"})),
                          ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
                          ("pareto", dict(lens="pareto", steps=4, warmup=1)),
                          # the reference's own defaults: the preset's 16 000-sample window, 1000 reads per minibatch
