@@ -299,6 +299,22 @@ static __device__ __forceinline__ double var_seg(double c2hi, double c2lo, doubl
     return div_by_len(c2hi - c2lo, dl, y) - mu * mu;
 }
 
+// lane l takes lane l - 1's value, lane 0 takes `fill` (wave-uniform); all 64 lanes must be active
+static __device__ __forceinline__ double wave_shr1_f64(double x, double fill)
+{
+    int2 v = __builtin_bit_cast(int2, x), f = __builtin_bit_cast(int2, fill);
+    v.x = __builtin_amdgcn_update_dpp(f.x, v.x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    v.y = __builtin_amdgcn_update_dpp(f.y, v.y, 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, v);
+}
+static __device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    int2 v = __builtin_bit_cast(int2, x);
+    v.x = __builtin_amdgcn_readlane(v.x, lane);
+    v.y = __builtin_amdgcn_readlane(v.y, lane);
+    return __builtin_bit_cast(double, v);
+}
+
 // grid = n_reads waves (block = 64).  PASS 1: start = 0, offsets (5, 5), also emits T1 (first / last
 // index with a positive-or-NaN gain).  PASS 2: start = adapter candidate, offsets (1, 1).
 // Emits the trace (float64) and per-64-point summaries: PASS 1 of the raw trace (NaN => +inf max),
@@ -467,29 +483,38 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
             }
         }
         ws_sync();
+        auto sanit = [](double x) { // np.nan_to_num
+            if (x != x) x = 0.0;
+            else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
+            return x;
+        };
+        auto sval = [&](int e) { return sanit(sg[(e / CK) * (CK + 1) + (e % CK)]); }; // sanitised value at tile offset e (e >= 0)
+        if (!emit) {
 #pragma unroll GAINS_SU
-        for (int k = 0; k < CK; k++) {
-            int e = k * 64 + ln;
-            int i = tb + e;
-            if (i < n) g[i] = sg[(e / CK) * (CK + 1) + (e % CK)];
-        }
-        if (emit) {
-            auto sval = [&](int e) { // sanitised value at tile offset e (e >= 0)
-                double x = sg[(e / CK) * (CK + 1) + (e % CK)];
-                if (x != x) x = 0.0;
-                else if (__builtin_isinf(x)) x = x > 0 ? 1.7976931348623157e308 : -1.7976931348623157e308;
-                return x;
-            };
+            for (int k = 0; k < CK; k++) {
+                int e = k * 64 + ln;
+                int i = tb + e;
+                if (i < n) g[i] = sg[(e / CK) * (CK + 1) + (e % CK)];
+            }
+        } else {
+            // ONE read of the staging tile serves both the trace's write-out and the pick-up of local maxima: the element a lane
+            // stores is its "next" value, the two in front of it are its neighbours' -- a wave shift (v_mov_dpp wave_shr:1, lane 0
+            // filled with what lane 63 / 62 held in the round before, or the tile's carries) instead of two more sanitised LDS reads
+            // with their index arithmetic per point (the pick-up was ~200 of pass 2's ~985 cycles per wave-point).
+            double p1 = carry1, p2 = carry2; // x[e - 1], x[e - 2] of lane 0 (wave-uniform)
 #pragma unroll GAINS_EU
             for (int k = 0; k < CK; k++) {
                 const int e = k * 64 + ln;
                 const int i = tb + e;   // x[i] is "next"; the candidate is j = i - 1
                 const int j = i - 1;
+                const double raw = sg[(e / CK) * (CK + 1) + (e % CK)];
+                if (i < n) g[i] = raw;
+                const double xn = sanit(raw);
+                const double xj = wave_shr1_f64(xn, p1);
+                const double xp = wave_shr1_f64(xj, p2);
+                p1 = readlane_f64(xn, 63); p2 = readlane_f64(xn, 62);
                 bool pkf = false;
                 if (i < n && j >= 1) {
-                    double xn = sval(e);
-                    double xj = (e >= 1) ? sval(e - 1) : carry1;
-                    double xp = (e >= 2) ? sval(e - 2) : (e == 1 ? carry1 : carry2);
                     if (xp < xj) {
                         if (xn < xj) pkf = true;
                         else if (xn == xj && !(xj == 0.0 && j >= E - ot)) plateau = true; // trailing zeros never peak
