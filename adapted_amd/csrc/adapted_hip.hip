@@ -22,6 +22,7 @@ __device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "peaks.h"
 #include "synth.h"
 #include "validate.h"
+#include "cand_stats2.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
 #include "cnn_conv_split.h"
@@ -81,7 +82,7 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used;
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used, series_plan;
     DevBuf tr_buf, tr_meta; // adp_c_llr_trace: staging of host arrays
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
@@ -271,7 +272,7 @@ int adp_destroy(adp_handle *h)
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
-    DevBuf *all[] = {&h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -448,6 +449,17 @@ static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dle
     return 0;
 }
 
+template <int THREADS, int HB>
+static int launch_cand_stats2(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
+{
+    typedef Cs2Sh<HB> Sh;
+    const unsigned bit = THREADS >= 512 ? 4096u : 8192u;
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats2<THREADS, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); h->attr_done |= bit; }
+    hipLaunchKernelGGL((k_cand_stats2<THREADS, HB>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+                       (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
+    return 0;
+}
+
 template <class SIG>
 static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int m, int kmax, int mbsize,
                            bool gate_mb)
@@ -473,7 +485,15 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
             auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
             const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 4 * (MS_CHUNK + 4)) * 4; // (two out halves per wave)
             if (lds > h->lds_series_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->lds_series_set = lds; }
-            hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+            // the plan (slice starts / lengths, have[]) and the order by falling length (validate.h), then the chains
+            if (h->series_plan.ensure((size_t)n * 12 + 2 * MS_NBKT * 4)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+            int32_t *pa = h->series_plan.as<int32_t>(), *pn = pa + n, *pp = pn + n;
+            uint32_t *pc = reinterpret_cast<uint32_t *>(pp + n);
+            HIPCHK(hipMemsetAsync(pc, 0, 2 * MS_NBKT * 4, h->stream));
+            hipLaunchKernelGGL(k_series_plan, dim3((n + 255) / 256), dim3(256), 0, h->stream, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg, cap,
+                               h->have_series.as<int8_t>(), pa, pn, pc);
+            hipLaunchKernelGGL(k_series_order, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cap, pn, pc, pc + MS_NBKT, pp);
+            hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, n, m, pa, pn, pp, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         }
         }
@@ -485,8 +505,14 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
         if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
             Scope s(h, "k_cand_stats");
-            int rc = h->m > 32768 ? launch_cand_stats<1024, CS_BIG_L0, 8>(h, dsig.base, dlen, n, m, kmax, cap)
+            // round 4: two sweeps per array (cand_stats2.h); ADP_CAND_STATS=old keeps the multi-level sweeps of cand_stats.h (cross-check)
+            int rc;
+            if (env_int("ADP_CAND_STATS_OLD", 0))
+                rc = h->m > 32768 ? launch_cand_stats<1024, CS_BIG_L0, 8>(h, dsig.base, dlen, n, m, kmax, cap)
                                   : launch_cand_stats<256, 8, 6>(h, dsig.base, dlen, n, m, kmax, cap);
+            else
+                rc = h->m > 32768 ? launch_cand_stats2<512, 12>(h, dsig.base, dlen, n, m, kmax, cap)
+                                  : launch_cand_stats2<256, 10>(h, dsig.base, dlen, n, m, kmax, cap);
             if (rc) return rc;
         }
         }

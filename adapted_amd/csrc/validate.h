@@ -671,15 +671,15 @@ static __device__ __forceinline__ void ms_var4(const float (&a)[4], const float 
 
 template <bool VAR>
 static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LDS int32_t *a_of, const LDS int32_t *n_of,
-                                 int r0, int n_reads, int w, float *__restrict__ series, int cap, LDS float *buf, LDS float *out,
+                                 const LDS int32_t *rid_of, int w, float *__restrict__ series, int cap, LDS float *buf, LDS float *out,
                                  int8_t *__restrict__ have)
 {
     const int ln = lane_id();
     const int RB = ms_ring(w), S = RB + 4, SO = MS_CHUNK + 4, MASK = RB - 1;
     const int g = ln & (MS_G - 1);
-    const int r = r0 + g;
-    const bool chain = ln < MS_G && r < n_reads;
-    const int n = (r < n_reads) ? n_of[g] : 0;        // every lane knows the length of read (lane % MS_G)
+    const int r = rid_of[g];                          // (a read of the launch even where the group has none: its length is 0 then)
+    const int n = n_of[g];                            // every lane knows the length of read (lane % MS_G)
+    const bool chain = ln < MS_G && n > 0;
     int nmax = n;
 #pragma unroll
     for (int o = MS_G / 2; o > 0; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
@@ -693,8 +693,8 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
     const GLB float *xq[MS_G];
 #pragma unroll
     for (int q = 0; q < MS_G; q++) {
-        nq[q] = (r0 + q < n_reads) ? n_of[q] : 0;
-        xq[q] = (const GLB float *)sigs + (size_t)(r0 + q < n_reads ? r0 + q : r0) * m + a_of[q];
+        nq[q] = n_of[q];
+        xq[q] = (const GLB float *)sigs + (size_t)rid_of[q] * m + a_of[q];
     }
     // the samples of the NEXT chunk are requested before the chains of the current one run (one load per read, all in
     // flight together; waiting for them one by one cost 8 us per chunk) and land in LDS after it.  The loads are
@@ -713,7 +713,7 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
     auto store_chunk = [&](int i0, const LDS float *o) {
 #pragma unroll
         for (int q = 0; q < MS_G; q++) {
-            GLB float *sp = (GLB float *)series + (size_t)(r0 + q < n_reads ? r0 + q : r0) * 2 * cap + (VAR ? cap : 0);
+            GLB float *sp = (GLB float *)series + (size_t)rid_of[q] * 2 * cap + (VAR ? cap : 0);
             const int i = i0 + ln;
             if (i < nq[q] && i >= w - 1) sp[i - w + 1] = o[q * SO + ln];
         }
@@ -792,44 +792,102 @@ static __device__ void ms_chains(const float *__restrict__ sigs, int m, const LD
     if (chain && n > 0 && (VAR ? assqdm != assqdm : asum != asum)) have[r] = 0;
 }
 
+// ---- the plan of the long-slice series: which reads get them, from where, how long -- and an ORDER by falling length.
+// A wave advances its MS_G chains in lockstep until the longest ends, and the launch ends with its longest workgroup: with the
+// reads as they come a wave's time is the MAXIMUM of 16 lengths (2.2 x their mean on the CNN path's candidates at the 200 k
+// window) and the long waves start whenever their turn comes.  Ordered by length (a counting sort over MS_NBKT length classes:
+// k_series_plan counts, k_series_order places), a wave's chains end together and the longest start first.
+#define MS_NBKT 256
+static __device__ __forceinline__ int ms_bucket(int n, int cap) // 0: no series; longer slices, larger classes
+{
+    if (n <= 0) return 0;
+    const long long b = 1 + (long long)n * (MS_NBKT - 2) / ((long long)cap + 1);
+    return (int)(b < MS_NBKT - 1 ? b : MS_NBKT - 1);
+}
+
+// grid = ceil(n_reads / 256), block = 256.  a_of / n_of: slice start and length (0: no series for this read); cnt [MS_NBKT] zeroed
+__global__ void __launch_bounds__(256) k_series_plan(const int32_t *__restrict__ full_len, int n_reads, int m, const int64_t *__restrict__ bounds,
+                                                     int kmax, adp_cfg cfg, int cap, int8_t *__restrict__ have, int32_t *__restrict__ a_of,
+                                                     int32_t *__restrict__ n_of, uint32_t *__restrict__ cnt)
+{
+    __shared__ uint32_t hs_[MS_NBKT];
+    LDS uint32_t *hs = (LDS uint32_t *)hs_;
+    hs[threadIdx.x] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads) {
+        int a = 0, n = 0;
+        const long long fl = full_len[r];
+        const int S = (int)(fl < m ? fl : m);
+        const long long a_e = bounds[(size_t)r * (1 + kmax)];
+        long long p_e = 0;
+        for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
+        bool ok = !(p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) && !((long long)S < a_e + cfg.median_shift_window);
+        a = (int)(a_e < S ? a_e : S);
+        const int b = (int)(p_e < S ? p_e : S);
+        n = b - a;
+        // (both series or none: a slice shorter than a window + 2 is k_validate's business, as is a window that does not fit)
+        if (ok && (p_e - a_e <= cfg.pA_var_window + 2 || p_e - a_e <= cfg.pA_mean_window + 2)) ok = false;
+        if (ok && (cfg.pA_var_window > n || cfg.pA_var_window < 1 || cfg.pA_mean_window > n || cfg.pA_mean_window < 1)) ok = false;
+        if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
+        if (!ok) { n = 0; a = 0; } // (a = 0: the unconditional prefetch of an unused read stays inside its row)
+        have[r] = ok ? 1 : 0;
+        a_of[r] = a; n_of[r] = n;
+        __hip_atomic_fetch_add(&hs[ms_bucket(n, cap)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const uint32_t c = hs[threadIdx.x];
+    if (c) atomicAdd(cnt + threadIdx.x, c); // (one device-scope atomic per class and block: ~100 blocks)
+}
+
+// grid = ceil(n_reads / 256), block = 256.  perm: the reads by falling length class; cursor [MS_NBKT] zeroed
+__global__ void __launch_bounds__(256) k_series_order(int n_reads, int cap, const int32_t *__restrict__ n_of, const uint32_t *__restrict__ cnt,
+                                                      uint32_t *__restrict__ cursor, int32_t *__restrict__ perm)
+{
+    __shared__ uint32_t start_[MS_NBKT];
+    LDS uint32_t *start = (LDS uint32_t *)start_;
+    {   // reads in longer classes come first: start[b] = sum of cnt[b' > b]
+        const int b = threadIdx.x;
+        uint32_t v = cnt[b];
+        start[b] = v;
+        __syncthreads();
+        uint32_t acc = 0;
+        for (int t = b + 1; t < MS_NBKT; t++) acc += start[t];
+        __syncthreads();
+        start[b] = acc;
+        __syncthreads();
+    }
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads) {
+        const int b = ms_bucket(n_of[r], cap);
+        const uint32_t pos = start[b] + atomicAdd(cursor + b, 1u);
+        perm[pos] = r;
+    }
+}
+
 // grid = ceil(n_reads / MS_G); block = 128 (wave 0: MS_G moving variances, wave 1: MS_G moving means); dynamic LDS
-__global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads,
-                                                         int m, const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
+__global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict__ sigs, int n_reads, int m, const int32_t *__restrict__ a_plan,
+                                                         const int32_t *__restrict__ n_plan, const int32_t *__restrict__ perm, adp_cfg cfg,
                                                          float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
     extern __shared__ float ms_raw[];
-    __shared__ int32_t a_of_[MS_G], n_of_[MS_G];
-    LDS int32_t *a_of = (LDS int32_t *)a_of_, *n_of = (LDS int32_t *)n_of_;
+    __shared__ int32_t a_of_[MS_G], n_of_[MS_G], rid_of_[MS_G];
+    LDS int32_t *a_of = (LDS int32_t *)a_of_, *n_of = (LDS int32_t *)n_of_, *rid_of = (LDS int32_t *)rid_of_;
     const int wave = threadIdx.x >> 6, ln = lane_id();
     const int r0 = blockIdx.x * MS_G;
     if (wave == 0 && ln < MS_G) {
-        const int r = r0 + ln;
-        int a = 0, n = 0;
-        if (r < n_reads) {
-            const long long fl = full_len[r];
-            const int S = (int)(fl < m ? fl : m);
-            const long long a_e = bounds[(size_t)r * (1 + kmax)];
-            long long p_e = 0;
-            for (int c = 0; c < kmax; c++) { const long long pc = bounds[(size_t)r * (1 + kmax) + 1 + c]; if (pc == 0) break; if (pc > p_e) p_e = pc; }
-            bool ok = !(p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) && !((long long)S < a_e + cfg.median_shift_window);
-            a = (int)(a_e < S ? a_e : S);
-            const int b = (int)(p_e < S ? p_e : S);
-            n = b - a;
-            // (both series or none: a slice shorter than a window + 2 is k_validate's business, as is a window that does not fit)
-            if (ok && (p_e - a_e <= cfg.pA_var_window + 2 || p_e - a_e <= cfg.pA_mean_window + 2)) ok = false;
-            if (ok && (cfg.pA_var_window > n || cfg.pA_var_window < 1 || cfg.pA_mean_window > n || cfg.pA_mean_window < 1)) ok = false;
-            if (ok && (n > cap || cfg.pA_var_window > MS_HIST || cfg.pA_mean_window > MS_HIST)) ok = false;
-            if (!ok) { n = 0; a = 0; } // (a = 0: the unconditional prefetch of an unused read stays inside its row)
-            have[r] = ok ? 1 : 0;
-        }
-        a_of[ln] = a; n_of[ln] = n;
+        const int idx = r0 + ln;
+        const int rd = perm[idx < n_reads ? idx : r0];
+        a_of[ln] = idx < n_reads ? a_plan[rd] : 0;
+        n_of[ln] = idx < n_reads ? n_plan[rd] : 0;
+        rid_of[ln] = rd;
     }
     __syncthreads();
     const int Sv = ms_ring(cfg.pA_var_window) + 4, Sm = ms_ring(cfg.pA_mean_window) + 4;
     LDS float *base = (LDS float *)ms_raw;
     LDS float *buf_v = base, *out_v = buf_v + MS_G * Sv, *buf_m = out_v + 2 * MS_G * (MS_CHUNK + 4), *out_m = buf_m + MS_G * Sm; // (out: two halves)
-    if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_var_window, series, cap, buf_v, out_v, have);
-    else ms_chains<false>(sigs, m, a_of, n_of, r0, n_reads, cfg.pA_mean_window, series, cap, buf_m, out_m, have);
+    if (wave == 0) ms_chains<true>(sigs, m, a_of, n_of, rid_of, cfg.pA_var_window, series, cap, buf_v, out_v, have);
+    else ms_chains<false>(sigs, m, a_of, n_of, rid_of, cfg.pA_mean_window, series, cap, buf_m, out_m, have);
 }
 
 static __device__ void row_clear(adp_row *row)

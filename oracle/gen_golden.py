@@ -5,6 +5,7 @@ vectors can be regenerated, never shipped to or run on the GPU box.
     /opt/conda/bin/python3.9 oracle/gen_golden.py llr        # LLR + start-peak cases, primitives
     /usr/local/bin/python3   oracle/gen_golden.py cnn        # CNN cases (needs torch)
     /usr/local/bin/python3   oracle/gen_golden.py cnn rna004_cnn_200k   # just the named case(s)
+    /usr/local/bin/python3   oracle/gen_golden.py preds      # cnn_detect over thousands of reads: positions + the scores there
 
 Inputs are regenerated from seeds by adapted_amd/synth.py (host twin of the device
 generator), so only the reference's OUTPUTS are stored.
@@ -22,7 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness  # noqa: E402
 
 import numpy as np  # noqa: E402
-from golden_cases import CASES, apply_blips, apply_extra, apply_overrides, apply_quantise, resolve_lens  # noqa: E402
+from golden_cases import (CASES, PREDS_CASES, apply_blips, apply_extra, apply_overrides, apply_quantise, preds_lens,  # noqa: E402
+                          resolve_lens)
 
 _spec = importlib.util.spec_from_file_location("synth", os.path.join(ROOT, "adapted_amd", "synth.py"))
 synth = importlib.util.module_from_spec(_spec)
@@ -210,6 +212,42 @@ def dump_intermediates(name, case, spc, sig, lens, model):
     np.savez_compressed(os.path.join(GOLD, name + ".stages.npz"), **arrs)
 
 
+def run_preds_case(name, case):
+    """cnn_detect (reference adapted/detect/cnn.py:165-182) over whole minibatches, no validation: the predicted sample positions
+    and the reference's own float32 scores at those positions -- the yardstick of the conv stacks' index-flip census
+    (tests/test_gpu_cnn.py::test_conv_stack_flips_against_the_reference)."""
+    import time
+
+    import torch
+    from adapted.detect.cnn import cnn_detect, cnn_score, load_cnn_model, prepare_data
+
+    spc = make_spc(case)
+    m, n, mb = spc.sig_preload_size, case["n"], case["minibatch"]
+    off, ds = spc.core.min_obs_adapter, spc.core.downscale_factor
+    lens = np.asarray(preds_lens(n, m), dtype=np.int32)
+    model = load_cnn_model(spc.cnn_boundaries.model_name)
+    k = int(spc.cnn_boundaries.polya_cand_k)
+    preds = np.zeros((n, 1 + k), dtype=np.int32)
+    at = np.full((n, 1 + k), np.nan, dtype=np.float32)
+    t0 = time.time()
+    for s0 in range(0, n, mb):
+        sig, _ = synth.synth_batch(case["seed"], case["first"] + s0, mb, m, lens[s0:s0 + mb])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            p = cnn_detect(sig, model, spc.cnn_boundaries, spc.core)
+            with torch.no_grad():
+                sc = cnn_score(prepare_data(sig, spc.core), model).numpy()
+        preds[s0:s0 + mb] = p
+        idx = np.where(p == 0, 0, (p - off) // ds)
+        rr = np.arange(mb)
+        at[s0:s0 + mb, 0] = sc[rr, 0, idx[:, 0]]
+        for j in range(1, 1 + k):
+            at[s0:s0 + mb, j] = np.where(p[:, j] == 0, np.nan, sc[rr, 1, idx[:, j]])
+        print(name, s0 + mb, "/", n, "%.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".preds.npz"), preds=preds, score_at=at, lens=lens,
+                        m=np.int64(m), seed=np.int64(case["seed"]), first=np.int64(case["first"]), minibatch=np.int64(mb))
+
+
 def gen_start_peak_table():
     from adapted.detect.start_peak import detect_rna_start_peak
 
@@ -320,7 +358,13 @@ def main():
         gen_bottleneck()
         gen_bottleneck_nan()
         return
-    ref_harness.install(need_torch=(what == "cnn"))
+    ref_harness.install(need_torch=(what in ("cnn", "preds")))
+    if what == "preds":
+        for name, case in PREDS_CASES.items():
+            if only and name not in only:
+                continue
+            run_preds_case(name, case)
+        return
     if what == "llr" and only:
         for name in sorted(only):
             if CASES[name]["primary"] == "llr_single":

@@ -261,6 +261,28 @@ def apply_extra(sig, lens, case):
     return sig
 
 
+
+# ---- round 4: index-flip census of the conv stacks against the reference's CPU scores (oneDNN) at scale ----
+# `oracle/gen_golden.py preds` runs cnn_detect (reference adapted/detect/cnn.py:165-182: prepare_data, the torch CPU net, cnn_predict;
+# no validation) over whole minibatches and stores, per read, the predicted sample positions [adapter_end, k poly(A) candidates] and
+# the reference's float32 scores AT those positions (tests/golden/<name>.preds.npz).  Reads are the synthetic generator's own
+# (seed, first read); 7 of 8 fill the window, every 8th is shorter (NaN tail).
+PREDS_CASES = {
+    "rna004_cnn_preds_default": dict(chem="RNA004", primary="cnn", max_obs_trace=None, seed=81, first=0, n=16000, minibatch=1000,
+                                     lens="preds"),
+    "rna004_cnn_preds_200k": dict(chem="RNA004", primary="cnn", max_obs_trace=200000, seed=82, first=0, n=1600, minibatch=160,
+                                  lens="preds"),
+}
+PREDS_SHORT = [0.31, 0.9, 0.12, 0.55, 0.07, 0.74]  # length of every 8th read as a share of the window
+
+
+def preds_lens(n, m):
+    out = []
+    for k in range(n):
+        out.append(m if k % 8 != 7 else max(2000, int(m * PREDS_SHORT[(k // 8) % len(PREDS_SHORT)])))
+    return out
+
+
 def apply_blips(sig, case):
     """case["blips"]: read i gets blips[i % len] open-pore events -- 3 samples at 260 pA every 40 samples from sample 120 on
     (inside the adapter, in front of min_obs_adapter) -- written over the synthetic signal."""
