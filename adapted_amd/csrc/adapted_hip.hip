@@ -843,6 +843,7 @@ static int llr_grouped(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
     }
     if (rows_out && !out_dev) HIPCHK(hipMemcpyAsync(rows_out, h->rows.p, (size_t)n * sizeof(adp_row), hipMemcpyDeviceToHost, h->stream));
@@ -889,6 +890,7 @@ static int llr_pipeline_t(adp_handle *h, SIG dsig, const int32_t *dlen, int n, i
         rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     }
     return ADP_OK;
@@ -1112,6 +1114,7 @@ int adp_detect_start_peak(adp_handle *h, const float *signals, const int32_t *fu
         rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     }
     return ADP_OK;
@@ -1145,6 +1148,7 @@ int adp_validate_candidates(adp_handle *h, const float *signals, const int32_t *
         rc = arena_end(h);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     }
     return ADP_OK;
@@ -1352,13 +1356,14 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     const size_t per_read = (size_t)Lrows * CNS_ROWB;
     size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
     if (cap_reads < 1) cap_reads = 1;
+    if (cap_reads > 65535) cap_reads = 65535;        // (the first / last layer's kernels take the chunk's reads as grid.y)
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
     if (h->cnn_act_kind != 1 || h->cnn_Lpad != Lrows || h->cnn_L1 != L1 || h->cnn_chunk < C) {
         for (int k = 0; k < 2; k++) {
             if (h->cnn_act[k].ensure((size_t)C * per_read + CNS_SLACK)) { g_err = "device allocation failed"; return ADP_ERR_HIP; } // (+ what the tile DMAs read past the last read's rows)
             HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding rows are never written again
         }
-        h->cnn_act_kind = 1; h->cnn_Lpad = Lrows; h->cnn_L1 = L1; h->cnn_chunk = (int)((h->cnn_act[0].cap - CNS_SLACK) / per_read);
+        h->cnn_act_kind = 1; h->cnn_Lpad = Lrows; h->cnn_L1 = L1; h->cnn_chunk = (int)((h->cnn_act[0].cap - CNS_SLACK) / per_read); if (h->cnn_chunk > 65535) h->cnn_chunk = 65535;
     }
     C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
     if (wh->op_used.ensure(8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
@@ -1415,13 +1420,14 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
     size_t per_read = (size_t)CNN_C * Lpad * 4;
     size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
     if (cap_reads < 1) cap_reads = 1;
+    if (cap_reads > 65535) cap_reads = 65535;        // (the first / last layer's kernels take the chunk's reads as grid.y)
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
     if (h->cnn_act_kind != 0 || h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
         for (int k = 0; k < 2; k++) {
             if (h->cnn_act[k].ensure((size_t)C * per_read)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
             HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding columns are never written again
         }
-        h->cnn_act_kind = 0; h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read);
+        h->cnn_act_kind = 0; h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read); if (h->cnn_chunk > 65535) h->cnn_chunk = 65535;
     }
     C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
     const float *W = wh->cnn_w.as<float>();
@@ -1537,6 +1543,7 @@ static int cnn_grouped(adp_handle *h, const float *dsig, const int32_t *dlen, in
         rc = arena_end(h, true);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         for (int i = 0; i < n_lanes; i++) { lanes[i]->prof.clear(); lanes[i]->ev_used = 0; }
     }
     if (rows_out && !out_dev) HIPCHK(hipMemcpyAsync(rows_out, h->rows.p, (size_t)n * sizeof(adp_row), hipMemcpyDeviceToHost, h->stream));
@@ -1593,6 +1600,7 @@ int adp_detect_cnn(adp_handle *h, const float *signals, const int32_t *full_len,
         rc = arena_end(h, true);
         if (rc < 0) return rc;
         if (rc == 0) break;
+        if (attempt == 2) { g_err = "the call's repeats (conv stack out of the float16 range, open-pore arena growth) are used up and the arena is still short"; return ADP_ERR_CAPACITY; }
         h->prof.clear(); h->ev_used = 0; h->last_grouped = false;
     }
     return ADP_OK;

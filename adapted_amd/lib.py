@@ -137,14 +137,57 @@ def hip_runtimes() -> List[str]:
     return seen
 
 
-def _share_torch_runtime():
-    """One process, ONE HIP runtime, whatever the import order.  PyTorch-ROCm wheels bundle a libamdhip64.so whose SONAME
-    (libamdhip64.so.7) is also what libadapted_hip.so asks for: loaded after torch, this library binds to torch's copy by
-    itself; loaded BEFORE torch it would bind to /opt/rocm's and a later `import torch` would map a second runtime beside it
-    (two runtimes = two device contexts: RCCL, events and allocations of one are invisible to the other).  So when no
-    runtime is mapped yet and a torch wheel with a bundled runtime is installed, map that copy first (by path, without
-    importing torch); the dynamic loader then resolves both this library and a later torch to it.
-    ADAPTED_HIP_RUNTIME=system keeps /opt/rocm's runtime (fine for processes that never import torch)."""
+def _elf_dynamic(path: str):
+    """(SONAME or None, [DT_NEEDED names]) of a little-endian ELF64 shared object -- read from the file, nothing is loaded"""
+    import struct
+
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if data[:6] != b"\x7fELF\x02\x01":
+        raise ValueError("not a little-endian ELF64 file: %s" % path)
+    e_phoff, = struct.unpack_from("<Q", data, 0x20)
+    e_phentsize, e_phnum = struct.unpack_from("<HH", data, 0x36)
+    loads, dyn = [], None
+    for i in range(e_phnum):
+        p_type, _flags, p_offset, p_vaddr, _paddr, p_filesz = struct.unpack_from("<IIQQQQ", data, e_phoff + i * e_phentsize)
+        if p_type == 1:
+            loads.append((p_vaddr, p_offset, p_filesz))
+        elif p_type == 2:
+            dyn = (p_offset, p_filesz)
+    if dyn is None:
+        return None, []
+
+    def off_of(vaddr):
+        for va, off, sz in loads:
+            if va <= vaddr < va + sz:
+                return off + (vaddr - va)
+        raise ValueError("address outside the file's segments")
+
+    tags = []
+    for o in range(dyn[0], dyn[0] + dyn[1], 16):
+        tag, val = struct.unpack_from("<qQ", data, o)
+        if tag == 0:
+            break
+        tags.append((tag, val))
+    strtab = off_of(next(v for t, v in tags if t == 5))
+
+    def name(v):
+        end = data.index(b"\0", strtab + v)
+        return data[strtab + v:end].decode()
+
+    return next((name(v) for t, v in tags if t == 14), None), [name(v) for t, v in tags if t == 1]
+
+
+def _share_torch_runtime(lib_path: Optional[str] = None):
+    """One process, ONE HIP runtime, whatever the import order.  PyTorch-ROCm wheels bundle a libamdhip64.so; when its SONAME is
+    the one libadapted_hip.so was linked against (libamdhip64.so.7 with this image's wheel and /opt/rocm), this library loaded
+    after torch binds to torch's copy by itself, and loaded BEFORE torch it would bind to /opt/rocm's and a later `import torch`
+    would map a second runtime beside it (two runtimes = two device contexts: RCCL, events and allocations of one are invisible to
+    the other).  So when no runtime is mapped yet and a torch wheel is installed whose bundled runtime carries exactly that
+    SONAME, map that copy first (by path, without importing torch); the dynamic loader then resolves both this library and a
+    later torch to it.  A wheel whose runtime has another SONAME (another ROCm major) is left alone: this library then runs on the
+    system runtime it was built against, as it did before.  ADAPTED_HIP_RUNTIME=system keeps /opt/rocm's runtime in any case
+    (fine for processes that never import torch)."""
     if os.environ.get("ADAPTED_HIP_RUNTIME", "auto") == "system" or hip_runtimes():
         return
     try:
@@ -154,7 +197,11 @@ def _share_torch_runtime():
         if spec is None or not spec.submodule_search_locations:
             return
         cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
+        if not os.path.exists(cand):
+            return
+        want = [n for n in _elf_dynamic(lib_path or _build.LIB)[1] if n.startswith("libamdhip64")]
+        have = _elf_dynamic(cand)[0]
+        if want and have == want[0]:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:  # noqa: BLE001 -- no torch, or an unusual install: the system runtime it is
         pass
@@ -167,13 +214,16 @@ def load():
         return _LIB
     try:
         path = os.environ.get("ADAPTED_HIP_LIB") or _build.build()  # (override: a developer's experimental build)
-        _share_torch_runtime()
+        _share_torch_runtime(path)
         lib = C.CDLL(path)
     except Exception as e:  # no CPU fallback by design
         raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
-    if len(hip_runtimes()) > 1:
-        raise HipLibraryError("two HIP runtimes are mapped into this process (%s): import torch before loading another "
-                              "library that links /opt/rocm's libamdhip64, or set ADAPTED_HIP_RUNTIME consistently"
+    if len(hip_runtimes()) > 1 and "torch" in sys.modules:
+        # (two runtimes with torch in the process: torch's device context and this library's would not see each other.  Without
+        # torch imported a second mapped copy is idle and harmless.)
+        raise HipLibraryError("two HIP runtimes are mapped into this process (%s) and torch is imported: import torch BEFORE anything "
+                              "that links /opt/rocm's libamdhip64, or -- for a process that does not need torch on the GPU -- set "
+                              "ADAPTED_HIP_RUNTIME=system before adapted_amd.lib is loaded and do not import torch"
                               % ", ".join(hip_runtimes()))
     if lib.adp_sizeof_cfg() != C.sizeof(AdpCfg) or lib.adp_sizeof_row() != ROW_DTYPE.itemsize:
         raise HipLibraryError("ABI mismatch between adapted_amd/lib.py and libadapted_hip.so")

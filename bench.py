@@ -138,7 +138,7 @@ def cpu_baseline(eng, spc, dsig, n_sample: int, m: int, gpu_rows, lens, pool, pr
         out["cores_all_from"] = _CPU_WHY
         out["value_all_cores"] = procs * n_all / wall
         out["sample_all_cores"] = "%d procs x %d reads (reference's pool layout), %.1f s wall" % (procs, n_all, wall)
-    for tname in ("r03_reference_timing.json", "r02_reference_timing.json"):
+    for tname in ("r04_reference_timing.json", "r03_reference_timing.json", "r02_reference_timing.json"):
         tfile = os.path.join(ROOT, "profiles", tname)
         if not os.path.exists(tfile):
             continue
@@ -457,7 +457,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         shape = None
         if w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and NS == 1 and os.environ.get("ADP_GROUPS", "1") == "1":
             shape = "int16" if getattr(w, "int16", False) else "f32"
-        tnames = {"f32": ("r03_traffic.json", "r02_traffic.json"), "int16": ("r03_traffic_int16.json", "r02_traffic_int16.json")}.get(shape, ())
+        tnames = {"f32": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "int16": ("r04_traffic_int16.json", "r03_traffic_int16.json", "r02_traffic_int16.json")}.get(shape, ())
         for tname in tnames:
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile):
@@ -576,6 +576,12 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
     return out
 
 
+def launch_command(n_ranks: int, port: int, argv):
+    """the launcher's own form of the driver's command: torchrun as a MODULE of this interpreter, one rank per GPU, 127.0.0.1"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, as a CHILD process (this
     process never touches the GPU), relay rank 0's JSON line and exit with the child's code."""
@@ -591,8 +597,7 @@ def spawn_ranks(args, argv):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    cmd = launch_command(args.gpus, port, argv)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line = None
@@ -638,6 +643,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workloads (configs[2] at the 200 k and the default window, configs[4]'s Pareto lengths, int16 input, two streams) that a "
                          "default 1-GPU run attaches to its JSON line")
+    ap.add_argument("--with-grouped", action="store_true", help="add the grouped-execution timeline experiment (ADP_GROUPS=9 over 3 lanes) to the secondaries")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
     ap.add_argument("--host-pipeline", type=int, default=0, metavar="N",
@@ -711,18 +717,21 @@ def main():
     if rank == 0 and world == 1 and dist is None and default_run and not args.no_secondary:
         # the other single-GPU configurations of BASELINE.json, driver-run with the headline (each its own roofline)
         sec = {}
+        detail = {"headline": {"kernel_ms": out["kernel_ms"], "ms_per_step": out["ms_per_step"]}}
         # (24 000 reads per step: the one-wave-per-chain series kernel takes the same ~11 ms for 1000 and for 24 000 reads)
-        for name, kw in (("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=3, warmup=1)),
-                         # the same step on the exact-float32 MFMA conv stack (cnn_conv.h): the round-2 kernels, 0.75 of the float32 matrix peak
-                         ("cnn_200k_f32_stack", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=2, warmup=1, env={"ADP_CNN_CONV": "f32"})),
-                         ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
-                         ("pareto", dict(lens="pareto", steps=4, warmup=1)),
-                         # the reference's own defaults: the preset's 16 000-sample window, 1000 reads per minibatch
-                         ("llr_default_window", dict(max_obs_trace=16000, steps=4, warmup=1)),
-                         ("int16", dict(int16=True, steps=4, warmup=1)),
-                         # the headline cut into groups of minibatches software-pipelined over three internal streams
-                         # (adp_detect_llr's opt-in grouped execution): the cross-phase overlap experiment, kept as a measurement
-                         ("grouped", dict(env={"ADP_GROUPS": "9", "ADP_LANES": "3", "ADP_STAGGER": "0"}, steps=4, warmup=1))):
+        plan = [("cnn_200k", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=3, warmup=1)),
+                # the same step on the exact-float32 MFMA conv stack (cnn_conv.h): the round-2 kernels, 0.75 of the float32 matrix peak
+                ("cnn_200k_f32_stack", dict(primary="cnn", max_obs_trace=200000, reads=24000, steps=2, warmup=1, env={"ADP_CNN_CONV": "f32"})),
+                ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
+                ("pareto", dict(lens="pareto", steps=4, warmup=1)),
+                # the reference's own defaults: the preset's 16 000-sample window, 1000 reads per minibatch
+                ("llr_default_window", dict(max_obs_trace=16000, steps=4, warmup=1)),
+                ("int16", dict(int16=True, steps=4, warmup=1))]
+        if args.with_grouped:
+            # the headline cut into groups of minibatches software-pipelined over three internal streams (adp_detect_llr's opt-in
+            # grouped execution): a TIMELINE experiment -- its kernels overlap each other, so it carries no roofline object
+            plan.append(("grouped", dict(env={"ADP_GROUPS": "9", "ADP_LANES": "3", "ADP_STAGGER": "0"}, steps=4, warmup=1)))
+        for name, kw in plan:
             w = argparse.Namespace(**vars(args))
             w.cpu_sample = 0
             env = kw.pop("env", {})
@@ -737,8 +746,30 @@ def main():
                     os.environ.pop(k, None)
                     if v is not None:
                         os.environ[k] = v
-            sec[name] = {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "config", "roofline", "kernel_ms")}
+            detail[name] = {"kernel_ms": o["kernel_ms"], "ms_per_step": o["ms_per_step"], "roofline": o["roofline"], "config": o["config"]}
+            rf = o["roofline"]
+            sec[name] = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                         "workload": o["config"]["workload"], "pass_rate": o["config"]["pass_rate"],
+                         "roofline": None if name == "grouped" else
+                         {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "whole_path_frac",
+                                             "f32_equivalent_tflops", "vs_f32_matrix_peak", "slowest_kernel", "slowest_kernel_ms") if k in rf}}
         out["secondary"] = sec
+        # per-kernel times of every workload of this run: a file beside the line (the line itself must survive a log tail)
+        try:
+            ddir = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(ddir, exist_ok=True)
+            with open(os.path.join(ddir, "bench_kernels.json"), "w") as fh:
+                json.dump(detail, fh, indent=1)
+            out["kernel_ms_file"] = "gpurun_out/bench_kernels.json"
+        except OSError:
+            pass
+        # LAST on the line, compact: every BASELINE configuration that fits one GPU as [reads/s, roofline.frac, whole_path_frac]
+        # (roofline: HBM for the LLR workloads, the matrix cores for the CNN ones -- the objects above say which)
+        out["summary"] = {"headline": [round(out["value"]), round(out["roofline"]["frac"], 4), round(out["roofline"]["whole_path_frac"], 4)]}
+        for name, o in sec.items():
+            rf = o["roofline"] or {}
+            out["summary"][name] = [round(o["value"]), round(rf["frac"], 4) if "frac" in rf else None,
+                                    round(rf["whole_path_frac"], 4) if "whole_path_frac" in rf else None]
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

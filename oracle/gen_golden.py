@@ -31,7 +31,7 @@ synth = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(synth)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
-CSV_CASES = ("rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_start_peak_blips", "rna004_llr_quantised", "rna004_llr_nan_holes")  # cases whose CSV text is kept as well
+CSV_CASES = ("rna002_llr_4k", "rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_start_peak_blips", "rna004_llr_quantised", "rna004_llr_nan_holes")  # cases whose CSV text is kept as well
 
 
 def make_spc(case):

@@ -35,3 +35,11 @@ def test_bench_json_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert c["mismatched_fields"] == 0 and len(c["sample"]) <= 100
     assert c["affinity_cpus"] >= 1 and "cgroup_cpu_max" in c
+    # the driver keeps the TAIL of the line: every single-GPU configuration's [reads/s, roofline.frac, whole_path_frac] ends it
+    tail = lines[0][-2000:]
+    assert '"summary"' in tail, tail[:200]
+    sm = json.loads(tail[tail.index('"summary"') + len('"summary": '):-1])
+    for k in ("headline", "cnn_200k", "cnn_200k_f32_stack", "cnn_default", "pareto", "llr_default_window", "int16"):
+        assert k in sm and sm[k][0] > 0, k
+        assert d["secondary"][k]["roofline"]["frac"] == pytest.approx(sm[k][1], abs=1e-4) if k != "headline" else True
+    assert len(json.dumps(sm)) < 1200 and "grouped" not in d["secondary"]

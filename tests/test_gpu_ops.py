@@ -65,7 +65,7 @@ def test_single_read_validator_equals_batch_rows():
         assert not row_diffs(got, w, float_rel=0.0), (i, row_diffs(got, w))
 
 
-@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k",
+@pytest.mark.parametrize("name", ["rna002_llr_4k", "rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k",
                                   "rna004_start_peak_blips", "rna004_llr_quantised", "rna004_llr_nan_holes"])
 def test_cli_detect_writes_reference_csv(tmp_path, name):
     from adapted_amd import main as cli

@@ -93,7 +93,7 @@ def _results_from_golden(name):
     return out
 
 
-@pytest.mark.parametrize("name", ["rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k",
+@pytest.mark.parametrize("name", ["rna002_llr_4k", "rna004_llr_default", "rna004_llr_mvs_overwrite_wide", "rna004_llr_open_pores", "rna004_cnn_default", "rna004_cnn_200k",
                                   "rna004_start_peak_blips", "rna004_llr_quantised", "rna004_llr_nan_holes"])
 def test_csv_text_equals_reference(tmp_path, name):
     from adapted_amd.output import CSV_COLUMNS, save_detected_boundaries
@@ -401,6 +401,25 @@ def test_one_hip_runtime_whatever_the_import_order():
         assert "torch" in first
     system = run("from adapted_amd import lib; lib.load(); print(len(lib.hip_runtimes()), lib.hip_runtimes())", ADAPTED_HIP_RUNTIME="system")
     assert system.startswith("1 ") and "torch" not in system, system
+    # a wheel whose bundled runtime carries ANOTHER SONAME than the one this library links (another ROCm major) is left alone:
+    # the library runs on the system runtime it was built against, and nothing is raised while torch stays unimported
+    other = run("from adapted_amd import lib\n"
+                "real = lib._elf_dynamic\n"
+                "lib._elf_dynamic = lambda p: (('libamdhip64.so.6', []) if '/torch/' in p else real(p))\n"
+                "lib.load(); print(len(lib.hip_runtimes()), lib.hip_runtimes())")
+    assert other.startswith("1 ") and "torch" not in other, other
+
+
+def test_elf_dynamic_reads_soname_and_needed():
+    from adapted_amd import build, lib
+
+    soname, needed = lib._elf_dynamic(build.build())
+    assert any(n.startswith("libamdhip64.so") for n in needed) and "libc.so.6" in needed
+    import glob
+
+    libc = [p for p in glob.glob("/lib/x86_64-linux-gnu/libm.so.6") + glob.glob("/usr/lib/x86_64-linux-gnu/libm.so.6")]
+    if libc:
+        assert lib._elf_dynamic(libc[0])[0] == "libm.so.6"
 
 
 def test_cpu_baseline_worker_count_follows_mask_and_quota(monkeypatch):
@@ -423,3 +442,116 @@ def test_cpu_baseline_worker_count_follows_mask_and_quota(monkeypatch):
     assert bench.cpu_worker_count(5) == (5, "--cpu-procs")
     g = bench.cpu_grant.__wrapped__() if hasattr(bench.cpu_grant, "__wrapped__") else None
     assert g is None or g["affinity_cpus"] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Multi-GPU preflight without hardware (round 4): the pieces of the N > 1 path that do not need a GPU, at the rank counts the
+# driver will launch (reference: the host pool of adapted/file_proc.py:738-784 -- here one process per GPU, whole groups of
+# minibatches per rank, one row gather).
+@pytest.mark.parametrize("ws", [2, 4, 8])
+def test_group_sharder_on_heavy_tailed_lengths(ws):
+    """io_utils.GroupSharder over 8000 Pareto lengths (BASELINE configs[4]): every rank computes the same assignment from the
+    metadata alone, every group has exactly one owner, the stream order comes back from the groups' ordinals, and the preloaded
+    samples per rank stay within 5 % of their mean (groups of 50 reads: a group is 1 / 20 of a rank's share at 8 ranks)."""
+    from adapted_amd import synth
+    from adapted_amd.io_utils import GroupSharder
+
+    m, group = 201500, 50
+    lens = [synth.pareto_length(2024, i) for i in range(8000)]
+    owners = []
+    for rank in range(ws):
+        sh = GroupSharder(ws, rank, m)
+        mine = []
+        for g0 in range(0, len(lens), group):
+            own = sh.start_group()
+            for n in lens[g0:g0 + group]:
+                sh.add(n)
+            if own:
+                mine.append(g0)
+        owners.append((mine, list(sh.load)))
+    loads = owners[0][1]
+    assert all(o[1] == loads for o in owners)                      # the same bookkeeping on every rank
+    allg = sorted(g for o in owners for g in o[0])
+    assert allg == list(range(0, len(lens), group))                # every group owned exactly once
+    order = sorted((g0, r) for r, o in enumerate(owners) for g0 in o[0])
+    assert [g for g, _ in order] == allg                            # ordinals rebuild the stream order
+    assert sum(loads) == sum(min(n, m) for n in lens)
+    assert max(loads) / (sum(loads) / ws) <= 1.05, loads
+    assert min(len(o[0]) for o in owners) >= 1
+
+
+_GLOO_WORKER_8 = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from adapted_amd import parallel, lib
+from adapted_amd.lib import ROW_DTYPE
+dist.init_process_group("gloo")
+rank, ws = dist.get_rank(), dist.get_world_size()
+assert ws == 8
+n_reads, mb = 5300, 1000                       # 6 minibatches over 8 ranks: ranks 6 and 7 own nothing
+a, b = parallel.shard_reads(n_reads, mb, ws, rank)
+rows = np.zeros(b - a, dtype=ROW_DTYPE)
+rows["col"][:, 0] = np.arange(a, b)
+rows["success"] = 1
+rows["n_open_pores"] = 0
+long_lists = {3: (7, 23), 5: (299, 39)}        # rank -> (local row, entries): lists beyond a row's 16 slots, on non-zero ranks
+if rank in long_lists:
+    i, k = long_lists[rank]
+    rows[i]["n_open_pores"] = k
+    rows[i]["open_pores_more"] = lib.register_open_pores(np.arange(k, dtype=np.int32) * 11 + rank)
+out = parallel.gather_rows(rows, dst=0)
+if rank == 0:
+    assert out.shape[0] == n_reads and np.array_equal(out["col"][:, 0], np.arange(n_reads))
+    for rk, (i, k) in long_lists.items():
+        g = parallel.shard_reads(n_reads, mb, ws, rk)[0] + i
+        assert out[g]["n_open_pores"] == k
+        got = lib._OPEN_PORES_MORE[int(out[g]["open_pores_more"])]
+        assert np.array_equal(got, np.arange(k, dtype=np.int32) * 11 + rk), (rk, got)
+    assert int((out["n_open_pores"] > lib.MAX_OPEN_PORES).sum()) == 2
+    print("GATHER8_OK", out.shape[0], [parallel.shard_reads(n_reads, mb, ws, r) for r in (5, 6, 7)])
+else:
+    assert out is None
+    assert not lib._OPEN_PORES_MORE       # the senders' lists left their registries
+dist.destroy_process_group()
+"""
+
+
+def test_row_gather_eight_ranks_gloo(tmp_path):
+    script = tmp_path / "w8.py"
+    script.write_text(_GLOO_WORKER_8 % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "GATHER8_OK 5300 [(5000, 5300), (5300, 5300), (5300, 5300)]" in r.stdout
+
+
+def test_bench_refuses_more_ranks_than_devices_before_touching_a_gpu():
+    """`python bench.py --gpus 8` with fewer visible devices: exit code 2 from the launcher itself -- no rank is started, nothing
+    that initialises the GPU is imported (counting devices does not) -- and the command it would start is torchrun's module form
+    on 127.0.0.1 (the driver's own command line)."""
+    import importlib.util
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launch_command(8, 29555, ["--gpus", "8", "--steps", "3"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29555"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight devices visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ADP_BENCH_BACKEND")}
+    probe = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '8', '--steps', '1', '--warmup', '0']\n"
+             "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n"
+             "    import torch\n    print('EXIT', e.code, 'GPU_INITIALISED', torch.cuda.is_initialized(), 'LIB', 'adapted_amd.lib' in sys.modules)\n    raise\n"
+             % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    assert "EXIT 2 GPU_INITIALISED False LIB False" in r.stdout
+    assert "--gpus 8 but only" in r.stderr
