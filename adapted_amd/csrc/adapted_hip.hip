@@ -23,6 +23,7 @@ __device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "synth.h"
 #include "validate.h"
 #include "cand_stats2.h"
+#include "validate_wg.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
 #include "cnn_conv_split.h"
@@ -82,7 +83,7 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used, series_plan;
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used, series_plan, vtodo;
     DevBuf tr_buf, tr_meta; // adp_c_llr_trace: staging of host arrays
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
@@ -272,7 +273,7 @@ int adp_destroy(adp_handle *h)
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
-    DevBuf *all[] = {&h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->vtodo, &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -525,6 +526,19 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     // launch of the call, shared by the lanes of a grouped call; a call that overflowed it is repeated on a larger one)
     adp_handle *a = h->owner ? h->owner : h;
     in.op_arena = a->op_arena.as<int32_t>(); in.op_used = a->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(a->op_arena.cap / 4);
+    // ADP_VALIDATE_WG=1 (opt-in; measured slower, profiles/r04_tried_and_dropped.txt): a workgroup per read with the slices staged in
+    // LDS takes every read that fits its plan (validate_wg.h) and flags the others; k_validate follows over the flagged ones
+    in.todo = nullptr;
+    if (!h->cfg.mvs_detect_overwrite && env_int("ADP_VALIDATE_WG", 0)) {
+        if (h->vtodo.ensure((size_t)n)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+        const unsigned vbit = std::is_same<SIG, SigF32>::value ? 16384u : 32768u;
+        if (!(h->attr_done & vbit)) { HIPCHK(hipFuncSetAttribute((const void *)k_validate_wg<SIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VwSh))); h->attr_done |= vbit; }
+        const int wg = n < 8 * h->n_cu ? n : 8 * h->n_cu;
+        { Scope s(h, "k_validate_wg");
+          hipLaunchKernelGGL(k_validate_wg<SIG>, dim3(wg), dim3(VW_THREADS), sizeof(VwSh), h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>(),
+                             h->vtodo.as<int8_t>()); }
+        in.todo = h->vtodo.as<int8_t>();
+    }
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
     { Scope s(h, "k_partition_stats");
@@ -1862,6 +1876,7 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     case 5: src = h->polya_idx.p; break;
     case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
     case 7: src = h->t1.p; break;
+    case 9: src = h->vtodo.p; if (bytes > h->vtodo.cap) return ADP_ERR_INVALID; break; // k_validate_wg: 0 = handled, else VW_WHY_*
     case 8: { if (bytes < 64 || bytes > sizeof(unsigned long long) * ADP_NDBG) return ADP_ERR_INVALID;
               HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost));
               static unsigned long long tally[ADP_NTALLY][8];

@@ -37,6 +37,7 @@ struct ValidateInT {
     int32_t *op_arena;         // whole open_pores lists of the reads with more than ADP_MAX_OPEN_PORES entries
     unsigned int *op_used;     // entries handed out (may exceed op_cap: the host then grows the arena and repeats the kernel)
     unsigned int op_cap;
+    const int8_t *todo;        // nullptr: every read; else only the reads flagged 1 (what k_validate_wg, validate_wg.h, left alone)
 };
 
 static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
@@ -916,6 +917,7 @@ __global__ void __launch_bounds__(64, 6) __attribute__((amdgpu_waves_per_eu(6, 6
     float *scr_mean = in.scratch + (size_t)blockIdx.x * 2 * in.scratch_stride;
     float *scr_var = scr_mean + in.scratch_stride;
     for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
+        if (in.todo && !in.todo[r]) continue; // (the workgroup kernel has finished this read)
         adp_row *row = rows + r;
         row_clear(row);
         if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = 0; sc->n = 0; } }

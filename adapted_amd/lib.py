@@ -713,7 +713,7 @@ class Engine:
         if what == 6:
             return Lp
         shapes = {1: ((n,), np.int32), 2: ((n, Lp), np.float32), 3: ((n, Lp), np.float64), 4: ((n,), np.int32),
-                  5: ((n,), np.int32), 7: ((n, 2), np.int32)}
+                  5: ((n,), np.int32), 7: ((n, 2), np.int32), 9: ((n,), np.int8)}
         if what == 0:
             raise ValueError("use debug_norm_params")
         shp, dt = shapes[what]
