@@ -24,6 +24,7 @@ __device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "validate.h"
 #include "cand_stats2.h"
 #include "validate_wg.h"
+#include "series_pipe.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
 #include "cnn_conv_split.h"
@@ -494,6 +495,12 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
             hipLaunchKernelGGL(k_series_plan, dim3((n + 255) / 256), dim3(256), 0, h->stream, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg, cap,
                                h->have_series.as<int8_t>(), pa, pn, pc);
             hipLaunchKernelGGL(k_series_order, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cap, pn, pc, pc + MS_NBKT, pp);
+            // round 4: the recurrences as a pipeline of waves (series_pipe.h) for the windows it takes; ADP_SERIES_PIPE=0: one wave per recurrence
+            if (sp_takes(h->cfg.pA_var_window, h->cfg.pA_mean_window) && env_int("ADP_SERIES_PIPE", 1)) {
+                if (!(h->attr_done & 32u)) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_FLOATS * 4)); h->attr_done |= 32u; }
+                hipLaunchKernelGGL(k_mvs_series_pipe, dim3((n + SP_G - 1) / SP_G), dim3(SP_THREADS), SP_LDS_FLOATS * 4, h->stream, dsig.base, n, m, pa, pn, pp,
+                                   h->cfg.pA_var_window, h->cfg.pA_mean_window, h->series.as<float>(), cap, h->have_series.as<int8_t>());
+            } else
             hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, n, m, pa, pn, pp, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         }
