@@ -451,13 +451,13 @@ static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dle
     return 0;
 }
 
-template <int THREADS, int HB>
+template <int THREADS, int HB, int U>
 static int launch_cand_stats2(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
 {
     typedef Cs2Sh<HB> Sh;
     const unsigned bit = THREADS >= 512 ? 4096u : 8192u;
-    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats2<THREADS, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); h->attr_done |= bit; }
-    hipLaunchKernelGGL((k_cand_stats2<THREADS, HB>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats2<THREADS, HB, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); h->attr_done |= bit; }
+    hipLaunchKernelGGL((k_cand_stats2<THREADS, HB, U>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                        (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
     return 0;
 }
@@ -519,8 +519,10 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
                 rc = h->m > 32768 ? launch_cand_stats<1024, CS_BIG_L0, 8>(h, dsig.base, dlen, n, m, kmax, cap)
                                   : launch_cand_stats<256, 8, 6>(h, dsig.base, dlen, n, m, kmax, cap);
             else
-                rc = h->m > 32768 ? launch_cand_stats2<512, 12>(h, dsig.base, dlen, n, m, kmax, cap)
-                                  : launch_cand_stats2<256, 10>(h, dsig.base, dlen, n, m, kmax, cap);
+                // (shapes tried on one box, 24 000 reads at the 200 k window / 32 000 at the default one: 512 threads x 8 loads in flight 14.3 ms,
+                // x 4 14.7, 1024 threads 18.9-19.8; 256 threads x 4 3.5 ms, x 8 4.4, x 2 3.45, 128 threads 4.1-4.2)
+                rc = h->m > 32768 ? launch_cand_stats2<512, 12, 8>(h, dsig.base, dlen, n, m, kmax, cap)
+                                  : launch_cand_stats2<256, 10, 4>(h, dsig.base, dlen, n, m, kmax, cap);
             if (rc) return rc;
         }
         }

@@ -29,7 +29,6 @@
 #define CS2_MAXC 16  // candidates per round (polya_cand_k beyond it: more rounds)
 #define CS2_QPC 10   // queries per candidate: 6 on the slice (median pair, two percentile pairs), 2 + 2 on the series
 #define CS2_SEGSH 27 // list entry = segment << 27 | key bits below the bin
-#define CS2_U 4      // 16-byte loads a thread keeps in flight per array
 
 template <int HB>
 struct Cs2Sh {
@@ -51,9 +50,9 @@ struct Cs2Sh {
 
 static __device__ __forceinline__ int cs2_arr(int t) { return t < 6 ? 0 : (t < 8 ? 1 : 2); }
 
-// f(value, index) for every element of p[b0 .. b1): 16-byte loads (any alignment), CS2_U per thread in flight, all of them
+// f(value, index) for every element of p[b0 .. b1): 16-byte loads (any alignment), CS2_U (template parameter) per thread in flight, all of them
 // unconditional (the last chunk is read at b1 - 4 and its leading elements, which belong to the chunk before, are skipped)
-template <int THREADS, class F>
+template <int THREADS, int CS2_U, class F>
 static __device__ __forceinline__ void cs2_sweep(const GLB float *p, int b0, int b1, int tid, F f)
 {
     if (b1 - b0 < 4) {
@@ -84,7 +83,7 @@ static __device__ __forceinline__ void cs2_sweep(const GLB float *p, int b0, int
 }
 
 // grid = n reads; block = THREADS; dynamic LDS = sizeof(Cs2Sh<HB>).  Arguments and results as k_cand_stats (cand_stats.h).
-template <int THREADS, int HB>
+template <int THREADS, int HB, int CS2_U>
 __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict__ sigs, const int32_t *__restrict__ full_len, int n_reads, int m,
                                                             const int64_t *__restrict__ bounds, int kmax, adp_cfg cfg,
                                                             const float *__restrict__ series, int cap, const int8_t *__restrict__ have,
@@ -204,7 +203,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
                     LDS uint32_t *h = (LDS uint32_t *)sh->hist + j * NB;
                     const uint32_t kl = klo[j]; const int sf = shf[j];
                     int nm = nanmin[j];
-                    cs2_sweep<THREADS>(arr[j], b0, b1, tid, [&](float v, int i) {
+                    cs2_sweep<THREADS, CS2_U>(arr[j], b0, b1, tid, [&](float v, int i) {
                         if (v != v) { nm = i < nm ? i : nm; return; }
                         const uint32_t key = f2key(v);
                         uint32_t b = ((key > kl ? key : kl) - kl) >> sf;
@@ -315,7 +314,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
                     const LDS uint8_t *lut = (const LDS uint8_t *)sh->lut + j * NB;
                     const uint32_t kl = klo[j]; const int sf = shf[j];
                     const uint32_t lowmask = sf ? ((1u << sf) - 1u) : 0u;
-                    cs2_sweep<THREADS>(arr[j], b0, b1, tid, [&](float v, int i) {
+                    cs2_sweep<THREADS, CS2_U>(arr[j], b0, b1, tid, [&](float v, int i) {
                         (void)i;
                         if (v != v) return;
                         const uint32_t key = f2key(v);
