@@ -354,6 +354,146 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
+// ---------------------------------------------------------------- layers 1, 2 with TWO waves per SIMD (round 4)
+// k_cnn_conv64s keeps one wave per SIMD (369 registers: both weight planes of 28 k-steps, the accumulators of four position tiles), and
+// that wave runs its phases in turn: DMA issue, 336 MFMAs, an epilogue of ~700 vector instructions, the copy-out -- the matrix pipe works
+// 0.37 of the time.  Here a workgroup has EIGHT waves = 2 channel halves x 4 position quarters of 32, two per SIMD, so that one's epilogue
+// and barrier waits lie under the other's MFMAs.  What makes a wave fit 256 registers: one position tile per wave (PB = 128 positions per
+// step), the hi weight plane in registers (112) and the lo plane in LDS (56 KB beside two 36 KB tiles = 128 KB per workgroup), read
+// per k-step like the activations.  Same GEMM orientation, fragments, accumulation order and epilogue arithmetic as k_cnn_conv64s: the
+// same scores, bit for bit.
+#define CNS8_PB 128
+#define CNS8_R (CNS8_PB + 6)
+#define CNS8_TILE_B ((CNS8_R * CNS_ROWB + 1023) / 1024 * 1024)
+#define CNS8_NDMA (CNS8_TILE_B / 1024)
+#define CNS8_WL_B (2 * CNS_KSTEPS * 64 * 16)
+#define CNS8_LDS (2 * CNS8_TILE_B + CNS8_WL_B)
+#define CNS8_NSTORE ((CNS8_PB * 17 + 511) / 512)
+__global__ void __launch_bounds__(512, 2) k_cnn_conv64s8(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
+                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
+                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
+                                                         int32_t *__restrict__ flag)
+{
+    extern __shared__ float cns_lds_raw[];
+    LDS char *lds = (LDS char *)cns_lds_raw;
+    LDS char *wl_lds = lds + 2 * CNS8_TILE_B;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mh = wave & 1, pq = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // A fragments: lane l holds W[o = 32 mh + (l & 31)][c = 16 cg + 8 (l >> 5) + e][t] of k-step 4 t + cg; hi plane in registers, lo plane in LDS
+    cnn_h8 wh[CNS_KSTEPS];
+    {
+        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(wsp) + (size_t)(mh * CNS_KSTEPS) * 2 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < CNS_KSTEPS; k++) wh[k] = wp[(size_t)(k * 2) * 64];
+        // lo planes of both channel halves: [mh][k][lane] 16-byte pieces
+        const cnn_h8 *wa = reinterpret_cast<const cnn_h8 *>(wsp);
+        for (int i = threadIdx.x; i < 2 * CNS_KSTEPS * 64; i += 512) {
+            const int l = i & 63, k = (i >> 6) % CNS_KSTEPS, h2 = i / (64 * CNS_KSTEPS);
+            *reinterpret_cast<LDS cnn_h8 *>(wl_lds + (size_t)i * 16) = wa[((size_t)(h2 * CNS_KSTEPS + k) * 2 + 1) * 64 + l];
+        }
+    }
+    const LDS char *wlp = wl_lds + ((size_t)mh * CNS_KSTEPS * 64 + lane) * 16;
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE);
+
+    const int total = n_reads * tiles_per_read;
+    auto dma = [&](int tix, int b) {
+        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
+        const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * CNS8_PB) * CNS_ROWB + lane * 16;
+        for (int inst = wave; inst < CNS8_NDMA; inst += 8)
+            __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + b * CNS8_TILE_B + inst * 1024), 16, 0, 0);
+    };
+    int it = blockIdx.x;
+    int buf = 0;
+    cnn_us2 hmax = {0, 0};
+    const float cx = inv_sw * (1.0f / 2048.0f);
+    if (it < total) dma(it, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; it < total; it += gridDim.x) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        // B fragment of k-step (t, cg): row pq * 32 + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
+        const LDS char *tb = lds + buf * CNS8_TILE_B + (pq * 32 + l31) * CNS_ROWB + lh * 16;
+        cnn_f32x16 am, ax;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { am[r] = bs[r]; ax[r] = 0.f; }
+        cnn_h8 fh[2], fl[2], wl[2];
+        fh[0] = *reinterpret_cast<const LDS cnn_h8 *>(tb);
+        fl[0] = *reinterpret_cast<const LDS cnn_h8 *>(tb + 128);
+        wl[0] = *reinterpret_cast<const LDS cnn_h8 *>(wlp);
+#pragma unroll
+        for (int k = 0; k < CNS_KSTEPS; k++) {
+            if (k + 1 < CNS_KSTEPS) {
+                const int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
+                fh[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(tb + t1 * CNS_ROWB + cg1 * 32);
+                fl[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(tb + t1 * CNS_ROWB + cg1 * 32 + 128);
+                wl[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(wlp + (size_t)(k + 1) * 64 * 16);
+            }
+            am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1], am, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k & 1], fh[k & 1], ax, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1], ax, 0, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+        const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // every wave has read its last fragment of this buffer
+        asm volatile("" ::: "memory");
+        LDS char *stg = lds + buf * CNS8_TILE_B;
+        {
+            LDS char *srow = stg + (pq * 32 + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                cnn_h2 hq[2], lq[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const cnn_f2 a2 = {am[4 * g + 2 * q], am[4 * g + 2 * q + 1]}, x2 = {ax[4 * g + 2 * q], ax[4 * g + 2 * q + 1]};
+                    cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
+                    v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f});
+                    const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
+                    const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+                    hq[q] = hi; lq[q] = __builtin_convertvector(rs, cnn_h2);
+                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+                }
+                const cnn_h4 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1]};
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 16 * g) = hh;
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 128 + 16 * g) = ll;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            // rows tile * PB .. of read n; pieces of rows at or beyond L1 (and the pieces a thread has no row for) go to the read's row 0,
+            // which nothing reads, so that every store is issued and the count below stays exact
+            const int nvalid = (L1 - tile * CNS8_PB < CNS8_PB ? L1 - tile * CNS8_PB : CNS8_PB) * 17;
+            char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
+            char *obase = rbase + (size_t)(CNS_FRONT + tile * CNS8_PB) * CNS_ROWB;
+            cnn_h8 piece[CNS8_NSTORE];
+#pragma unroll
+            for (int c = 0; c < CNS8_NSTORE; c++) {
+                const int i = c * 512 + (int)threadIdx.x;
+                piece[c] = *reinterpret_cast<const LDS cnn_h8 *>(stg + (i < CNS8_PB * 17 ? i : 0) * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < CNS8_NSTORE; c++) {
+                const int i = c * 512 + (int)threadIdx.x;
+                char *dst = i < nvalid ? obase + (size_t)i * 16 : rbase + (i % 17) * 16;
+                *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
+            }
+        }
+        // the DMA issued at the top of this step is older than these CNS8_NSTORE stores
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNS8_NSTORE) : "memory");
+        buf ^= 1;
+    }
+    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
 // ---------------------------------------------------------------- layer 3: ConvTranspose1d(64 -> 2, k 7, stride 3, pad 3) from split rows
 // the arithmetic of k_cnn_conv_out on a = hi + lo 2^-11; thread j makes the outputs 3 j, 3 j + 1, 3 j + 2 of both channels.
 // grid = (ceil(L1 / 128), n); block = 128: the 130 rows of the block are one contiguous range, brought into LDS by LDS-DMA
