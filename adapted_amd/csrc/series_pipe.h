@@ -45,7 +45,7 @@ typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 // grid = ceil(n_reads / SP_G); block = SP_THREADS; dynamic LDS = SP_LDS_FLOATS floats.  a_plan / n_plan / perm: k_series_plan, k_series_order
 __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__restrict__ sigs, int n_reads, int m, const int32_t *__restrict__ a_plan,
                                                                 const int32_t *__restrict__ n_plan, const int32_t *__restrict__ perm, int wv, int wm,
-                                                                float *__restrict__ series, int cap, int8_t *__restrict__ have)
+                                                                float *__restrict__ series, int cap, int8_t *__restrict__ have, int abl)
 {
     extern __shared__ float sp_raw[];
     __shared__ int32_t rid_[SP_G], a_[SP_G], n_[SP_G];
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         for (int k = 0; k < nchunks + 2; k++) {
             const int i0 = k * SP_CH;
             LDS float *myout = outm + (k & 1) * SP_G * SP_SO + g * SP_SO;
-            if (i0 < n) {
+            if (i0 < n && !(abl & 1)) {
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0;
                 for (; i < hi && i < wm; i++) { asum += mybuf[i & MASK]; if (i == wm - 1) myout[i - i0] = asum / (float)wm; }
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         for (int k = 0; k < nchunks + 2; k++) {
             const int i0 = k * SP_CH;
             LDS float *myt = tbuf + (k & 1) * SP_G * SP_SO + g * SP_SO;
-            if (i0 < n) {
+            if (i0 < n && !(abl & 2)) {
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0;
                 for (; i < hi && i < wv; i++) {
@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - 1, i0 = c * SP_CH;
-            if (c >= 0 && i0 < n) {
+            if (c >= 0 && i0 < n && !(abl & 4)) {
                 const LDS float *myt = tbuf + (c & 1) * SP_G * SP_SO + g * SP_SO;
                 LDS float *myout = outv + (c & 1) * SP_G * SP_SO + g * SP_SO;
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - lag;
-            if (c >= 0) {
+            if (c >= 0 && !(abl & 16)) {
 #pragma unroll
                 for (int u = 0; u < NU; u++) {
                     const int q = 4 * u + (ln >> 4), e = 4 * sub, i = c * SP_CH + e;
