@@ -501,7 +501,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
             if (sp_takes(h->cfg.pA_var_window, h->cfg.pA_mean_window) && env_int("ADP_SERIES_PIPE", 1)) {
                 if (!(h->attr_done & 32u)) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_FLOATS * 4)); h->attr_done |= 32u; }
                 hipLaunchKernelGGL(k_mvs_series_pipe, dim3((n + SP_G - 1) / SP_G), dim3(SP_THREADS), SP_LDS_FLOATS * 4, h->stream, dsig.base, n, m, pa, pn, pp,
-                                   h->cfg.pA_var_window, h->cfg.pA_mean_window, h->series.as<float>(), cap, h->have_series.as<int8_t>(), env_int("ADP_SP_ABL", 0));
+                                   h->cfg.pA_var_window, h->cfg.pA_mean_window, h->series.as<float>(), cap, h->have_series.as<int8_t>());
             } else
             hipLaunchKernelGGL(k_mvs_series_wave, dim3((n + MS_G - 1) / MS_G), dim3(128), lds, h->stream, dsig.base, n, m, pa, pn, pp, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());

@@ -16,7 +16,12 @@
 //     wave 4  storer      outv of the chunk before -> global memory, 16-byte stores (4 reads per instruction)
 //     wave 5  storer      outm likewise
 // (waves 0 / 4 and 1 / 5 share a SIMD, the two halves of the variance have one each); one barrier per chunk of 64 steps, every
-// buffer between two waves double.  A lane is a read (SP_G = 48 of the 64: LDS, 128 KB per workgroup), the reads come ordered by
+// buffer between two waves double.  Measured (24 000 reads at the 200 k window, longest slice 195 000 steps = 3050 chunks): 12.1 ms against
+// 12.8 for k_mvs_series_wave on the same ordered reads; with parts of it left out (results wrong, timing only): no mean wave 10.2, no
+// part 1 9.0, no part 2 10.5, no storers 10.0, neither part 7.9, no arithmetic at all 6.4 ms -- the skeleton (loader, storers, one barrier
+// per chunk) costs 2 us per chunk, and the roles' costs ADD although they sit on different SIMDs: at this occupancy (six waves on a CU,
+// most CUs' SIMDs idle) an instruction costs ~3.3 ns to issue and ~10 ns when it depends on its predecessor (tools/wave_simd_placement.hip),
+// and every wave has a few hundred of them per chunk behind the same barrier.  A lane is a read (SP_G = 48 of the 64: LDS, 128 KB per workgroup), the reads come ordered by
 // falling length (k_series_plan / k_series_order), so a wave's chains end together and the longest start first.
 #pragma once
 #include "validate.h"
@@ -45,7 +50,7 @@ typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 // grid = ceil(n_reads / SP_G); block = SP_THREADS; dynamic LDS = SP_LDS_FLOATS floats.  a_plan / n_plan / perm: k_series_plan, k_series_order
 __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__restrict__ sigs, int n_reads, int m, const int32_t *__restrict__ a_plan,
                                                                 const int32_t *__restrict__ n_plan, const int32_t *__restrict__ perm, int wv, int wm,
-                                                                float *__restrict__ series, int cap, int8_t *__restrict__ have, int abl)
+                                                                float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
     extern __shared__ float sp_raw[];
     __shared__ int32_t rid_[SP_G], a_[SP_G], n_[SP_G];
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         for (int k = 0; k < nchunks + 2; k++) {
             const int i0 = k * SP_CH;
             LDS float *myout = outm + (k & 1) * SP_G * SP_SO + g * SP_SO;
-            if (i0 < n && !(abl & 1)) {
+            if (i0 < n) {
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0;
                 for (; i < hi && i < wm; i++) { asum += mybuf[i & MASK]; if (i == wm - 1) myout[i - i0] = asum / (float)wm; }
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         for (int k = 0; k < nchunks + 2; k++) {
             const int i0 = k * SP_CH;
             LDS float *myt = tbuf + (k & 1) * SP_G * SP_SO + g * SP_SO;
-            if (i0 < n && !(abl & 2)) {
+            if (i0 < n) {
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0;
                 for (; i < hi && i < wv; i++) {
@@ -227,7 +232,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - 1, i0 = c * SP_CH;
-            if (c >= 0 && i0 < n && !(abl & 4)) {
+            if (c >= 0 && i0 < n) {
                 const LDS float *myt = tbuf + (c & 1) * SP_G * SP_SO + g * SP_SO;
                 LDS float *myout = outv + (c & 1) * SP_G * SP_SO + g * SP_SO;
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
@@ -267,7 +272,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - lag;
-            if (c >= 0 && !(abl & 16)) {
+            if (c >= 0) {
 #pragma unroll
                 for (int u = 0; u < NU; u++) {
                     const int q = 4 * u + (ln >> 4), e = 4 * sub, i = c * SP_CH + e;
