@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Per-kernel average durations of a rocprofv3 --kernel-trace run of `python bench.py`, split by WORKLOAD.
 
-The default bench run holds seven workloads in one process (the headline, then the secondaries cnn_200k, cnn_default,
-pareto, llr_default_window, int16, grouped); each begins with the synthetic generator (k_synth), which separates them in the trace.  Inside a workload the
+The default bench run holds seven workloads in one process (the headline, then the secondaries cnn_200k, cnn_200k_f32_stack,
+cnn_default, pareto, llr_default_window, int16; grouped with --with-grouped); each begins with the synthetic generator (k_synth), which separates them in the trace.  Inside a workload the
 launches are grouped by kernel name and grid size (the CPU-baseline check of the headline runs the same kernels on one
 minibatch: a different grid).  Durations are in microseconds, over ALL launches of the group (warm-up steps included).
 
-usage: summarize_phases.py <results.db> <out.csv> [names of the phases, default headline cnn_200k cnn_default pareto llr_default_window int16 grouped]
+usage: summarize_phases.py <results.db> <out.csv> [names of the phases, default headline cnn_200k cnn_200k_f32_stack cnn_default pareto llr_default_window int16 grouped]
 """
 import csv
 import sqlite3
@@ -19,7 +19,7 @@ from kname import kname  # noqa: E402
 
 def main():
     db, out = sys.argv[1], sys.argv[2]
-    names = sys.argv[3:] or ["headline", "cnn_200k", "cnn_default", "pareto", "llr_default_window", "int16", "grouped"]
+    names = sys.argv[3:] or ["headline", "cnn_200k", "cnn_200k_f32_stack", "cnn_default", "pareto", "llr_default_window", "int16", "grouped"]
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, duration, grid_x, grid_y, workgroup_x from kernels order by start").fetchall()
     phase = -1

@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o run --outp
 # 4. the CNN step at the 200 k window: kernel stats, matrix-core counters, traffic
 CNN="python3 bench.py --primary cnn --reads 8000 --steps 3 --warmup 1 --no-secondary --cpu-sample 0"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_cnn_stats -o run -- $CNN > $OUT/${TAG}_cnn_under_rocprof.json 2> $OUT/${TAG}_cnn_under_rocprof.err
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/${TAG}_cnn_pmc_sq -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_sq.err
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/${TAG}_cnn_pmc_sq -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_sq.err || { rm -rf $OUT/${TAG}_cnn_pmc_sq; rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/${TAG}_cnn_pmc_sq -o run --output-format csv -- $CNN > /dev/null 2>> $OUT/${TAG}_cnn_pmc_sq.err; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_cnn_pmc_fetch -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_cnn_pmc_write -o run --output-format csv -- $CNN > /dev/null 2> $OUT/${TAG}_cnn_pmc_write.err
 # 5. the int16-native path (raw ADC samples in HBM): the same traffic pass, to set beside the float32 one
