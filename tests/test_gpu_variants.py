@@ -1,0 +1,112 @@
+"""The kernels that stayed in the tree beside the defaults (round 4) must keep giving the same BYTES: every switch below selects another
+implementation of the same reference rows -- the round-2 candidate statistics (`ADP_CAND_STATS_OLD=1`, cand_stats.h) against the
+two-sweep form (cand_stats2.h), one wave per moving-window recurrence (`ADP_SERIES_PIPE=0`) against the pipeline of waves
+(series_pipe.h), validation by a workgroup per read with LDS-staged slices (`ADP_VALIDATE_WG=1`, validate_wg.h) against the wave
+per read, the 64 -> 64 conv layers with two waves per SIMD (`ADP_CNN_WG8=1`: same scores bit for bit).  Reference rows: V1-V4
+adapted/detect/combined.py:358-631, mvs.py:45-158; C2 adapted/detect/cnn.py:16-52."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8")
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in SWITCHES}
+    try:
+        for k in SWITCHES:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        return fn()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+def _canon(rows, lib):
+    lists = {int(i): lib._OPEN_PORES_MORE[int(rows[i]["open_pores_more"])].tolist() for i in np.flatnonzero(rows["n_open_pores"] > lib.MAX_OPEN_PORES)}
+    r = rows.copy()
+    r["open_pores_more"] = 0
+    return r.tobytes(), lists
+
+
+def _spc(primary, max_obs_trace=None, **over):
+    from adapted_amd.config import get_chemistry_specific_config
+
+    spc = get_chemistry_specific_config("RNA004")
+    spc.llr_boundaries.llr_detect = primary == "llr"
+    spc.cnn_boundaries.cnn_detect = primary == "cnn"
+    if max_obs_trace:
+        spc.core.max_obs_trace = max_obs_trace
+    for k, v in over.items():
+        sec, name = k.split("__")
+        setattr(getattr(spc, sec), name, v)
+    spc.update_primary_method()
+    spc.update_sig_preload_size()
+    return spc
+
+
+@pytest.mark.parametrize("window, k, quantise, windows", [(None, 10, 0.0, None), (60000, 10, 0.18, None), (200000, 10, 0.0, None), (200000, 15, 0.18, None),
+                                                           (34000, 3, 0.0, (48, 12)), (34000, 10, 0.0, (101, 23))])
+def test_cnn_path_variants_give_the_same_rows(window, k, quantise, windows):
+    from adapted_amd import lib, synth
+    from adapted_amd.detect import cnn
+
+    over = {"cnn_boundaries__polya_cand_k": k}
+    if windows:
+        over["mvs_polya__pA_var_window"], over["mvs_polya__pA_mean_window"] = windows
+    spc = _spc("cnn", window, **over)
+    m = spc.sig_preload_size
+    n = 64 if m > 100000 else 128
+    rng = np.random.default_rng(k + (window or 0))
+    lens = np.array([m if rng.random() < 0.6 else max(1012, synth.pareto_length(9, i, lo=3000, hi=3 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(900 + k, 0, n, m, lens)
+    if quantise:
+        q = np.float32(quantise)
+        sig = (np.round(sig / q) * q).astype(np.float32)
+    for r in (3, 17):                                  # open_pores lists beyond a row's 16 entries
+        for j in range(19):
+            sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
+    ref = None
+    for env in ({}, {"ADP_CAND_STATS_OLD": "1"}, {"ADP_SERIES_PIPE": "0"}, {"ADP_VALIDATE_WG": "1"}, {"ADP_CNN_WG8": "1"},
+                {"ADP_CAND_STATS_OLD": "1", "ADP_SERIES_PIPE": "0", "ADP_VALIDATE_WG": "1", "ADP_CNN_WG8": "1"}):
+        def run():
+            eng = lib.Engine(spc, n, m, device=0)       # (ADP_CNN_WG8 is read when the engine is made)
+            try:
+                cnn.ensure_weights(eng, None, spc)
+                rows, bounds = eng.detect_cnn_rows(sig, lens, n, n // 2)
+                return _canon(rows, lib), bounds.tobytes()
+            finally:
+                eng.close()
+        got = _with_env(env, run)
+        if ref is None:
+            ref = got
+            assert np.frombuffer(got[1], dtype=np.int64).any()
+        assert got == ref, env
+
+
+@pytest.mark.parametrize("window", [None, 200000])
+def test_llr_path_with_the_workgroup_validation_gives_the_same_rows(window):
+    from adapted_amd import lib, synth
+
+    spc = _spc("llr", window)
+    m = spc.sig_preload_size
+    n = 96
+    lens = np.array([m if i % 4 else max(1012, synth.pareto_length(3, i, lo=1500, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(77, 0, n, m, lens)
+    sig[5, 3000:3004] = np.nan                          # a NaN hole inside a read (whichever kernel ends up validating it)
+    for j in range(21):
+        sig[9, 120 + 40 * j: 123 + 40 * j] = 260.0      # an open_pores list beyond 16 entries
+    eng = lib.Engine(spc, n, m, device=0)
+    a, _ = _with_env({}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
+    b, _ = _with_env({"ADP_VALIDATE_WG": "1"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
+    why = eng.debug_fetch(9, n)
+    eng.close()
+    assert _canon(a, lib) == _canon(b, lib)
+    assert (why == 0).sum() >= n // 2  # most reads took the workgroup kernel
+    print("k_validate_wg left to k_validate:", {int(k): int(v) for k, v in zip(*np.unique(why, return_counts=True))}, "the NaN read:", int(why[5]))
