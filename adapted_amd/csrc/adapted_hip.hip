@@ -91,7 +91,9 @@ struct adp_handle {
     int cnn_Lpad = 0, cnn_L1 = 0, cnn_chunk = 0, n_cu = 256;
     // conv stack: 1 = split float16 MFMA (cnn_conv_split.h, the default), 0 = exact float32 MFMA (cnn_conv.h; ADP_CNN_CONV=f32).
     // cnn_redo_f32: the split kernels met an activation outside the float16 range in this call -- it is being repeated in float32
-    int cnn_mode = 1, cnn_act_kind = -1;
+    int cnn_mode = 1;
+    DevBuf cnn_actf[2];                                  // the exact-float32 stack's activations [chunk][64][Lpad] (cnn_act: the split rows)
+    int cnn_f_Lpad = 0, cnn_f_L1 = 0, cnn_f_chunk = 0;
     bool cnn_redo_f32 = false;
     bool cnn_wg8 = false;     // ADP_CNN_WG8=1: the 64 -> 64 layers with two waves per SIMD (k_cnn_conv64s8)
     bool cnn_fuse_in = false; // ADP_CNN_FUSE_IN=1: layer 0 computed inside layer 1's kernel (measured: no gain at the 200 k window, see below)
@@ -276,7 +278,7 @@ int adp_destroy(adp_handle *h)
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
-    DevBuf *all[] = {&h->vtodo, &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cnn_actf[0], &h->cnn_actf[1], &h->vtodo, &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -1385,12 +1387,12 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     if (cap_reads < 1) cap_reads = 1;
     if (cap_reads > 65535) cap_reads = 65535;        // (the first / last layer's kernels take the chunk's reads as grid.y)
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
-    if (h->cnn_act_kind != 1 || h->cnn_Lpad != Lrows || h->cnn_L1 != L1 || h->cnn_chunk < C) {
+    if (h->cnn_Lpad != Lrows || h->cnn_L1 != L1 || h->cnn_chunk < C) {
         for (int k = 0; k < 2; k++) {
             if (h->cnn_act[k].ensure((size_t)C * per_read + CNS_SLACK)) { g_err = "device allocation failed"; return ADP_ERR_HIP; } // (+ what the tile DMAs read past the last read's rows)
             HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding rows are never written again
         }
-        h->cnn_act_kind = 1; h->cnn_Lpad = Lrows; h->cnn_L1 = L1; h->cnn_chunk = (int)((h->cnn_act[0].cap - CNS_SLACK) / per_read); if (h->cnn_chunk > 65535) h->cnn_chunk = 65535;
+        h->cnn_Lpad = Lrows; h->cnn_L1 = L1; h->cnn_chunk = (int)((h->cnn_act[0].cap - CNS_SLACK) / per_read); if (h->cnn_chunk > 65535) h->cnn_chunk = 65535;
     }
     C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
     if (wh->op_used.ensure(8)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
@@ -1457,16 +1459,18 @@ static int cnn_forward_dev(adp_handle *h, const float *prepared, int n_reads, in
     if (cap_reads < 1) cap_reads = 1;
     if (cap_reads > 65535) cap_reads = 65535;        // (the first / last layer's kernels take the chunk's reads as grid.y)
     int C = (int)((size_t)n_reads < cap_reads ? (size_t)n_reads : cap_reads);
-    if (h->cnn_act_kind != 0 || h->cnn_Lpad != Lpad || h->cnn_L1 != L1 || h->cnn_chunk < C) {
+    // (buffers of its own: a call that falls back from the split stack -- an activation beyond the float16 range -- and the split
+    // call after it used to share one pair and cleared up to 2 x 4 GiB of padding on every change of kind)
+    if (h->cnn_f_Lpad != Lpad || h->cnn_f_L1 != L1 || h->cnn_f_chunk < C) {
         for (int k = 0; k < 2; k++) {
-            if (h->cnn_act[k].ensure((size_t)C * per_read)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-            HIPCHK(hipMemsetAsync(h->cnn_act[k].p, 0, h->cnn_act[k].cap, h->stream)); // the padding columns are never written again
+            if (h->cnn_actf[k].ensure((size_t)C * per_read)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+            HIPCHK(hipMemsetAsync(h->cnn_actf[k].p, 0, h->cnn_actf[k].cap, h->stream)); // the padding columns are never written again
         }
-        h->cnn_act_kind = 0; h->cnn_Lpad = Lpad; h->cnn_L1 = L1; h->cnn_chunk = (int)(h->cnn_act[0].cap / per_read); if (h->cnn_chunk > 65535) h->cnn_chunk = 65535;
+        h->cnn_f_Lpad = Lpad; h->cnn_f_L1 = L1; h->cnn_f_chunk = (int)(h->cnn_actf[0].cap / per_read); if (h->cnn_f_chunk > 65535) h->cnn_f_chunk = 65535;
     }
-    C = h->cnn_chunk < n_reads ? h->cnn_chunk : n_reads;
+    C = h->cnn_f_chunk < n_reads ? h->cnn_f_chunk : n_reads;
     const float *W = wh->cnn_w.as<float>();
-    float *A = h->cnn_act[0].as<float>(), *B = h->cnn_act[1].as<float>();
+    float *A = h->cnn_actf[0].as<float>(), *B = h->cnn_actf[1].as<float>();
     for (int s0 = 0; s0 < n_reads; s0 += C) {
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
         const float *x = prepared + (size_t)s0 * Lc;

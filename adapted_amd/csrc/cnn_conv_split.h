@@ -47,6 +47,9 @@ typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
                              // rides through the 64 -> 64 layers with the bias and leaves in layer 3)
 #define CNS_SLACK 65536      // bytes behind the last read's rows that a tile DMA may read (k_cnn_conv_out_s: up to 130 rows from a row below L1)
 #define CNS_WSP_LAYER (2 * CNS_KSTEPS * 2 * 64 * 8) // float16 per layer in the split-weight buffer
+// Row 0 of a read's front padding is the DUMP row: the epilogues store the pieces of rows at or beyond L1 there so that every store is issued
+// and the counted s_waitcnt stays exact.  Nothing may read it: a tile's DMA starts at row CNS_FRONT - 3, layer 3's block at CNS_FRONT - 1.
+static_assert(CNS_FRONT >= 4, "the dump row (row 0) must lie in front of every row a tile DMA or the last layer reads");
 
 static __device__ __forceinline__ void cns_split(float y, _Float16 &hi, _Float16 &lo)
 {
@@ -166,6 +169,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 {
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
+    static_assert(NSTORE * 256 >= PB * 17 && (NSTORE - 1) * 256 < PB * 17, "the epilogue issues exactly NSTORE stores per thread: the s_waitcnt below counts them");
     extern __shared__ float cns_lds_raw[];
     LDS char *lds = (LDS char *)cns_lds_raw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
