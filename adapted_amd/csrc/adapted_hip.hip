@@ -72,7 +72,7 @@ struct adp_handle {
     // geometry of the LLR path
     int T = 0, off = 0, ds = 1, L = 0, Lp = 0, nck = 0, nsum = 0;
     DevBuf mbs, ghist, gbelow, gcnt, cbuf, fz, fcnt, n1heavy, ct_pk, ct_pv, ct_out, gstat, down, nvalid, ck, tail, trace, bmax, bmin, t1, adapter_idx, polya_idx;
-    DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
+    DevBuf bounds, topk_none, rows, preq, series, have_series, vscratch, pk, pkv, npk, mk, st, sp, any_none, sig_stage, len_stage, bounds_stage;
     int vslots = 0, vstride = 0, pslots = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -186,6 +186,7 @@ static int alloc_all(adp_handle *h, int reads, bool llr)
     h->pslots = (int)(R < 8192 ? R : 8192);
     if (llr) {
     bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
+    bad |= h->pkv.ensure(R * (Lp / 2 + 1) * 8);  // ... and the maxima's heights
     bad |= h->npk.ensure(R * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
     }
@@ -279,7 +280,7 @@ int adp_destroy(adp_handle *h)
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
     DevBuf *all[] = {&h->cnn_actf[0], &h->cnn_actf[1], &h->vtodo, &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
-                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->npk,
+                     &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->pkv, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -759,18 +760,19 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
                                h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
                                h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>());
         }
+        double *pkvp = env_int("ADP_PK_VALUES", 1) ? h->pkv.as<double>() : nullptr; // (0: k_polya_peak gathers the heights from the trace, as before)
         if (upto >= 6) {
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
                                h->ck.as<double2>(), h->tail.as<double2>(), h->adapter_idx.as<int32_t>(), minibatch, mbs,
-                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n, 5);
+                               h->trace.as<double>(), h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), 0, h->pk.as<int32_t>(), h->npk.as<int32_t>(), h->Lp / 2 + 1, h->gstat.as<double>(), n, 5, pkvp);
         }
         if (upto >= 7) {
             Scope s(h, "k_polya_peak");
             int grid = n < h->pslots ? n : h->pslots;
             hipLaunchKernelGGL(k_polya_peak, dim3(grid), dim3(64), (size_t)(((h->Lp / 2 + 1) + 8) / 16 + 2) * 4, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->adapter_idx.as<int32_t>(), n, minibatch, mbs,
-                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>());
+                               h->pk.as<int32_t>(), h->mk.as<uint32_t>(), h->polya_idx.as<int32_t>(), h->npk.as<int32_t>(), pkvp);
         }
         if (ps && ps->done[1]) HIPCHK(hipEventRecord(ps->done[1], st));
     }

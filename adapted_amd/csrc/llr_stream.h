@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
                                               const MbState *__restrict__ mbs, double *__restrict__ trace,
                                               double *__restrict__ bmax, double *__restrict__ bmin, int nsum,
                                               int2 *__restrict__ t1, int sanitize, int32_t *__restrict__ pk_all,
-                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat, int n_reads, int oh1)
+                                              int32_t *__restrict__ npk_all, int pk_stride, double *__restrict__ gstat, int n_reads, int oh1,
+                                              double *__restrict__ pkv_all = nullptr)
 {
     // GAINS_WPB waves (reads) per block share log_cr's table; everything else is private to a wave, so the only
     // block-wide barrier is the one after the table copy
@@ -388,6 +389,8 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
     // is in LDS, and handed to k_polya_peak as an index list (npk = -1: a plateau was met, recount there)
     const bool emit = (PASS == 2 || sanitize) && pk_all;
     int32_t *pk = emit ? pk_all + (size_t)r * pk_stride : nullptr;
+    // the maxima's (sanitised) heights beside their positions: k_polya_peak reads them as a list instead of gathering one cache line per maximum
+    double *pkv = (emit && pkv_all) ? pkv_all + (size_t)r * pk_stride : nullptr;
     int npk = 0;
     bool plateau = false;
     double carry1 = 0.0, carry2 = 0.0; // sanitised x[tb-1], x[tb-2]
@@ -521,7 +524,7 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
                     }
                 }
                 unsigned long long mk = __ballot(pkf);
-                if (pkf) pk[npk + __popcll(mk & ((1ull << ln) - 1ull))] = j;
+                if (pkf) { const int at = npk + __popcll(mk & ((1ull << ln) - 1ull)); pk[at] = j; if (pkv) pkv[at] = xj; }
                 npk += __popcll(mk);
             }
             const int last = min(TRACE_TILE, n - tb) - 1;

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                                                    const int32_t *__restrict__ adapter_idx, int n_reads, int mbsize,
                                                    const MbState *__restrict__ mbs, int32_t *__restrict__ pk_all,
                                                    uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx,
-                                                   const int32_t *__restrict__ npk_all)
+                                                   const int32_t *__restrict__ npk_all, const double *__restrict__ pkv_all = nullptr)
 {
     extern __shared__ uint32_t stw_raw[];
     LDS uint32_t *stw = (LDS uint32_t *)stw_raw; // ordinal k is slot k + 4 (slots 0..3 stay PST_NONE)
@@ -418,6 +418,8 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
             //    recounted here (one load per lane, neighbours by shuffle) when a plateau was met
             int npk = npk_all[r];
             const bool recount = npk < 0;
+            // heights of the listed maxima as k_gains wrote them (none after a recount: gathered from the trace then)
+            const double *pkv = (pkv_all && !recount) ? pkv_all + (size_t)r * half : nullptr;
             if (recount) npk = 0;
             double carry = 0.0; // value at base - 1
             __syncthreads();
@@ -473,11 +475,20 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                     const bool valid = k >= 0 && k < npk;
                     pp[u] = valid ? pk[k] : (k < 0 ? -0x40000000 : 0x40000000);
                 }
+                if (pkv) { // (uniform) positions and heights are independent loads: one round trip per step instead of two
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int k = base4 + 56 * u - 4 + ln;
+                        const bool valid = k >= 0 && k < npk;
+                        vv[u] = valid ? pkv[k] : 0.0;
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int k = base4 + 56 * u - 4 + ln;
                     const bool valid = k >= 0 && k < npk;
                     vv[u] = valid ? tv_get(tv, pp[u]) : 0.0;
+                }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
