@@ -701,7 +701,23 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # RCCL prints its version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there:
+        # file descriptor 1 points at stderr while the group and its first collective are made
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                t0 = torch.zeros(1, device=torch.device("cuda", local))
+                dist.all_reduce(t0)
+                torch.cuda.synchronize()
+            else:
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     if args.host_pipeline > 0:
         return host_pipeline_bench(args, make_spc(args.max_obs_trace), local)

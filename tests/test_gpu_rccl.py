@@ -43,13 +43,18 @@ def _bench(extra_env, launcher):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
     assert len(lines) == 1, out.stdout[-2000:]
+    if not launcher:  # (torchrun adds nothing to a rank's stdout either, but only the plain form is promised to be bare)
+        # ONE line on stdout, nothing else: RCCL's version banner (printed on stdout when the first communicator comes up) goes to stderr
+        assert [ln for ln in out.stdout.splitlines() if ln.strip()] == lines, out.stdout[:500]
     return json.loads(lines[0])
 
 
 def test_bench_rccl_branch_on_a_group_of_one():
     plain = _bench({}, launcher=False)
     grouped = _bench({"ADP_BENCH_FORCE_DIST": "1", "ADP_BENCH_BACKEND": "nccl"}, launcher=True)
-    _keep("r03_rccl_group_of_one_bench.json", json.dumps({"plain": plain, "rccl_group_of_one": grouped}, indent=1))
+    bare = _bench({"ADP_BENCH_FORCE_DIST": "1", "ADP_BENCH_BACKEND": "nccl"}, launcher=False)  # (its own rendezvous; stdout checked bare)
+    assert bare["rows_sha256"] == plain["rows_sha256"] and bare["dist"]["backend"] == "nccl"
+    _keep("r04_rccl_group_of_one_bench.json", json.dumps({"plain": plain, "rccl_group_of_one": grouped}, indent=1))
     d = grouped["dist"]
     assert d["backend"] == "nccl" and d["world_size"] == 1 and d["forced_group_of_one"] is True
     assert len(d["hip_runtimes"]) == 1, d["hip_runtimes"]            # RCCL and the library share ONE runtime
