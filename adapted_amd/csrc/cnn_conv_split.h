@@ -255,7 +255,20 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-        } else if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        }
+        // the next tile's LDS-DMA pieces are issued INSIDE the k-loop, one per k-step (a piece costs ~60 cycles of issue among MFMAs,
+        // 100-185 in a burst in front of them: MI355X_MICROARCH.md), still older than this step's stores for the counted wait below
+        // (NT = 4 sits at the register limit -- 512 with the accumulators of four tiles: there the pieces stay a burst at the step's top)
+        constexpr bool INLOOP = NT < 4;
+        if (!FIRST && !INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        const bool more = !FIRST && INLOOP && it + gridDim.x < total;
+        const GLB char *nsrc = nullptr;
+        if (more) {
+            const int tix = it + gridDim.x, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
+            nsrc = (const GLB char *)in + ((size_t)nn * Lrows + CNS_FRONT - 3 + (size_t)tile2 * PB) * CNS_ROWB + lane * 16;
+        }
+        LDS char *ndst = lds + (buf ^ 1) * TILE_B;
+        static_assert((NDMA + 3) / 4 <= CNS_KSTEPS, "one DMA piece per k-step and wave");
         // B fragment of k-step (t, cg), position tile j: row ph * 32 NT + 32 j + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
         const LDS char *tb = lds + buf * TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
         cnn_f32x16 am[NT], ax[NT];
@@ -271,6 +284,8 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         }
 #pragma unroll
         for (int k = 0; k < CNS_KSTEPS; k++) {
+            if (more && wave + 4 * k < NDMA)
+                __builtin_amdgcn_global_load_lds((const GLB float *)(nsrc + (wave + 4 * k) * 1024), (LDS float *)(ndst + (wave + 4 * k) * 1024), 16, 0, 0);
             if (k + 1 < CNS_KSTEPS) {
                 const int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
 #pragma unroll
