@@ -1311,7 +1311,8 @@ int adp_cnn_prepare(adp_handle *h, const float *signals, int n_reads, int m, int
 #define CNN_B2 (CNN_W2 + CNN_C * CNN_C * CNN_K)
 #define CNN_W3 (CNN_B2 + CNN_C)
 #define CNN_B3 (CNN_W3 + CNN_C * 2 * CNN_K)
-#define CNN_WTOTAL (CNN_B3 + 2)
+#define CNN_W3S (CNN_B3 + 2)                 // layer 3's weights times 1 / CNS_ASCALE (exact: a power of two) for the split stack's last layer
+#define CNN_WTOTAL (CNN_W3S + CNN_C * 2 * CNN_K)
 
 int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const float *w1, const float *b1, const float *w2,
                         const float *b2, const float *w3, const float *b3)
@@ -1324,6 +1325,7 @@ int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const f
     memcpy(&all[CNN_W1], w1, sizeof(float) * CNN_C * CNN_C * CNN_K); memcpy(&all[CNN_B1], b1, sizeof(float) * CNN_C);
     memcpy(&all[CNN_W2], w2, sizeof(float) * CNN_C * CNN_C * CNN_K); memcpy(&all[CNN_B2], b2, sizeof(float) * CNN_C);
     memcpy(&all[CNN_W3], w3, sizeof(float) * CNN_C * 2 * CNN_K); memcpy(&all[CNN_B3], b3, sizeof(float) * 2);
+    for (int i = 0; i < CNN_C * 2 * CNN_K; i++) all[CNN_W3S + i] = w3[i] * (1.0f / CNS_ASCALE);
     HIPCHK(hipMemcpyAsync(h->cnn_w.p, all.data(), (size_t)CNN_WTOTAL * 4, hipMemcpyHostToDevice, h->stream));
     // the 64 -> 64 layers once more as split float16 B fragments (cnn_conv_split.h), scaled by a power of two per layer so that the
     // largest weight lands in [2^13, 2^14)
@@ -1441,7 +1443,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
             if (rc) return rc;
         }
         { Scope s(h, "k_cnn_conv_out");
-          hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, h->stream, A, L1, Lrows, Lo, W + CNN_W3, W + CNN_B3, sc); }
+          hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, h->stream, A, L1, Lrows, Lo, W + CNN_W3S, W + CNN_B3, sc); }
     }
     return 0;
 }

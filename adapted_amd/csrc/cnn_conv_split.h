@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(512, 2) k_cnn_conv64s8(const _Float16 *__restr
 #define CNS_OUT_P 128
 #define CNS_OUT_LDS (((CNS_OUT_P + 2) * CNS_ROWB + 1023) / 1024 * 1024)
 __global__ void __launch_bounds__(CNS_OUT_P) k_cnn_conv_out_s(const _Float16 *__restrict__ h, int L1, int Lrows, int Lo,
-                                                               const float *__restrict__ w /* [64][2][7] */, const float *__restrict__ b,
+                                                               const float *__restrict__ w /* [64][2][7] times 1 / CNS_ASCALE */, const float *__restrict__ b,
                                                                float *__restrict__ scores /* [n][2][Lo] */)
 {
     __shared__ __attribute__((aligned(16))) char rows_[CNS_OUT_LDS];
@@ -548,8 +548,9 @@ __global__ void __launch_bounds__(CNS_OUT_P) k_cnn_conv_out_s(const _Float16 *__
         const cnn_h8 ph_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + c8 * 16), pl_ = *reinterpret_cast<const LDS cnn_h8 *>(hr + CNS_ROWB + 128 + c8 * 16);
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float hm = cns_join(mh_[e], ml_[e]) * (1.0f / CNS_ASCALE), h0 = cns_join(zh_[e], zl_[e]) * (1.0f / CNS_ASCALE),
-                        hp = cns_join(ph_[e], pl_[e]) * (1.0f / CNS_ASCALE);
+            // (the activations carry CNS_ASCALE; its inverse sits in the weights -- w holds w3 / CNS_ASCALE: a power of two moved from one
+            // factor of every product to the other, the same real products and so the same fmaf results, three multiplies per channel fewer)
+            const float hm = cns_join(mh_[e], ml_[e]), h0 = cns_join(zh_[e], zl_[e]), hp = cns_join(ph_[e], pl_[e]);
             const float *wc = w + (c8 * 8 + e) * 2 * CNN_K;
 #pragma unroll
             for (int o = 0; o < 2; o++) {
