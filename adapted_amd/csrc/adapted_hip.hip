@@ -67,6 +67,7 @@ struct adp_handle {
     hipEvent_t ev_copy[16] = {};            // adp_copy_mark / adp_copy_wait
     hipStream_t stream2 = nullptr;          // side stream: the start-peak scan (HBM-bound) beside the float64 gains (ALU-bound)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_conv[3] = {};             // conv stack: layer 2 done (main -> side), layer 3 of an even / odd chunk done (side -> main)
     adp_cfg cfg;
     int max_reads = 0, m = 0;
     // geometry of the LLR path
@@ -287,6 +288,7 @@ int adp_destroy(adp_handle *h)
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
     for (int i = 0; i < 16; i++) if (h->ev_copy[i]) (void)hipEventDestroy(h->ev_copy[i]);
+    for (int i = 0; i < 3; i++) if (h->ev_conv[i]) (void)hipEventDestroy(h->ev_conv[i]);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1403,11 +1405,23 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     int32_t *flag = wh->op_used.as<int32_t>() + 1;
     const float *W = wh->cnn_w.as<float>();
     const _Float16 *wsp = wh->cnn_wsp.as<_Float16>();
-    _Float16 *A = h->cnn_act[0].as<_Float16>(), *B = h->cnn_act[1].as<_Float16>();
-    for (int s0 = 0; s0 < n_reads; s0 += C) {
+    _Float16 *bufs[2] = {h->cnn_act[0].as<_Float16>(), h->cnn_act[1].as<_Float16>()};
+    // The chunks' LAST layer runs on the side stream beside the NEXT chunk's first layer (round 4): layer 3 only reads split rows (4.4 TB/s),
+    // layer 0 only writes them (3.5 TB/s), neither touches the matrix cores -- together they move more bytes per second than in turn.  The
+    // two activation buffers swap roles from chunk to chunk (X: layer 0's output and layer 2's; Y: layer 1's), so layer 0 of chunk c + 1
+    // writes what layer 2 of chunk c has just finished READING while layer 3 of chunk c reads the other buffer; layer 1 of chunk c + 1 waits
+    // for that layer 3 (it overwrites its input).  ADP_CNN_OVERLAP=0: everything in turn on one stream, as before.
+    const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0 && !wh->cnn_fuse_in;
+    if (overlap && !h->ev_conv[0]) {
+        for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_conv[i], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
+    }
+    int chunk = 0;
+    bool out_pending = false; // a layer 3 on the side stream that the main stream has not waited for yet
+    for (int s0 = 0; s0 < n_reads; s0 += C, chunk++) {
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
+        _Float16 *A = bufs[overlap ? (chunk & 1) : 0], *B = bufs[overlap ? 1 - (chunk & 1) : 1];
         // ADP_CNN_FUSE_IN=1 (opt-in): layer 0 inside layer 1 (k_cnn_conv64s<NT, true>), no rows of layer 0 in HBM.  Measured per 2000
         // reads of the 200 k window: 3.69 ms against 1.33 (1.04 since its row copy has no holes) + 2.25 for the two kernels (the rows cost the single wave per SIMD ~5 us per
         // step in front of its MFMAs -- scalar weight loads, four dependent row rounds -- as much as the HBM round trip saved);
@@ -1417,6 +1431,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
             Scope s(h, "k_cnn_conv_in");
             hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag);
         }
+        if (out_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0)); out_pending = false; } // (layer 1 overwrites what that layer 3 reads)
         for (int layer = 0; layer < 2; layer++) {
             Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : (fuse_in ? "k_cnn_conv64 (layers 0 + 1)" : "k_cnn_conv64 (layer 1)"));
             const _Float16 *in = layer ? B : A; _Float16 *out = layer ? A : B;
@@ -1442,9 +1457,14 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
                              : launch_conv64s<2, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr);
             if (rc) return rc;
         }
-        { Scope s(h, "k_cnn_conv_out");
-          hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, h->stream, A, L1, Lrows, Lo, W + CNN_W3S, W + CNN_B3, sc); }
+        const bool last = s0 + C >= n_reads;
+        hipStream_t so = (overlap && !last) ? h->stream2 : h->stream; // (the last chunk's layer 3 has nothing to run beside)
+        if (so != h->stream) { HIPCHK(hipEventRecord(h->ev_conv[0], h->stream)); HIPCHK(hipStreamWaitEvent(so, h->ev_conv[0], 0)); }
+        { Scope s(h, "k_cnn_conv_out", so);
+          hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, so, A, L1, Lrows, Lo, W + CNN_W3S, W + CNN_B3, sc); }
+        if (so != h->stream) { HIPCHK(hipEventRecord(h->ev_conv[1 + (chunk & 1)], so)); out_pending = true; }
     }
+    if (out_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0));
     return 0;
 }
 

@@ -2,7 +2,8 @@
 implementation of the same reference rows -- the round-2 candidate statistics (`ADP_CAND_STATS_OLD=1`, cand_stats.h) against the
 two-sweep form (cand_stats2.h), one wave per moving-window recurrence (`ADP_SERIES_PIPE=0`) against the pipeline of waves
 (series_pipe.h), validation by a workgroup per read with LDS-staged slices (`ADP_VALIDATE_WG=1`, validate_wg.h) against the wave
-per read, the 64 -> 64 conv layers with two waves per SIMD (`ADP_CNN_WG8=1`: same scores bit for bit).  Reference rows: V1-V4
+per read, the 64 -> 64 conv layers with two waves per SIMD (`ADP_CNN_WG8=1`: same scores bit for bit), the conv stack's layers in turn on one stream (`ADP_CNN_OVERLAP=0`) against a chunk's last
+layer beside the next chunk's first.  Reference rows: V1-V4
 adapted/detect/combined.py:358-631, mvs.py:45-158; C2 adapted/detect/cnn.py:16-52."""
 import os
 
@@ -11,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8")
+SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP")
 
 
 def _with_env(env, fn):
@@ -73,7 +74,7 @@ def test_cnn_path_variants_give_the_same_rows(window, k, quantise, windows):
         for j in range(19):
             sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
     ref = None
-    for env in ({}, {"ADP_CAND_STATS_OLD": "1"}, {"ADP_SERIES_PIPE": "0"}, {"ADP_VALIDATE_WG": "1"}, {"ADP_CNN_WG8": "1"},
+    for env in ({}, {"ADP_CAND_STATS_OLD": "1"}, {"ADP_SERIES_PIPE": "0"}, {"ADP_VALIDATE_WG": "1"}, {"ADP_CNN_WG8": "1"}, {"ADP_CNN_OVERLAP": "0"},
                 {"ADP_CAND_STATS_OLD": "1", "ADP_SERIES_PIPE": "0", "ADP_VALIDATE_WG": "1", "ADP_CNN_WG8": "1"}):
         def run():
             eng = lib.Engine(spc, n, m, device=0)       # (ADP_CNN_WG8 is read when the engine is made)
