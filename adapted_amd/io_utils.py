@@ -67,11 +67,19 @@ def _lazy(fn, threadsafe: bool):
     return fn
 
 
+def _pod5_decode_in_pool() -> bool:
+    """ADAPTED_POD5_DECODE=pool: the copy pool also DECODES .pod5 records (VBZ decompression beside the row copies; the
+    records stay valid because every assembler drains its pending copies before a file's Reader closes).  Opt-in: pod5
+    does not promise that records of one Reader may be decoded from several threads, and pod5 is absent from the build
+    image, so the default keeps the decode in the thread that iterates the Reader."""
+    return os.environ.get("ADAPTED_POD5_DECODE", "reader").lower() == "pool"
+
+
 def _fetch(get):
-    """what goes to the copy pool for one read: the accessor itself when any thread may call it (.npz arrays), else the
-    signal decoded HERE, in the thread that iterates the reader (a pod5 Reader is neither promised to be thread-safe nor
-    alive once its file's iteration ends)"""
-    if getattr(get, "threadsafe", False):
+    """what goes to the copy pool for one read: the accessor itself when any thread may call it (.npz arrays; .pod5
+    records under ADAPTED_POD5_DECODE=pool), else the signal decoded HERE, in the thread that iterates the reader (a
+    pod5 Reader is neither promised to be thread-safe nor alive once its file's iteration ends)"""
+    if getattr(get, "threadsafe", False) or _pod5_decode_in_pool():
         return get
     sig = get()
     return lambda: sig

@@ -273,16 +273,20 @@ def test_minibatches_fill_caller_buffers_in_place(tmp_path):
     assert seen == n and len(handed) == 3
 
 
-def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(monkeypatch):
-    """The copy pool must never touch a pod5 record: decoding happens in the thread that iterates the Reader and before the
-    file is closed (groups that span two files, the final partial group).  A stand-in `pod5` whose records refuse any other
-    use (wrong thread, closed reader) drives all three assemblers over three files."""
+@pytest.mark.parametrize("mode", ["reader", "pool"])
+def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(monkeypatch, mode):
+    """By default the copy pool never touches a pod5 record: decoding happens in the thread that iterates the Reader and before
+    the file is closed (groups that span two files, the final partial group).  A stand-in `pod5` whose records refuse any other
+    use (wrong thread, closed reader) drives all three assemblers over three files.  ADAPTED_POD5_DECODE=pool (opt-in) hands the
+    decode to the pool: other threads, but still never after the Reader has closed."""
     import sys
     import threading
     import types
 
     from adapted_amd import io_utils
 
+    monkeypatch.setenv("ADAPTED_POD5_DECODE", mode)
+    other_threads = set()
     m, per_file = 700, 5
     rng = np.random.default_rng(3)
     store = {"f%d.pod5" % f: [(("r%d_%d" % (f, i)), rng.integers(200, 900, int(rng.integers(300, 1000))).astype(np.int16))
@@ -297,7 +301,10 @@ def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(mo
 
         def _check(self):
             assert not self._o.closed, "record used after its Reader was closed"
-            assert threading.get_ident() == self._o.thread, "record decoded outside the reader's thread"
+            if mode == "reader":
+                assert threading.get_ident() == self._o.thread, "record decoded outside the reader's thread"
+            elif threading.get_ident() != self._o.thread:
+                other_threads.add(threading.get_ident())
 
         @property
         def signal(self):
@@ -363,6 +370,7 @@ def test_pod5_records_are_decoded_in_the_reader_thread_while_the_file_is_open(mo
                 assert np.array_equal(flat[offs[j]:offs[j + 1]], want)
             k0 += k
         assert k0 == len(ids_all)
+    assert bool(other_threads) == (mode == "pool")
 
 
 def test_adapted_console_script_is_declared():
