@@ -26,6 +26,7 @@
 #include "cand_stats.h"
 #include "common.h"
 
+extern __device__ int g_ablate; // (timing experiments, ADP_ABLATE: 2^20 no finish, 2^21 no sweep B, 2^23 no sweep A; tools/experiments/cs2_ablate.sh)
 #define CS2_MAXC 16  // candidates per round (polya_cand_k beyond it: more rounds)
 #define CS2_QPC 10   // queries per candidate: 6 on the slice (median pair, two percentile pairs), 2 + 2 on the series
 #define CS2_SEGSH 27 // list entry = segment << 27 | key bits below the bin
@@ -203,6 +204,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
                     LDS uint32_t *h = (LDS uint32_t *)sh->hist + j * NB;
                     const uint32_t kl = klo[j]; const int sf = shf[j];
                     int nm = nanmin[j];
+                    if (!(g_ablate & (1 << 23)))
                     cs2_sweep<THREADS, CS2_U>(arr[j], b0, b1, tid, [&](float v, int i) {
                         if (v != v) { nm = i < nm ? i : nm; return; }
                         const uint32_t key = f2key(v);
@@ -314,6 +316,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
                     const LDS uint8_t *lut = (const LDS uint8_t *)sh->lut + j * NB;
                     const uint32_t kl = klo[j]; const int sf = shf[j];
                     const uint32_t lowmask = sf ? ((1u << sf) - 1u) : 0u;
+                    if (!(g_ablate & (1 << 21)))
                     cs2_sweep<THREADS, CS2_U>(arr[j], b0, b1, tid, [&](float v, int i) {
                         (void)i;
                         if (v != v) return;
@@ -342,7 +345,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
             const LDS uint32_t *pool = (const LDS uint32_t *)sh->hist;
             for (int qi = wv; qi < nc * CS2_QPC; qi += NW) {
                 const int k = sh->q_k[qi];
-                if (k < 0) continue;
+                if (k < 0 || (g_ablate & (1 << 20))) continue;
                 const int c = qi / CS2_QPC, t = qi % CS2_QPC, j = cs2_arr(t);
                 const int b = sh->q_bin[qi];
                 if (b < 1 || b > NB - 2 || sh->q_cnt[qi] >= (1 << 20)) continue; // (c_bad is set)
