@@ -22,15 +22,21 @@
 extern __device__ int g_ablate;
 extern __device__ unsigned long long g_dbg[ADP_NDBG]; // (debug tallies; 16-23: k_polya_peak in a -DADP_PHASE_TIMING build)
 
-struct TraceView {
-    const double *x;     // trace of one read (full-trace coordinates)
-    const double *bmax;  // per-64 block max (NaN -> +inf) or nullptr
-    const double *bmin;  // per-64 block min or nullptr
+// P: `const double *` (the trace in global memory) or `const LDS double *` (a short trace staged in LDS: every walk below is a chain
+// of dependent loads, a memory round trip each from HBM / L2)
+template <class P>
+struct TraceViewT {
+    P x;                 // trace of one read (full-trace coordinates)
+    P bmax;              // per-64 block max (NaN -> +inf) or nullptr
+    P bmin;              // per-64 block min or nullptr
     int lo, hi;          // inclusive index bounds of the array find_peaks sees
     int sanitize;        // apply np.nan_to_num(nan=0) on load
 };
+typedef TraceViewT<const double *> TraceView;
+typedef TraceViewT<const LDS double *> TraceViewL;
 
-static __device__ __forceinline__ double tv_get(const TraceView &t, int i)
+template <class TV>
+static __device__ __forceinline__ double tv_get(const TV &t, int i)
 {
     double v = t.x[i];
     if (t.sanitize) {
@@ -42,7 +48,8 @@ static __device__ __forceinline__ double tv_get(const TraceView &t, int i)
 
 // Is full-trace index i the left edge of a strict local maximum (scipy _local_maxima_1d)?
 // Returns the plateau midpoint or -1.
-static __device__ __forceinline__ int tv_peak_at(const TraceView &t, int i)
+template <class TV>
+static __device__ __forceinline__ int tv_peak_at(const TV &t, int i)
 {
     if (i <= t.lo || i >= t.hi) return -1;
     double xi = tv_get(t, i);
@@ -79,8 +86,8 @@ static __device__ __forceinline__ bool walk_hit(double v, double xp, double heig
 
 // nearest j in [limit, start], searching downwards, with walk_hit(x[j]); limit - 1 if none.  mn (WALK_PROM):
 // minimum of the samples passed, i.e. those above j.  Uniform call (all lanes, same arguments).
-template <int KIND>
-static __device__ int coop_find_down(const TraceView &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
+template <int KIND, class TV>
+static __device__ int coop_find_down(const TV &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
 {
     const int ln = lane_id();
     double lmn = xp;
@@ -118,8 +125,8 @@ static __device__ int coop_find_down(const TraceView &t, int start, int limit, d
 }
 
 // nearest j in [start, limit], searching upwards; limit + 1 if none
-template <int KIND>
-static __device__ int coop_find_up(const TraceView &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
+template <int KIND, class TV>
+static __device__ int coop_find_up(const TV &t, int start, int limit, double xp, double height, double &mn, double smin = 0.0)
 {
     const int ln = lane_id();
     double lmn = xp;
@@ -154,16 +161,25 @@ static __device__ int coop_find_up(const TraceView &t, int start, int limit, dou
     return found;
 }
 
-// the walks of tv_prominence / tv_width with a step budget: false if a walk was cut short.  Eight samples are
+// the walks of tv_prominence / tv_width with a step budget.  WALK_CHUNK samples are
 // loaded per round trip to memory (the loads do not depend on the comparisons), then examined in walk order.
-#define WALK_CHUNK 8
-static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budget, double &prom, double &lmin_out, double &rmin_out)
+#ifndef WALK_CHUNK
+#define WALK_CHUNK 4
+#endif
+// Result: PB_DONE (both walks ended: prom exact), PB_REJECT (a COMPLETED side's minimum already shows prominence < pmin: the prominence
+// is xp - max(left_min, right_min) <= xp - either minimum, in floating point too, so whatever the other side holds the test
+// pmin <= prominence fails -- the noise maxima of a rising or falling stretch, whose walk on the far side would run on to the end of
+// the trace, leave here), or PB_LEFT / PB_RIGHT bits: that side's walk was cut short by the budget (its minimum so far is not final).
+enum { PB_DONE = 0, PB_LEFT = 1, PB_RIGHT = 2, PB_REJECT = 4 };
+template <class TV>
+static __device__ int tv_prominence_budget(const TV &t, int p, int budget, double pmin, double &prom, double &lmin_out, double &rmin_out)
 {
     const double xp = tv_get(t, p);
     double left_min = xp, right_min = xp;
+    int more = 0;
     bool stopped = false;
     for (int i0 = p, steps = 0; !stopped && i0 >= t.lo; i0 -= WALK_CHUNK, steps += WALK_CHUNK) {
-        if (steps >= budget) return false;
+        if (steps >= budget) { more |= PB_LEFT; break; }
         double v[WALK_CHUNK];
 #pragma unroll
         for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 - u >= t.lo) ? tv_get(t, i0 - u) : 0.0;
@@ -175,9 +191,10 @@ static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budge
             }
         }
     }
+    if (!(more & PB_LEFT) && !(pmin <= xp - left_min)) return PB_REJECT;
     stopped = false;
     for (int i0 = p, steps = 0; !stopped && i0 <= t.hi; i0 += WALK_CHUNK, steps += WALK_CHUNK) {
-        if (steps >= budget) return false;
+        if (steps >= budget) { more |= PB_RIGHT; break; }
         double v[WALK_CHUNK];
 #pragma unroll
         for (int u = 0; u < WALK_CHUNK; u++) v[u] = (i0 + u <= t.hi) ? tv_get(t, i0 + u) : 0.0;
@@ -189,11 +206,13 @@ static __device__ bool tv_prominence_budget(const TraceView &t, int p, int budge
             }
         }
     }
+    if (!(more & PB_RIGHT) && !(pmin <= xp - right_min)) return PB_REJECT;
     prom = xp - (left_min > right_min ? left_min : right_min);
     lmin_out = left_min; rmin_out = right_min;
-    return true;
+    return more;
 }
-static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, double rel, int budget, double &width, double lmin, double rmin)
+template <class TV>
+static __device__ bool tv_width_budget(const TV &t, int p, double prom, double rel, int budget, double &width, double lmin, double rmin)
 {
     const double xp = tv_get(t, p);
     const double height = xp - prom * rel;
@@ -241,23 +260,32 @@ static __device__ bool tv_width_budget(const TraceView &t, int p, double prom, d
 
 // Per lane: does the local maximum p (or -1: none) pass prominence >= pmin and width(rel) >= wmin?
 // Uniform call.  Short walks run privately in each lane, long ones cooperatively, one peak at a time.
-#define WALK_BUDGET 48
-static __device__ bool wave_peak_ok(const TraceView &t, int p, double pmin, double wmin, double rel)
+// (round 4, with the certain-reject exit of tv_prominence_budget: budget x chunk 48 x 8 -> 8 x 4; 96 000 reads, k_adapter_peak / k_polya_peak:
+// 2.2 / 2.25 -> 1.1 / 1.57 ms at the preset's 16 k window, 2.33 / 5.65 -> 1.2 / 5.12 ms at the 200 k window; 8 x 8, 12 x 4, 16 x 8 within 5 %,
+// 0 (every walk cooperative) 1.6 / 2.16, 96 x 8 3.4 / 2.9 -- tools/ab_lib.sh)
+#ifndef WALK_BUDGET
+#define WALK_BUDGET 8
+#endif
+template <class TV>
+static __device__ bool wave_peak_ok(const TV &t, int p, double pmin, double wmin, double rel)
 {
     const int ln = lane_id();
     double prom = 0.0, lmn = 0.0, rmn = 0.0; // prominence and the minima of the two sides (the values at the bases)
     bool have = p >= 0, done = true;
-    if (have) done = tv_prominence_budget(t, p, WALK_BUDGET, prom, lmn, rmn);
-    unsigned long long todo = __ballot(have && !done);
+    int pb = PB_DONE;
+    if (have) pb = tv_prominence_budget(t, p, WALK_BUDGET, pmin, prom, lmn, rmn);
+    if (pb == PB_REJECT) have = false;
+    unsigned long long todo = __ballot(have && pb != PB_DONE);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const int pp = __shfl(p, src);
+        const int pp = __shfl(p, src), sides = __shfl(pb, src);
         const double xp = tv_get(t, pp);
-        double lmin, rmin;
-        coop_find_down<WALK_PROM>(t, pp, t.lo, xp, 0.0, lmin);
-        coop_find_up<WALK_PROM>(t, pp, t.hi, xp, 0.0, rmin);
-        if (ln == src) { prom = xp - (lmin > rmin ? lmin : rmin); lmn = lmin; rmn = rmin; }
+        double lmin = __shfl(lmn, src), rmin = __shfl(rmn, src); // (a side whose private walk ended keeps its minimum)
+        bool rej = false;
+        if (sides & PB_LEFT) { coop_find_down<WALK_PROM>(t, pp, t.lo, xp, 0.0, lmin); rej = !(pmin <= xp - lmin); } // (as PB_REJECT; uniform)
+        if (!rej && (sides & PB_RIGHT)) coop_find_up<WALK_PROM>(t, pp, t.hi, xp, 0.0, rmin);
+        if (ln == src) { if (rej) have = false; else { prom = xp - (lmin > rmin ? lmin : rmin); lmn = lmin; rmn = rmin; } }
     }
     bool cand = have && (pmin <= prom);
     double width = 0.0;
@@ -287,7 +315,8 @@ static __device__ bool wave_peak_ok(const TraceView &t, int p, double pmin, doub
 
 // First peak (lowest index) of find_peaks(x[lo..hi], prominence=pmin, width=wmin, rel_height=rel),
 // in full-trace coordinates, or -1.  Wave-cooperative: call from uniform control flow.
-static __device__ int wave_first_peak(const TraceView &t, double pmin, double wmin, double rel)
+template <class TV>
+static __device__ int wave_first_peak(const TV &t, double pmin, double wmin, double rel)
 {
     const int ln = lane_id();
     for (int base = t.lo + 1; base < t.hi; base += 64) {
@@ -301,78 +330,111 @@ static __device__ int wave_first_peak(const TraceView &t, double pmin, double wm
 }
 
 // ---------------------------------------------------------------- adapter end (P1 + P2 + P3 + A1)
+// One read by one wave: the candidate in pooled units, or -1.  g / bmx / bmn: the read's trace and block summaries, in global memory or
+// staged in LDS (P); se = T1's clip; s1 / s2 / nnan: the moments k_gains<1> left.
+template <class P>
+static __device__ int adapter_peak_read(P g, P bmx, P bmn, int n, int2 se, double s1, double s2, int nnan,
+                                        double prominence, double rel_height, int width)
+{
+    const int ln = lane_id();
+    const int cn = se.y - se.x; // clip = g[start:end]
+    if (n < 3 || cn < 3) return -1;
+    // np.nanstd(clip), clip = g[start:end]: k_gains<1> left the sum, sum of squares and NaN count of the whole
+    // trace; the few points outside the clip (all <= 0, never NaN, except possibly g[end]) are taken out here.
+    // (One-pass float64 moments instead of numpy's two passes: it only scales a threshold.)
+    double o1 = 0.0, o2 = 0.0; int onan = 0;
+    // (eight loads in flight per lane: these two sweeps cover most of the trace of a typical read)
+    for (int i0 = 0; i0 < se.x; i0 += 512) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < se.x ? g[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { o1 += v[u]; o2 += v[u] * v[u]; }
+    }
+    for (int i0 = se.y; i0 < n; i0 += 512) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < n ? g[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { if (v[u] == v[u]) { o1 += v[u]; o2 += v[u] * v[u]; } else onan++; }
+    }
+    o1 = wave_sum(o1); o2 = wave_sum(o2); onan = wave_sum(onan);
+    const int cnt = cn - (nnan - onan);
+    const double sum = s1 - o1, sq = s2 - o2;
+    const double mean = sum / (double)cnt;
+    double var = (sq - sum * mean) / (double)cnt;
+    if (var < 0.0) var = 0.0;
+    double sd = sqrt(var);
+    TraceViewT<P> tv{g, bmx, bmn, se.x, se.y - 1, 0};
+    int peak = wave_first_peak(tv, prominence * sd, (double)width, rel_height);
+    if (peak < 0) return -1;
+    // P2 correct_for_plateau(trace, peak, s=10, t=0.9, window=500)
+    {
+        const int wn = min(peak + 500, n) - peak;
+        const int nch = wn - 1;
+        const double w0 = g[peak];
+        int best = -1;
+        for (int i = ln; i <= nch - 10; i += 64) {
+            bool ok = g[peak + i + 9] > 0.9 * w0;
+            for (int j = i; ok && j < i + 9; j++) ok = (g[peak + j + 1] - g[peak + j] >= 0.0);
+            if (ok) best = i;
+        }
+        best = wave_max(best);
+        if (best >= 0) peak += best + 9;
+    }
+    // P3 correct_for_split_peak: find_peaks(window, width=10, prominence=1.0)[0]
+    {
+        const int wn = min(peak + 500, n) - peak;
+        TraceViewT<P> tw{g, nullptr, nullptr, peak, peak + wn - 1, 0};
+        int pk = wave_first_peak(tw, 1.0, 10.0, 0.5);
+        if (pk >= 0 && g[pk] >= 0.9 * g[peak]) peak = pk;
+    }
+    return peak;
+}
+
 // grid = n_reads waves.  adapter_idx[r] = candidate in pooled units, or -1.
+// Two launches share the reads by trace length (round 4): STAGED takes the reads of at most stage_cap points -- trace and block
+// summaries copied into LDS first (dynamic LDS = APK_LDS_DOUBLES(stage_cap) doubles), the walks' dependent loads then cost an LDS
+// access instead of a trip to L2 / HBM -- and the other launch (which also answers for dropped minibatches) those beyond it;
+// stage_cap = 0: no staged launch, every read here.
+#define APK_LDS_DOUBLES(cap) ((cap) + 2 * (((cap) + 63) / 64))
+template <bool STAGED>
 __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
                                                      const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                      const int2 *__restrict__ t1, int mbsize, const MbState *__restrict__ mbs,
                                                      double prominence, double rel_height, int width,
-                                                     int32_t *__restrict__ adapter_idx, const double *__restrict__ gstat)
+                                                     int32_t *__restrict__ adapter_idx, const double *__restrict__ gstat, int stage_cap)
 {
+    extern __shared__ double apk_raw[];
     const int r = blockIdx.x;
     const int ln = lane_id();
-    if (mbs[r / mbsize].status != ADP_MB_OK) { if (ln == 0) adapter_idx[r] = -1; return; }
+    if (mbs[r / mbsize].status != ADP_MB_OK) { if (!STAGED && ln == 0) adapter_idx[r] = -1; return; }
     const int n = nvalid[r];
+    if (STAGED ? n > stage_cap : n <= stage_cap) return; // the other launch's read
     int result = -1;
     if (n >= 3) {
         const double *g = trace + (size_t)r * Lp;
+        const double *bx = bmax + (size_t)r * nsum, *bn = bmin + (size_t)r * nsum;
         const int2 se = t1[r];
-        const int cn = se.y - se.x; // clip = g[start:end]
-        if (cn >= 3) {
-            // np.nanstd(clip), clip = g[start:end]: k_gains<1> left the sum, sum of squares and NaN count of the whole
-            // trace; the few points outside the clip (all <= 0, never NaN, except possibly g[end]) are taken out here.
-            // (One-pass float64 moments instead of numpy's two passes: it only scales a threshold.)
-            double s1 = gstat[3 * r], s2 = gstat[3 * r + 1];
-            int nnan = (int)gstat[3 * r + 2];
-            double o1 = 0.0, o2 = 0.0; int onan = 0;
-            // (eight loads in flight per lane: these two sweeps cover most of the trace of a typical read)
-            for (int i0 = 0; i0 < se.x; i0 += 512) {
-                double v[8];
+        const double s1 = gstat[3 * r], s2 = gstat[3 * r + 1];
+        const int nnan = (int)gstat[3 * r + 2];
+        if (STAGED) {
+            LDS double *xs = (LDS double *)apk_raw, *bxs = xs + stage_cap, *bns = bxs + (stage_cap + 63) / 64;
+            if (se.y - se.x >= 3) { // (else nothing is looked at)
+                for (int i0 = 0; i0 < n; i0 += 512) {
+                    double v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < se.x ? g[i] : 0.0; }
+                    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < n ? g[i] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 8; u++) { o1 += v[u]; o2 += v[u] * v[u]; }
-            }
-            for (int i0 = se.y; i0 < n; i0 += 512) {
-                double v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < n ? g[i] : 0.0; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) { if (v[u] == v[u]) { o1 += v[u]; o2 += v[u] * v[u]; } else onan++; }
-            }
-            o1 = wave_sum(o1); o2 = wave_sum(o2); onan = wave_sum(onan);
-            const int cnt = cn - (nnan - onan);
-            const double sum = s1 - o1, sq = s2 - o2;
-            const double mean = sum / (double)cnt;
-            double var = (sq - sum * mean) / (double)cnt;
-            if (var < 0.0) var = 0.0;
-            double sd = sqrt(var);
-            TraceView tv{g, bmax + (size_t)r * nsum, bmin + (size_t)r * nsum, se.x, se.y - 1, 0};
-            int peak = wave_first_peak(tv, prominence * sd, (double)width, rel_height);
-            if (peak >= 0) {
-                // P2 correct_for_plateau(trace, peak, s=10, t=0.9, window=500)
-                {
-                    const int wn = min(peak + 500, n) - peak;
-                    const int nch = wn - 1;
-                    const double w0 = g[peak];
-                    int best = -1;
-                    for (int i = ln; i <= nch - 10; i += 64) {
-                        bool ok = g[peak + i + 9] > 0.9 * w0;
-                        for (int j = i; ok && j < i + 9; j++) ok = (g[peak + j + 1] - g[peak + j] >= 0.0);
-                        if (ok) best = i;
-                    }
-                    best = wave_max(best);
-                    if (best >= 0) peak += best + 9;
+                    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; if (i < n) xs[i] = v[u]; }
                 }
-                // P3 correct_for_split_peak: find_peaks(window, width=10, prominence=1.0)[0]
-                {
-                    const int wn = min(peak + 500, n) - peak;
-                    TraceView tw{g, nullptr, nullptr, peak, peak + wn - 1, 0};
-                    int pk = wave_first_peak(tw, 1.0, 10.0, 0.5);
-                    if (pk >= 0 && g[pk] >= 0.9 * g[peak]) peak = pk;
-                }
-                result = peak;
+                const int nb = (n + 63) / 64 < nsum ? (n + 63) / 64 : nsum;
+                for (int b = ln; b < nb; b += 64) { bxs[b] = bx[b]; bns[b] = bn[b]; }
+                ws_sync();
             }
-        }
+            result = adapter_peak_read<const LDS double *>(xs, bxs, bns, n, se, s1, s2, nnan, prominence, rel_height, width);
+        } else
+            result = adapter_peak_read<const double *>(g, bx, bn, n, se, s1, s2, nnan, prominence, rel_height, width);
     }
     if (ln == 0) adapter_idx[r] = result;
 }

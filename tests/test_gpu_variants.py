@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP")
+SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP", "ADP_APK_STAGE")
 
 
 def _with_env(env, fn):
@@ -105,9 +105,10 @@ def test_llr_path_with_the_workgroup_validation_gives_the_same_rows(window):
         sig[9, 120 + 40 * j: 123 + 40 * j] = 260.0      # an open_pores list beyond 16 entries
     eng = lib.Engine(spc, n, m, device=0)
     a, _ = _with_env({}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
+    c, _ = _with_env({"ADP_APK_STAGE": "2048"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))  # (P1-P3 from LDS for short traces)
     b, _ = _with_env({"ADP_VALIDATE_WG": "1"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
     why = eng.debug_fetch(9, n)
     eng.close()
-    assert _canon(a, lib) == _canon(b, lib)
+    assert _canon(a, lib) == _canon(b, lib) and _canon(a, lib) == _canon(c, lib)
     assert (why == 0).sum() >= n // 2  # most reads took the workgroup kernel
     print("k_validate_wg left to k_validate:", {int(k): int(v) for k, v in zip(*np.unique(why, return_counts=True))}, "the NaN read:", int(why[5]))
