@@ -445,6 +445,9 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
 #ifndef PK_STEP
 #define PK_STEP 16 // kept maxima examined per step of step 4
 #endif
+#ifndef PK_PREFIX
+#define PK_PREFIX 224 // maxima of the first attempt (one round of step 2; 96 000 reads at the 200 k window: 5.2 ms without the prefix, 2.88 with 896, 2.50 with 448, 2.30 with 224, 2.38 with 112); ADP_ABLATE bit 2^24: the whole list at once, as before
+#endif
 #define PST_NONE 0u
 #define PST_REMOVED 1u
 #define PST_KEPT 2u
@@ -519,8 +522,20 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                 }
             }
             if (g_ablate & 256) npk = 0;
-            for (int w = ln; w < (npk + 8 + 15) / 16 + 1; w += 64) stw[w] = 0;
+            // Only the first two survivors in index order are wanted, and they lie near the front of almost every trace: steps 2-4 run
+            // on a PREFIX of the list first (the first wn maxima; the maxima behind it read as undecided, so a state that depends on
+            // them stays undecided -- whatever is decided is final: the fixed point is unique).  The answer stands when the second
+            // survivor was found among maxima in front of the first undecided one; otherwise the steps run again on the whole list.
+            int p0 = -1, p1 = -1;
+            for (int attempt = 0; attempt < 2; attempt++) {
+            const int wn = (attempt == 0 && npk > PK_PREFIX && !(g_ablate & 16777216)) ? PK_PREFIX : npk;
             __syncthreads();
+            for (int w = ln; w < (wn + 8 + 15) / 16 + 1; w += 64) stw[w] = 0;
+            __syncthreads();
+            if (ln < 4 && wn + ln < npk) { // (ordinals wn .. wn + 3: neighbours of the prefix's last maxima)
+                const uint32_t sl = (uint32_t)(wn + ln + 4);
+                __hip_atomic_fetch_or(&stw[sl >> 4], PST_UNDECIDED << ((sl & 15u) * 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             // 2. per maximum: which of the up to 8 maxima within +-9 samples have a higher priority
             //    (scipy _select_by_peak_distance, distance = 10 -> |dp| < 10; equal heights: later index first).
             //    56 maxima per step (lanes 4..59), their neighbours by shuffle.  A maximum without any is kept
@@ -528,7 +543,7 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
             int nund = 0;
             // (four steps' positions, then their four trace values, are requested together: a step is two dependent round
             // trips to memory -- the list entry, then the trace value it points at -- and a read has up to 180 steps)
-            for (int base4 = 0; base4 < npk; base4 += 56 * 4) {
+            for (int base4 = 0; base4 < wn; base4 += 56 * 4) {
                 int pp[4];
                 double vv[4];
 #pragma unroll
@@ -555,7 +570,7 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int base = base4 + 56 * u;
-                    if (base >= npk) break;
+                    if (base >= wn) break;
                     const int k = base - 4 + ln;
                     const bool valid = k >= 0 && k < npk;
                     const int p = pp[u];
@@ -575,7 +590,7 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                         const uint32_t lb = (uint32_t)__shfl_up((int)lower, j);
                         if (lb >> (j - 1) & 1u) mask |= 1u << (4 + j - 1); // k-j is within 9 and k is lower than it
                     }
-                    const bool out = valid && ln >= 4 && ln < 60;
+                    const bool out = valid && ln >= 4 && ln < 60 && k < wn;
                     if (out) {
                         const uint32_t sl = (uint32_t)(k + 4);
                         __hip_atomic_fetch_or(&stw[sl >> 4], (mask ? PST_UNDECIDED : PST_KEPT) << ((sl & 15u) * 2u), __ATOMIC_RELAXED,
@@ -631,37 +646,42 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                         __syncthreads();
                     }
                 }
+                if (w == nund) break; // (a prefix: what is left waits for maxima behind it)
                 nund = w;
             }
             __syncthreads();
-            // kept maxima, in index order, compacted in place
-            int nkept = 0;
-            for (int base4 = 0; base4 < npk; base4 += 256) { // (four loads in flight; the stores land at or below what was read)
+            // kept maxima in front of the first undecided one, in index order, into the work list's place (it is dead by now)
+            int32_t *kl = reinterpret_cast<int32_t *>(mk);
+            int nkept = 0, first_und = wn;
+            for (int base4 = 0; base4 < wn && first_und == wn; base4 += 256) { // (four loads in flight)
                 int pq[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int k = base4 + 64 * u + ln; pq[u] = (k < npk) ? pk[k] : -1; }
+                for (int u = 0; u < 4; u++) { const int k = base4 + 64 * u + ln; pq[u] = (k < wn) ? pk[k] : -1; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int k = base4 + 64 * u + ln;
-                    bool kp = false;
-                    if (k < npk) {
+                    uint32_t stt = PST_NONE;
+                    if (k < wn) {
                         const uint32_t sl = (uint32_t)(k + 4);
-                        kp = ((stw[sl >> 4] >> ((sl & 15u) * 2u)) & 3u) == PST_KEPT;
+                        stt = (stw[sl >> 4] >> ((sl & 15u) * 2u)) & 3u;
                     }
+                    const unsigned long long mu = __ballot(stt == PST_UNDECIDED);
+                    if (mu && first_und == wn) first_und = base4 + 64 * u + __ffsll((long long)mu) - 1;
+                    const bool kp = stt == PST_KEPT && k < first_und;
                     const unsigned long long m = __ballot(kp);
-                    if (kp) pk[nkept + __popcll(m & ((1ull << ln) - 1ull))] = pq[u];
+                    if (kp) kl[nkept + __popcll(m & ((1ull << ln) - 1ull))] = pq[u];
                     nkept += __popcll(m);
                 }
             }
             __syncthreads();
             // 4. survivors in index order: prominence >= 1, width(rel 0.5) >= 10; first two
             // survivors, compacted in index order (LDS state scan), then 64 candidates per step
-            int p0 = -1, p1 = -1;
+            p0 = -1; p1 = -1;
             // (16 candidates per step: the second survivor is among the first 32 kept maxima of almost every read, and
             // every candidate with a long walk costs the whole wave a cooperative scan)
             for (int base = 0; base < nkept && p1 < 0 && !(g_ablate & 1024); base += PK_STEP) {
                 int k = base + ln;
-                int i = (ln < PK_STEP && k < nkept) ? pk[k] : -1;
+                int i = (ln < PK_STEP && k < nkept) ? kl[k] : -1;
                 const bool ok = wave_peak_ok(tv, i, 1.0, 10.0, 0.5);
                 unsigned long long m = __ballot(ok);
                 while (m && p1 < 0) {
@@ -670,6 +690,8 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                     int pi = __shfl(i, f);
                     if (p0 < 0) p0 = pi; else p1 = pi;
                 }
+            }
+            if (p1 >= 0 || first_und >= npk) break; // (else: the prefix did not settle it)
             }
             // 5. spike heuristics on the UN-sanitised trace
             if (p0 >= 0 && p1 < 0) result = p0;
