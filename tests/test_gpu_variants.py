@@ -112,3 +112,41 @@ def test_llr_path_with_the_workgroup_validation_gives_the_same_rows(window):
     assert _canon(a, lib) == _canon(b, lib) and _canon(a, lib) == _canon(c, lib)
     assert (why == 0).sum() >= n // 2  # most reads took the workgroup kernel
     print("k_validate_wg left to k_validate:", {int(k): int(v) for k, v in zip(*np.unique(why, return_counts=True))}, "the NaN read:", int(why[5]))
+
+
+def test_polya_peak_on_a_prefix_of_the_maxima_equals_the_whole_list():
+    """P4 (reference adapted/detect/llr.py:406-479): k_polya_peak settles the distance rule and the survivors on the first 224 maxima and
+    takes the whole list only when that does not show the second survivor; ADP_ABLATE bit 2^24 (read when the engine is made) runs the
+    whole list at once, as before round 4.  Reads with few, one or no survivor (flat tails, short reads) take the second attempt."""
+    from adapted_amd import lib, synth
+
+    spc = _spc("llr", 200000)
+    m = spc.sig_preload_size
+    n = 128
+    lens = np.array([m if i % 3 else max(1012, synth.pareto_length(5, i, lo=1500, hi=2 * m)) for i in range(n)], dtype=np.int32)
+    sig, lens = synth.synth_batch(91, 0, n, m, lens)
+    rng = np.random.default_rng(4)
+    for r in range(0, n, 5):                             # no change point behind the adapter: no (or a late, single) survivor
+        a = int(rng.integers(8000, 20000))
+        sig[r, a:lens[r]] = (80.0 + rng.normal(0.0, 4.0, max(0, int(lens[r]) - a))).astype(np.float32)[: max(0, min(m, int(lens[r])) - a)]
+    got = []
+    for env in ({}, {"ADP_ABLATE": "16777216"}):
+        def run():
+            eng = lib.Engine(spc, n, m, device=0)
+            try:
+                rows, _ = eng.detect_llr_rows(sig, lens, n, 64, with_start_peak=True)
+                return _canon(rows, lib), rows["col"][:, lib.COLS.index("{primary}_polya_end")].copy()
+            finally:
+                eng.close()
+        old = os.environ.get("ADP_ABLATE")
+        try:
+            os.environ.pop("ADP_ABLATE", None)
+            os.environ.update(env)
+            got.append(run())
+        finally:
+            os.environ.pop("ADP_ABLATE", None)
+            if old is not None:
+                os.environ["ADP_ABLATE"] = old
+    assert got[0][0] == got[1][0]
+    pe = got[0][1]
+    assert (pe > 0).sum() >= n // 3 and (pe == 0).sum() >= 5   # both kinds of read are there
