@@ -488,9 +488,14 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     in.series = h->series.as<float>(); in.have_series = h->have_series.as<int8_t>(); in.series_cap = cap;
     in.cstat = multi ? h->cstat.as<CandStat>() : nullptr;
     if (h->cfg.mvs_detect_check && !h->cfg.mvs_detect_overwrite) {
+        // one candidate per read (the LLR path): the same pipeline of waves over the slice [adapter end, poly(A) end) where it takes the
+        // windows (round 4; the lane-per-read kernel k_mvs_series waits on 64 scattered rows per load instruction); ADP_SERIES_PIPE_LLR=0: as before
+        bool piped = false;
         if constexpr (std::is_same<SIG, SigF32>::value) {
-        if (multi) {
-            Scope s(h, "k_mvs_series_wave");
+        const bool pipe_ok = sp_takes(h->cfg.pA_var_window, h->cfg.pA_mean_window) && env_int("ADP_SERIES_PIPE", 1);
+        if (multi || (pipe_ok && kmax == 1 && env_int("ADP_SERIES_PIPE_LLR", 1))) {
+            piped = true;
+            Scope s(h, multi ? "k_mvs_series_wave" : "k_mvs_series");
             auto ring = [](int w) { int rb = 128; while (rb < w + MS_CHUNK) rb <<= 1; return rb; };
             const size_t lds = (size_t)MS_G * (ring(h->cfg.pA_var_window) + 4 + ring(h->cfg.pA_mean_window) + 4 + 4 * (MS_CHUNK + 4)) * 4; // (two out halves per wave)
             if (lds > h->lds_series_set) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->lds_series_set = lds; }
@@ -503,7 +508,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
                                h->have_series.as<int8_t>(), pa, pn, pc);
             hipLaunchKernelGGL(k_series_order, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, cap, pn, pc, pc + MS_NBKT, pp);
             // round 4: the recurrences as a pipeline of waves (series_pipe.h) for the windows it takes; ADP_SERIES_PIPE=0: one wave per recurrence
-            if (sp_takes(h->cfg.pA_var_window, h->cfg.pA_mean_window) && env_int("ADP_SERIES_PIPE", 1)) {
+            if (pipe_ok) {
                 if (!(h->attr_done & 32u)) { HIPCHK(hipFuncSetAttribute((const void *)k_mvs_series_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS_FLOATS * 4)); h->attr_done |= 32u; }
                 hipLaunchKernelGGL(k_mvs_series_pipe, dim3((n + SP_G - 1) / SP_G), dim3(SP_THREADS), SP_LDS_FLOATS * 4, h->stream, dsig.base, n, m, pa, pn, pp,
                                    h->cfg.pA_var_window, h->cfg.pA_mean_window, h->series.as<float>(), cap, h->have_series.as<int8_t>());
@@ -512,7 +517,7 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
         }
         }
-        if (!multi) {
+        if (!piped) {
             Scope s(h, "k_mvs_series");
             hipLaunchKernelGGL(k_mvs_series<SIG>, dim3((n + 63) / 64), dim3(64), 0, h->stream, dsig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
                                h->series.as<float>(), cap, h->have_series.as<int8_t>());
