@@ -97,6 +97,7 @@ struct adp_handle {
     int cnn_f_Lpad = 0, cnn_f_L1 = 0, cnn_f_chunk = 0;
     bool cnn_redo_f32 = false;
     bool cnn_wg8 = false;     // ADP_CNN_WG8=1: the 64 -> 64 layers with two waves per SIMD (k_cnn_conv64s8)
+    bool cnn_pipe = false;    // ADP_CNN_PIPE=1: the 64 -> 64 layers with a tile's epilogue under the next tile's MFMAs (k_cnn_conv64p)
     bool cnn_fuse_in = false; // ADP_CNN_FUSE_IN=1: layer 0 computed inside layer 1's kernel (measured: no gain at the 200 k window, see below)
     DevBuf cnn_wsp;          // split B fragments of layers 1 and 2
     float cnn_sw[2] = {1.f, 1.f};
@@ -267,6 +268,7 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
     { const char *cv = getenv("ADP_CNN_CONV"); if (cv && !strcmp(cv, "f32")) h->cnn_mode = 0; } // the exact-float32 conv stack (cnn_conv.h)
     { const char *cv = getenv("ADP_CNN_FUSE_IN"); h->cnn_fuse_in = cv && *cv == '1'; }
     { const char *cv = getenv("ADP_CNN_WG8"); h->cnn_wg8 = cv && *cv == '1'; }
+    { const char *cv = getenv("ADP_CNN_PIPE"); h->cnn_pipe = cv && *cv == '1'; }
     *out = h;
     return ADP_OK;
 }
@@ -1404,7 +1406,9 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
 {
     // ADP_CNN_WG8=1 (round 4): the 64 -> 64 layers by k_cnn_conv64s8 -- eight waves per workgroup, two per SIMD, tiles of 128 positions
     const bool wg8 = wh->cnn_wg8 && !wh->cnn_fuse_in; // (the fused first layer belongs to k_cnn_conv64s's tile geometry)
-    const int PB = wg8 ? CNS8_PB : 64 * NT, tiles = (L1 + PB - 1) / PB, Lrows = CNS_FRONT + tiles * PB + 4;
+    const bool pipe = wh->cnn_pipe && !wh->cnn_fuse_in && !wg8;
+    static_assert(CNP_PB == CNS8_PB, "the two 128-position kernels share the row geometry");
+    const int PB = (wg8 || pipe) ? CNS8_PB : 64 * NT, tiles = (L1 + PB - 1) / PB, Lrows = CNS_FRONT + tiles * PB + 4;
     const size_t per_read = (size_t)Lrows * CNS_ROWB;
     size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
     if (cap_reads < 1) cap_reads = 1;
@@ -1456,6 +1460,14 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
             const float *b = W + (layer ? CNN_B2 : CNN_B1);
             const float sw = wh->cnn_sw[layer];
             int rc;
+            if (pipe) {
+                if (!(h->attr_done & 131072u)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64p, hipFuncAttributeMaxDynamicSharedMemorySize, CNP_LDS)); h->attr_done |= 131072u; }
+                const long long total = (long long)n * tiles;
+                if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64p"; return ADP_ERR_UNSUPPORTED; }
+                const int grid = (int)(total < h->n_cu ? total : h->n_cu);
+                hipLaunchKernelGGL(k_cnn_conv64p, dim3(grid), dim3(256), CNP_LDS, h->stream, in, out, w, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
+                rc = 0;
+            } else
             if (wg8 && !fuse_in) {
                 if (!(h->attr_done & 65536u)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s8, hipFuncAttributeMaxDynamicSharedMemorySize, CNS8_LDS)); h->attr_done |= 65536u; }
                 const long long total = (long long)n * tiles;

@@ -38,6 +38,12 @@ typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
 #define CNS_ABL 0 // (development: 1 = no MFMAs, 2 = no epilogue stores)
 #endif
 
+template <int N, class F, int I = 0>
+static __device__ __forceinline__ void cns_static_for(F &&f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); cns_static_for<N, F, I + 1>(static_cast<F &&>(f)); }
+}
+
 #define CNS_ROW 136          // float16 per position row
 #define CNS_ROWB 272         // bytes
 #define CNS_FRONT 4          // zero rows in front of position 0
@@ -188,6 +194,10 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 #pragma unroll
     for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE); // (inputs and outputs carry CNS_ASCALE)
 
+    cnn_f32x16 bsv;
+#pragma unroll
+    for (int r = 0; r < 16; r++) bsv[r] = bs[r];
+    const cnn_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
     auto dma = [&](int tix, int b) {
         const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
@@ -271,11 +281,9 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         static_assert((NDMA + 3) / 4 <= CNS_KSTEPS, "one DMA piece per k-step and wave");
         // B fragment of k-step (t, cg), position tile j: row ph * 32 NT + 32 j + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
         const LDS char *tb = lds + buf * TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
+        // (no initialisation of the accumulators: the first k-step's MFMAs take the bias vector / zero as their C operand -- NT x 32
+        // v_accvgpr_write per tile otherwise, in front of the MFMAs of the only wave on the SIMD)
         cnn_f32x16 am[NT], ax[NT];
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { am[j][r] = bs[r]; ax[j][r] = 0.f; }
         cnn_h8 fh[2][NT], fl[2][NT];
 #pragma unroll
         for (int j = 0; j < NT; j++) {
@@ -296,14 +304,14 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             }
 #if !(CNS_ABL & 1)
 #pragma unroll
-            for (int j = 0; j < NT; j++) am[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1][j], am[j], 0, 0, 0);
+            for (int j = 0; j < NT; j++) am[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1][j], k == 0 ? bsv : am[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < NT; j++) ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], fh[k & 1][j], ax[j], 0, 0, 0);
+            for (int j = 0; j < NT; j++) ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], fh[k & 1][j], k == 0 ? zero16 : ax[j], 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < NT; j++) ax[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1][j], ax[j], 0, 0, 0);
 #else
 #pragma unroll
-            for (int j = 0; j < NT; j++) { am[j][k & 15] += (float)fh[k & 1][j][0] * (float)wh[k][0]; ax[j][k & 15] += (float)fl[k & 1][j][0] * (float)wl[k][0]; }
+            for (int j = 0; j < NT; j++) { if (k == 0) { am[j] = bsv; ax[j] = zero16; } am[j][k & 15] += (float)fh[k & 1][j][0] * (float)wh[k][0]; ax[j][k & 15] += (float)fl[k & 1][j][0] * (float)wl[k][0]; }
 #endif
             asm volatile("" ::: "memory");
         }
@@ -508,6 +516,191 @@ __global__ void __launch_bounds__(512, 2) k_cnn_conv64s8(const _Float16 *__restr
         // the DMA issued at the top of this step is older than these CNS8_NSTORE stores
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNS8_NSTORE) : "memory");
         buf ^= 1;
+    }
+    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
+    if (__any(bad) && lane == 0) atomicOr(flag, 1);
+}
+
+// ---------------------------------------------------------------- layers 1, 2 with the EPILOGUE UNDER THE NEXT TILE'S MFMAs (round 4)
+// k_cnn_conv64s runs a tile's phases in turn in its one wave per SIMD: 252 MFMAs, then ~700 vector instructions of epilogue (fold the
+// cross terms, bias, ReLU, split, staging rows), then the copy-out -- the matrix pipe rests during a third of the step.  Here the
+// accumulators are DOUBLE: while the MFMAs of tile t fill one set, the epilogue arithmetic of tile t - 1 works through the other, cut
+// into 16 pieces that sit between the MFMAs of the first 16 k-steps (a 32 x 32 x 16 MFMA occupies the matrix pipe for 32 cycles; the
+// wave issues ~4 vector instructions in its shadow).  What makes the second set fit: PB = 128 positions per step (two position
+// tiles per wave: 2 x 64 accumulator registers beside the 224 of the weights) and a staging area of its own in LDS (the consumed tile
+// is the next DMA's target now): 2 x 36 KB of tiles + 34 KB.  Same fragments, same order of accumulation, same epilogue arithmetic
+// as k_cnn_conv64s: the same rows, bit for bit (tests/test_gpu_variants.py).
+#ifndef CNP_ABL
+#define CNP_ABL 0 // (development, timing only: 1 = no epilogue pieces, 2 = no copy-out, 4 = no MFMAs, 8 = no DMA)
+#endif
+#define CNP_NT 2
+#define CNP_PB (64 * CNP_NT)
+#define CNP_R (CNP_PB + 6)
+#define CNP_TILE_B ((CNP_R * CNS_ROWB + 1023) / 1024 * 1024)
+#define CNP_NDMA (CNP_TILE_B / 1024)
+#define CNP_STG_B (CNP_PB * CNS_ROWB)
+#define CNP_LDS (2 * CNP_TILE_B + CNP_STG_B)
+#define CNP_NSTORE ((CNP_PB * 17 + 255) / 256)
+#define CNP_NEPI (8 * CNP_NT) // epilogue pieces: (position tile, register group of four, pair)
+static_assert((CNP_NDMA + 3) / 4 <= CNS_KSTEPS && CNP_NEPI <= CNS_KSTEPS, "one DMA piece and one epilogue piece per k-step");
+__global__ void __launch_bounds__(256, 1) k_cnn_conv64p(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
+                                                        const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
+                                                        float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
+                                                        int32_t *__restrict__ flag)
+{
+    constexpr int NT = CNP_NT, PB = CNP_PB;
+    extern __shared__ float cns_lds_raw[];
+    LDS char *lds = (LDS char *)cns_lds_raw;
+    LDS char *stg = lds + 2 * CNP_TILE_B;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mh = wave & 1, ph = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    cnn_h8 wh[CNS_KSTEPS], wl[CNS_KSTEPS];
+    {
+        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(wsp) + (size_t)(mh * CNS_KSTEPS) * 2 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < CNS_KSTEPS; k++) { wh[k] = wp[(size_t)(k * 2) * 64]; wl[k] = wp[(size_t)(k * 2 + 1) * 64]; }
+    }
+    float bs[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE);
+    const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
+    const int G = gridDim.x;
+    cnn_us2 hmax = {0, 0};
+    const float cx = inv_sw * (1.0f / 2048.0f);
+    cnn_f32x16 am[2][NT], ax[2][NT];
+    // this lane's staging rows (position tile j: + 32 j rows)
+    LDS char *srow0 = stg + (ph * (NT * 32) + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
+
+    // piece e of the epilogue of accumulator set S: position tile e >> 3, registers 4 g + 2 q, 4 g + 2 q + 1 (g = (e >> 1) & 3, q = e & 1)
+    auto epi = [&](auto Sc, auto Ec) {
+        constexpr int S = decltype(Sc)::value, e = decltype(Ec)::value, j = e >> 3, g = (e >> 1) & 3, q = e & 1;
+        const cnn_f2 a2 = {am[S][j][4 * g + 2 * q], am[S][j][4 * g + 2 * q + 1]}, x2 = {ax[S][j][4 * g + 2 * q], ax[S][j][4 * g + 2 * q + 1]};
+        cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
+        v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f});
+        const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
+        const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+        const cnn_h2 lo = __builtin_convertvector(rs, cnn_h2);
+        hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+        LDS char *d = srow0 + (32 * j) * CNS_ROWB + 16 * g + 4 * q;
+        *reinterpret_cast<LDS cnn_h2 *>(d) = hi;
+        *reinterpret_cast<LDS cnn_h2 *>(d + 128) = lo;
+    };
+    // the staged rows of tile (n, tile) leave as one contiguous range (rows at or beyond L1: to the read's dump row, as in k_cnn_conv64s)
+    auto copy_out = [&](int n, int tile) {
+        const int nvalid = (L1 - tile * PB < PB ? L1 - tile * PB : PB) * 17;
+        char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
+        char *obase = rbase + (size_t)(CNS_FRONT + tile * PB) * CNS_ROWB;
+        cnn_h8 piece[CNP_NSTORE];
+#pragma unroll
+        for (int c = 0; c < CNP_NSTORE; c++) {
+            const int i = c * 256 + (int)threadIdx.x;
+            piece[c] = *reinterpret_cast<const LDS cnn_h8 *>(stg + (i < PB * 17 ? i : 0) * 16);
+        }
+#pragma unroll
+        for (int c = 0; c < CNP_NSTORE; c++) {
+            const int i = c * 256 + (int)threadIdx.x;
+            char *dst = i < nvalid ? obase + (size_t)i * 16 : rbase + (i % 17) * 16;
+            *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
+        }
+    };
+    int it = blockIdx.x, buf = 0;
+    int pn = 0, ptile = 0; // the tile whose results wait in the other accumulator set
+    // one tile: MFMAs into set P; EPI: the epilogue of the tile before (set 1 - P) in pieces among them, its copy-out behind them
+    auto step = [&](auto Pc, auto EPIc) {
+        constexpr int P = decltype(Pc)::value;
+        constexpr bool EPI = decltype(EPIc)::value;
+        // every wave has waited for its own share of tile `it`, has finished reading the other buffer and the staging rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool more = it + G < total;
+        const GLB char *nsrc = nullptr;
+        if (more) {
+            const int tix = it + G, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
+            nsrc = (const GLB char *)in + ((size_t)nn * Lrows + CNS_FRONT - 3 + (size_t)tile2 * PB) * CNS_ROWB + lane * 16;
+        }
+        LDS char *ndst = lds + (buf ^ 1) * CNP_TILE_B;
+        const LDS char *tb = lds + buf * CNP_TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { am[P][j][r] = bs[r]; ax[P][j][r] = 0.f; }
+        cnn_h8 fh[2][NT], fl[2][NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            fh[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB);
+            fl[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB + 128);
+        }
+        auto kstep = [&](auto Kc) {
+            constexpr int k = decltype(Kc)::value;
+            if (!(CNP_ABL & 8) && more && wave + 4 * k < CNP_NDMA)
+                __builtin_amdgcn_global_load_lds((const GLB float *)(nsrc + (wave + 4 * k) * 1024), (LDS float *)(ndst + (wave + 4 * k) * 1024), 16, 0, 0);
+            if (k + 1 < CNS_KSTEPS) {
+                constexpr int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    fh[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32);
+                    fl[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32 + 128);
+                }
+            }
+#if !(CNP_ABL & 4)
+#pragma unroll
+            for (int j = 0; j < NT; j++) am[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1][j], am[P][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; j++) ax[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], fh[k & 1][j], ax[P][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NT; j++) ax[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1][j], ax[P][j], 0, 0, 0);
+#else
+#pragma unroll
+            for (int j = 0; j < NT; j++) { am[P][j][k & 15] += (float)fh[k & 1][j][0] * (float)wh[k][0]; ax[P][j][k & 15] += (float)fl[k & 1][j][0] * (float)wl[k][0]; }
+#endif
+            if constexpr (EPI && k < CNP_NEPI && !(CNP_ABL & 1)) epi(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, k>{});
+            asm volatile("" ::: "memory");
+        };
+        cns_static_for<CNS_KSTEPS>(kstep);
+        if constexpr (EPI) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier(); // the staging rows are complete
+            asm volatile("" ::: "memory");
+            if constexpr (!(CNP_ABL & 2)) copy_out(pn, ptile);
+            // this step's DMA pieces are older than these stores
+            if constexpr (!(CNP_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNP_NSTORE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        pn = it / tiles_per_read; ptile = it - pn * tiles_per_read;
+        buf ^= 1;
+        it += G;
+    };
+    // the last tile's epilogue, nothing beside it
+    auto finish = [&](auto Sc) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier(); // (the copy-out before has read the staging rows)
+        asm volatile("" ::: "memory");
+        cns_static_for<CNP_NEPI>([&](auto Ec) { epi(Sc, Ec); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        copy_out(pn, ptile);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    if (it < total) {
+        {   // the first tile: a burst, waited for
+            const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
+            const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * PB) * CNS_ROWB + lane * 16;
+            for (int inst = wave; inst < CNP_NDMA; inst += 4)
+                __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + inst * 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        step(I0{}, std::false_type{});
+        for (;;) {
+            if (it >= total) { finish(I0{}); break; }
+            step(I1{}, std::true_type{});
+            if (it >= total) { finish(I1{}); break; }
+            step(I0{}, std::true_type{});
+        }
     }
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && lane == 0) atomicOr(flag, 1);

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP", "ADP_APK_STAGE")
+SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP", "ADP_APK_STAGE", "ADP_CNN_PIPE")
 
 
 def _with_env(env, fn):
@@ -74,7 +74,7 @@ def test_cnn_path_variants_give_the_same_rows(window, k, quantise, windows):
         for j in range(19):
             sig[r, 120 + 40 * j: 123 + 40 * j] = 260.0
     ref = None
-    for env in ({}, {"ADP_CAND_STATS_OLD": "1"}, {"ADP_SERIES_PIPE": "0"}, {"ADP_VALIDATE_WG": "1"}, {"ADP_CNN_WG8": "1"}, {"ADP_CNN_OVERLAP": "0"},
+    for env in ({}, {"ADP_CAND_STATS_OLD": "1"}, {"ADP_SERIES_PIPE": "0"}, {"ADP_VALIDATE_WG": "1"}, {"ADP_CNN_WG8": "1"}, {"ADP_CNN_PIPE": "1"}, {"ADP_CNN_PIPE": "0"}, {"ADP_CNN_OVERLAP": "0"},
                 {"ADP_CAND_STATS_OLD": "1", "ADP_SERIES_PIPE": "0", "ADP_VALIDATE_WG": "1", "ADP_CNN_WG8": "1"}):
         def run():
             eng = lib.Engine(spc, n, m, device=0)       # (ADP_CNN_WG8 is read when the engine is made)
