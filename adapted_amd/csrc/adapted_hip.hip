@@ -181,7 +181,7 @@ static int alloc_all(adp_handle *h, int reads, bool llr)
     {
         size_t cap = (size_t)10000000000ull / ((size_t)8 * h->vstride);
         if (cap < 256) cap = 256;
-        size_t want = R < 6144 ? R : 6144;
+        size_t want = R < 1024 * VAL_WPE ? R : 1024 * VAL_WPE;
         h->vslots = (int)(want < cap ? want : cap);
     }
     bad |= h->vscratch.ensure((size_t)h->vslots * 2 * h->vstride * 4);

@@ -906,8 +906,11 @@ static __device__ void row_exception(adp_row *row, int code)
 }
 
 // persistent grid: blockIdx.x = slot, block = 64 threads
+#ifndef VAL_WPE
+#define VAL_WPE 6 // waves per SIMD of k_validate (512 / VAL_WPE vector registers each)
+#endif
 template <class SIG>
-__global__ void __launch_bounds__(64, 6) __attribute__((amdgpu_waves_per_eu(6, 6))) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
+__global__ void __launch_bounds__(64, VAL_WPE) __attribute__((amdgpu_waves_per_eu(VAL_WPE, VAL_WPE))) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
                                                  PartReq *__restrict__ preq)
 {
     __shared__ WaveScratch ws_;

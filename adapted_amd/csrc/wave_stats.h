@@ -30,8 +30,10 @@ static __device__ __forceinline__ void ws_sync()
 }
 
 struct WaveScratch {
-    uint32_t hist[256];
-    float stage[WS_STAGE_FLOATS];
+    union { // (the selections' histogram and the sums' staging rows are never in use together: 4992 bytes per wave, 32 waves per CU)
+        uint32_t hist[256];
+        float stage[WS_STAGE_FLOATS];
+    };
     float leaf[WS_LEAFBUF];
 };
 
