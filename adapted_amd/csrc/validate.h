@@ -13,6 +13,9 @@
 // therefore wave-uniform.
 #pragma once
 #include <type_traits>
+#ifndef VAL_MULTI_RANKS
+#define VAL_MULTI_RANKS 1 // k_validate: the percentile pairs (and the median beside them) of one slice by ONE multi-rank selection (wave_stats.h)
+#endif
 #include "common.h"
 #include "wave_stats.h"
 #include "llr_stream.h"
@@ -447,8 +450,11 @@ static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, lon
     else fvar = wave_np_var(x, n, ws, nullptr);
     if (wmean) fmean = nanx ? wave_nanmedian(scr_mean, n - cfg.pA_mean_window + 1, ws) : wave_median(scr_mean, n - cfg.pA_mean_window + 1, 0, 0.f, ws, sc);
     else fmean = wave_np_mean(x, n, ws);
+    if (VAL_MULTI_RANKS && n > 0) wave_median_local_range(x, n, ws, fmed, lrange); // (median and both percentiles in the passes of one selection)
+    else {
     fmed = wave_median(x, n, 0, 0.f, ws, sc);
     lrange = (n > 0) ? wave_percentile(x, n, 85.0, ws, sc) - wave_percentile(x, n, 15.0, ws, sc) : (double)__builtin_nanf("");
+    }
     }
     if (!shift_have) {
         long long r1 = a_e + cfg.median_shift_window; if (r1 > S) r1 = S;
@@ -528,9 +534,13 @@ static __device__ __noinline__ MvsLoc mvs_detect_at_loc(X sig, int S, long long 
     long long e1 = loc_ + cfg.polyA_window; if (e1 > S) e1 = S;
     long long e2 = loc_ + cfg.median_shift_window; if (e2 > S) e2 = S;
     const X y = sig + loc_;
-    const float fmed = wave_median(y, (int)(e1 - loc_), 0, 0.f, ws, sc);
+    float fmed;
+    if (VAL_MULTI_RANKS && e1 - loc_ > 0) wave_median_local_range(y, (int)(e1 - loc_), ws, fmed, o.lrange);
+    else {
+        fmed = wave_median(y, (int)(e1 - loc_), 0, 0.f, ws, sc);
+        o.lrange = wave_percentile(y, (int)(e1 - loc_), 85.0, ws, sc) - wave_percentile(y, (int)(e1 - loc_), 15.0, ws, sc);
+    }
     o.med = (double)fmed;
-    o.lrange = wave_percentile(y, (int)(e1 - loc_), 85.0, ws, sc) - wave_percentile(y, (int)(e1 - loc_), 15.0, ws, sc);
     const float before = (loc_ == loc) ? med_before_loc : wave_median(sig, (int)loc_, 0, 0.f, ws, sc);
     o.shift = (double)(wave_median(y, (int)(e2 - loc_), 0, 0.f, ws, sc) - before);
     o.ok = idx > 0 && in_range_d(o.med, cfg.polyA_med_range[0], cfg.polyA_med_range[1]) &&
@@ -1024,7 +1034,8 @@ __global__ void __launch_bounds__(64, VAL_WPE) __attribute__((amdgpu_waves_per_e
                 if (in_range_d((double)ms, cfg.mean_start_range[0], cfg.mean_start_range[1]) &&
                     in_range_d((double)me, cfg.mean_end_range[0], cfg.mean_end_range[1])) {
                     int k = n < cfg.max_obs_local_range ? n : cfg.max_obs_local_range;
-                    double lr = wave_percentile(x + n - k, k, 85.0, ws, sc) - wave_percentile(x + n - k, k, 15.0, ws, sc);
+                    double lr = VAL_MULTI_RANKS ? wave_local_range(x + n - k, k, ws)
+                                                : wave_percentile(x + n - k, k, 85.0, ws, sc) - wave_percentile(x + n - k, k, 15.0, ws, sc);
                     rw.set(ADP_C_REAL_LOCAL_RANGE, lr);
                     ok = in_range_d(lr, cfg.local_range[0], cfg.local_range[1]);
                 }

@@ -158,6 +158,124 @@ static __device__ __forceinline__ void wave_select2_impl(P x, int n, int k, int 
         if (have) vkm1 = key2f(mn + d0);
     }
 }
+// The same radix select for NR ranks of ONE array at once (round 4): the key-range pass is shared, and every later pass histograms
+// the elements under each rank's prefix into that rank's own 256 bins (NR <= 4 histograms fit the scratch's staging rows) -- the two
+// percentiles of a slice, or its median and both percentiles, cost the passes of one selection instead of two or three.
+// k[] in any order; vk[r] = x_(k[r]), vkm1[r] = x_(k[r] - 1) as wave_select2_impl returns them (same keys, same rules).
+template <class P, int NR>
+static __device__ __noinline__ void wave_select_ranks(P x, int n, const int (&k)[NR], int mode, float c, LDS WaveScratch *ws,
+                                                      float (&vk)[NR], float (&vkm1)[NR])
+{
+    static_assert(NR >= 2 && NR * 256 <= WS_STAGE_FLOATS, "the histograms live in the staging rows");
+    const int ln = lane_id();
+    constexpr int UN = 8;
+    LDS uint32_t *hist = (LDS uint32_t *)ws->stage;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    bool has_nan = false;
+    for (int base = 0; base < n; base += 64 * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) { int i = base + u * 64 + ln; v[u] = ld_or_first(x, i, i < n); }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const float xf = ws_xform(v[u], mode, c);
+            has_nan |= xf != xf;
+            uint32_t key = f2key(xf); mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+        }
+    }
+    if (__any(has_nan)) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) { vk[r] = __builtin_nanf(""); vkm1[r] = vk[r]; }
+        return;
+    }
+    mn = wave_min(mn); mx = wave_max(mx);
+    const uint32_t span = mx - mn;
+    int rb = span ? 32 - __clz(span) : 0;
+    uint32_t prefix[NR], krem[NR], below[NR];
+    int lowbin[NR], lastw = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) { prefix[r] = 0; krem[r] = (uint32_t)k[r]; below[r] = 0; lowbin[r] = -1; }
+    while (rb > 0) {
+        const int w = rb < 8 ? rb : 8;
+        const int shift = rb - w;
+        for (int i = ln; i < 256 * NR; i += 64) hist[i] = 0;
+        ws_sync();
+        for (int base = 0; base < n; base += 64 * UN) {
+            float v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; u++) { int i = base + u * 64 + ln; v[u] = ld_if(x, i, i < n); }
+#pragma unroll
+            for (int u = 0; u < UN; u++) {
+                const int i = base + u * 64 + ln;
+                const float xf = ws_xform(v[u], mode, c);
+                const uint32_t d = f2key(xf) - mn;
+                const uint32_t top = (rb >= 32) ? 0u : (d >> rb);
+                const uint32_t dig = (d >> shift) & ((1u << w) - 1u);
+                if (i < n) {
+#pragma unroll
+                    for (int r = 0; r < NR; r++) {
+                        if (top == prefix[r]) __hip_atomic_fetch_add(&hist[256 * r + dig], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else if (shift == 0 && top < prefix[r] && d + 1u > below[r]) below[r] = d + 1u;
+                    }
+                }
+            }
+        }
+        ws_sync();
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const LDS uint32_t *h = hist + 256 * r + 4 * ln;
+            const uint32_t h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+            const int s = (int)(h0 + h1 + h2 + h3);
+            const int incl = wave_scan_incl(s);
+            const int excl = incl - s;
+            const bool mine = (int)krem[r] >= excl && (int)krem[r] < incl;
+            int bin = 0, before = 0;
+            if (mine) {
+                int cacc = excl;
+                if ((int)krem[r] < cacc + (int)h0) { bin = 4 * ln; before = cacc; }
+                else { cacc += h0;
+                    if ((int)krem[r] < cacc + (int)h1) { bin = 4 * ln + 1; before = cacc; }
+                    else { cacc += h1;
+                        if ((int)krem[r] < cacc + (int)h2) { bin = 4 * ln + 2; before = cacc; }
+                        else { cacc += h2; bin = 4 * ln + 3; before = cacc; } } }
+            }
+            const unsigned long long mm = __ballot(mine);
+            const int src = __ffsll((long long)mm) - 1;
+            bin = __shfl(bin, src);
+            before = __shfl(before, src);
+            if (shift == 0) {
+                int cand = -1;
+                if (4 * ln < bin && h0) cand = 4 * ln;
+                if (4 * ln + 1 < bin && h1) cand = 4 * ln + 1;
+                if (4 * ln + 2 < bin && h2) cand = 4 * ln + 2;
+                if (4 * ln + 3 < bin && h3) cand = 4 * ln + 3;
+                lowbin[r] = wave_max(cand);
+            }
+            prefix[r] = (prefix[r] << w) | (uint32_t)bin;
+            krem[r] -= (uint32_t)before;
+        }
+        if (shift == 0) lastw = w;
+        rb = shift;
+        ws_sync();
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        vk[r] = key2f(mn + prefix[r]);
+        vkm1[r] = vk[r];
+        if (krem[r] == 0 && k[r] > 0) {
+            const uint32_t bl = wave_max(below[r]);
+            uint32_t d0 = bl ? bl - 1u : 0u;
+            bool have = bl != 0;
+            if (span && lowbin[r] >= 0) {
+                uint32_t da = (prefix[r] & ~((1u << lastw) - 1u)) | (uint32_t)lowbin[r];
+                if (!have || da > d0) d0 = da;
+                have = true;
+            }
+            if (have) vkm1[r] = key2f(mn + d0);
+        }
+    }
+}
+
 // x: a signal row (RowF32 / RowI16, common.h) or a plain float array in global memory
 template <class X>
 static __device__ __noinline__ void wave_select2_global(X x, int n, int k, int mode, float c,
@@ -247,6 +365,52 @@ static __device__ __forceinline__ double wave_percentile(X x, int n, double q100
 {
     const auto r = as_row(x);
     return wave_percentile_t<decltype(as_row(x))>(r, n, q100, ws, sc);
+}
+
+// np.percentile's rank arithmetic (wave_percentile_t's), apart from the selection
+static __device__ __forceinline__ void ws_pct_ranks(int n, double q100, int &lo, int &hi, double &g)
+{
+    const double vi = (double)(n - 1) * (q100 / 100.0);
+    lo = (int)floor(vi);
+    if (lo < 0) lo = 0;
+    if (lo > n - 1) lo = n - 1;
+    hi = min(lo + 1, n - 1);
+    g = vi - (double)lo;
+}
+static __device__ __forceinline__ double ws_pct_value(float vk, float vkm1, int lo, int hi, double g)
+{
+    const float a = (hi == lo) ? vk : vkm1, b = vk;
+    const float diff = b - a;
+    double r = (double)a + (double)diff * g;
+    if (g >= 0.5) r = (double)b - (double)diff * (1.0 - g);
+    return r;
+}
+// np.percentile(x, 85) - np.percentile(x, 15) of a NaN-free slice (n >= 1): one multi-rank selection
+template <class X>
+static __device__ double wave_local_range(X x0, int n, LDS WaveScratch *ws)
+{
+    const auto x = as_row(x0);
+    int lo85, hi85, lo15, hi15; double g85, g15;
+    ws_pct_ranks(n, 85.0, lo85, hi85, g85);
+    ws_pct_ranks(n, 15.0, lo15, hi15, g15);
+    const int k[2] = {hi85, hi15};
+    float vk[2], vkm1[2];
+    wave_select_ranks<decltype(as_row(x0)), 2>(x, n, k, 0, 0.0f, ws, vk, vkm1);
+    return ws_pct_value(vk[0], vkm1[0], lo85, hi85, g85) - ws_pct_value(vk[1], vkm1[1], lo15, hi15, g15);
+}
+// np.median(x) and the same local range: three ranks of one slice
+template <class X>
+static __device__ void wave_median_local_range(X x0, int n, LDS WaveScratch *ws, float &med, double &lrange)
+{
+    const auto x = as_row(x0);
+    int lo85, hi85, lo15, hi15; double g85, g15;
+    ws_pct_ranks(n, 85.0, lo85, hi85, g85);
+    ws_pct_ranks(n, 15.0, lo15, hi15, g15);
+    const int k[3] = {n / 2, hi85, hi15};
+    float vk[3], vkm1[3];
+    wave_select_ranks<decltype(as_row(x0)), 3>(x, n, k, 0, 0.0f, ws, vk, vkm1);
+    med = (n & 1) ? vk[0] : (vkm1[0] + vk[0]) / 2.0f;
+    lrange = ws_pct_value(vk[1], vkm1[1], lo85, hi85, g85) - ws_pct_value(vk[2], vkm1[2], lo15, hi15, g15);
 }
 
 // ---------------------------------------------------------------- numpy-ordered sums
