@@ -402,7 +402,8 @@ struct MvsOut { int ok, vec_fail, exc; double mean, var, med, lrange, shift; };
 template <class X>
 static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, long long p_e, const adp_cfg &cfg, double pr0,
                                    double pr1, LDS WaveScratch *ws, float *scr_mean, float *scr_var, LDS SegCache *sc,
-                                   const float *pre_mean, const float *pre_var, const CandStat *cst, float &shift_val, bool &shift_have)
+                                   const float *pre_mean, const float *pre_var, const CandStat *cst, float &shift_val, bool &shift_have,
+                                   bool series_clean = false)
 {
     MvsOut o; o.ok = 0; o.vec_fail = 31; o.exc = 0; o.mean = o.var = o.med = o.lrange = o.shift = 0.0;
     if (p_e == 0 || a_e == 0 || p_e < a_e || p_e - a_e <= 2) return o;
@@ -421,7 +422,8 @@ static __device__ __noinline__ MvsOut mvs_check(X sig, int S, long long a_e, lon
     } else {
     // the two sequential recurrences run side by side in lanes 0 and 1
     __syncthreads();
-    const bool nanx = wave_has_nan(x, n);
+    // (series prepared by the series kernels exist only for slices without a NaN: a NaN stays in the recurrences to their end and withdraws them)
+    const bool nanx = (pre_mean && series_clean) ? false : wave_has_nan(x, n);
     if (nanx) {
         if constexpr (!std::is_same<X, RowI16>::value) {
             if (lane_id() == 0 && wvar) bn_move_var_nan(x, n, cfg.pA_var_window, scr_var);
@@ -1098,7 +1100,7 @@ __global__ void __launch_bounds__(64, VAL_WPE) __attribute__((amdgpu_waves_per_e
                     const float *pm = !pre ? nullptr : (own_mean ? own_mean : in.series + (size_t)r * 2 * in.series_cap);
                     const float *pv = !pre ? nullptr : (own_var ? own_var : in.series + (size_t)r * 2 * in.series_cap + in.series_cap);
                     MvsOut o = mvs_check(sig, S, a_e, p_e, cfg, pr0, pr1, ws, scr_mean, scr_var, sc, pm, pv,
-                                         in.cstat ? in.cstat + (size_t)r * in.kmax + c : nullptr, shift_val, shift_have);
+                                         in.cstat ? in.cstat + (size_t)r * in.kmax + c : nullptr, shift_val, shift_have, pre && !own_mean);
                     if (o.exc) { row_exception(row, o.exc); exception = true; break; }
                     rw.set(ADP_C_MVS_MEAN, o.mean); rw.set(ADP_C_MVS_VAR, o.var);
                     rw.set(ADP_C_MVS_POLYA_MED, o.med); rw.set(ADP_C_MVS_LOCAL_RANGE, o.lrange);
