@@ -262,7 +262,7 @@ static __device__ bool tv_width_budget(const TV &t, int p, double prom, double r
 // Uniform call.  Short walks run privately in each lane, long ones cooperatively, one peak at a time.
 // (round 4, with the certain-reject exit of tv_prominence_budget: budget x chunk 48 x 8 -> 8 x 4; 96 000 reads, k_adapter_peak / k_polya_peak:
 // 2.2 / 2.25 -> 1.1 / 1.57 ms at the preset's 16 k window, 2.33 / 5.65 -> 1.2 / 5.12 ms at the 200 k window; 8 x 8, 12 x 4, 16 x 8 within 5 %,
-// 0 (every walk cooperative) 1.6 / 2.16, 96 x 8 3.4 / 2.9 -- tools/ab_lib.sh)
+// 0 (every walk cooperative) 1.6 / 2.16, 96 x 8 3.4 / 2.9 -- tools/ab_libs.sh)
 #ifndef WALK_BUDGET
 #define WALK_BUDGET 8
 #endif
