@@ -269,26 +269,37 @@ static __device__ void ct_chain(const CtView &V, int r0, int r1, int k, int32_t 
         if (!__any(progress)) break; // (cannot happen: "counts as higher" is a strict total order)
     }
     // 4. per read of the chain: the kept maxima whose position lies in its row; k rounds of arg-max (height descending,
-    //    index ascending: np.lexsort((-heights, read_idx)) is stable)
+    //    index ascending: np.lexsort((-heights, read_idx)) is stable).  The kept maxima are first packed to the front of the two
+    //    lists (in place, in index order: a third to a half of the maxima survive the distance rule, and every round walks them).
+    int nk_all = 0;
+    for (int base = 0; base < npk; base += 64) {
+        const int q = base + ln;
+        bool kp = false; int pp = 0; float vv = 0.f;
+        if (q < npk) { const uint32_t sl = (uint32_t)(q + 2); pp = pk[q]; vv = pv[q]; kp = ((ct_ld<SP>(&stw[sl >> 4]) >> ((sl & 15u) * 2u)) & 3u) == 2u; }
+        const unsigned long long m = __ballot(kp);
+        if (kp) { const int at = nk_all + __popcll(m & ((1ull << ln) - 1ull)); pk[at] = pp; pv[at] = vv; } // (at <= q: behind what has been read)
+        nk_all += __popcll(m);
+    }
+    __threadfence_block();
+    __syncthreads();
     for (int rr = r0; rr <= r1; rr++) {
         const long long glo = (long long)rr * Lo, ghi = glo + Lo;
         int nkept = 0;
-        for (int base = 0; base < npk; base += 64) {
+        for (int base = 0; base < nk_all; base += 64) {
             const int q = base + ln;
             bool kp = false;
-            if (q < npk) { const uint32_t sl = (uint32_t)(q + 2); const int pp = pk[q]; kp = pp >= glo && pp < ghi && ((ct_ld<SP>(&stw[sl >> 4]) >> ((sl & 15u) * 2u)) & 3u) == 2u; }
+            if (q < nk_all) { const int pp = pk[q]; kp = pp >= glo && pp < ghi; }
             nkept += __popcll(__ballot(kp));
         }
         const int rounds = nkept < k ? nkept : k;
         float lim_v = __builtin_inff(); int lim_i = -1; // the previous pick: later picks come after it in (height desc, index asc)
         for (int t = 0; t < rounds; t++) {
             float bv = -__builtin_inff(); int bi = 0x7fffffff;
-            for (int base = 0; base < npk; base += 64) {
+            for (int base = 0; base < nk_all; base += 64) {
                 const int q = base + ln;
-                if (q < npk) {
-                    const uint32_t sl = (uint32_t)(q + 2);
+                if (q < nk_all) {
                     const int i = pk[q];
-                    if (i >= glo && i < ghi && ((ct_ld<SP>(&stw[sl >> 4]) >> ((sl & 15u) * 2u)) & 3u) == 2u) {
+                    if (i >= glo && i < ghi) {
                         const float v = pv[q];
                         const bool after = (v < lim_v) || (v == lim_v && i > lim_i);
                         if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
