@@ -609,8 +609,11 @@ static int launch_n1(adp_handle *h, SIG dsig, int n, int m, int T, int minibatch
         uint32_t *hvy = h->n1heavy.as<uint32_t>();
         HIPCHK(hipMemsetAsync(hvy, 0, (size_t)n_mb * N1H_WORDS * 4, st));
         { Scope s(h, !profile ? nullptr : "k_n1 sample passes");
+        // the first level of a statistic's sample only picks the 2^21-key window the second level works in: an eighth of the sampled
+        // rows does (ADP_N1_S0: 1 = every sampled row, as before); the second level, whose counts place the bracket, keeps them all
+        const int s0 = (col_div > 1 && minibatch >= 64) ? env_int("ADP_N1_S0", 8) : 1;
         for (int mode = 0; mode < 2; mode++) {
-            hipLaunchKernelGGL((k_n1_hist<0, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
+            hipLaunchKernelGGL((k_n1_hist<0, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step * (s0 > 1 ? s0 : 1), N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<0, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
             hipLaunchKernelGGL((k_n1_hist<1, SIG>), sg, dim3(N1_THREADS), 0, st, dsig, n, m, T, minibatch, mode, mbs, gh, gb, gc, row_step, N1_ALWAYS, cb, 0, col_div, pdiv, tails);
             hipLaunchKernelGGL((k_n1_pick<1, N1_SAMPLE>), pg, dim3(256), 0, st, mbs, gh, gb, gc, mode, thr);
