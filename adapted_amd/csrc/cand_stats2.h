@@ -30,6 +30,9 @@ extern __device__ int g_ablate; // (timing experiments, ADP_ABLATE: 2^20 no fini
 #define CS2_MAXC 16  // candidates per round (polya_cand_k beyond it: more rounds)
 #define CS2_QPC 10   // queries per candidate: 6 on the slice (median pair, two percentile pairs), 2 + 2 on the series
 #define CS2_SEGSH 27 // list entry = segment << 27 | key bits below the bin
+#ifndef CS2_TPQ
+#define CS2_TPQ 96   // lists up to this length are finished by one thread per query
+#endif
 
 template <int HB>
 struct Cs2Sh {
@@ -340,7 +343,47 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
             }
         }
         __syncthreads();
-        // ---- finish: a wave per query
+        // ---- finish, short lists: a THREAD per query (round 4: at the default window a bin holds a few dozen elements, and the wave-per-query
+        // loop below -- a ballot per bit and 64 entries, 25 queries in turn per wave -- was a third of the kernel); the query is done when its
+        // rank comes back as -1
+        if (THREADS <= 256 && !(g_ablate & (1 << 20))) { // (the small shape: at the 200 k window the lists are long and this phase only adds to the wave loop: 15.0 -> 15.7 ms)
+            const LDS uint32_t *pool = (const LDS uint32_t *)sh->hist;
+            for (int qi = tid; qi < nc * CS2_QPC; qi += THREADS) {
+                const int k = sh->q_k[qi];
+                if (k < 0) continue;
+                const int c = qi / CS2_QPC, t = qi % CS2_QPC, j = cs2_arr(t);
+                const int b = sh->q_bin[qi];
+                if (b < 1 || b > NB - 2 || sh->q_cnt[qi] >= (1 << 20)) continue; // (the wave loop's business: c_bad is set there)
+                const int sl = sh->lut[j * NB + b];
+                if (sl == 0xff) continue;
+                const uint32_t smn = sh->s_min[sl], smx = sh->s_max[sl];
+                uint32_t low;
+                if (smn == smx) low = smn;
+                else {
+                    const int total = sh->s_total[sl];
+                    if (!sh->s_ok[sl] || total > CS2_TPQ) continue;
+                    const int Sq = sh->c_seg[c], krem = k - sh->q_before[qi];
+                    const LDS uint32_t *list = pool + sh->s_off[sl];
+                    uint32_t pre = 0;
+                    for (int bit = shf[j] - 1; bit >= 0; bit--) {
+                        const uint32_t trial = pre | (1u << bit);
+                        int cnt = 0;
+                        for (int i = 0; i < total; i++) {
+                            const uint32_t e = list[i];
+                            cnt += ((int)(e >> CS2_SEGSH) <= Sq && (e & ((1u << CS2_SEGSH) - 1u)) < trial) ? 1 : 0;
+                        }
+                        if (cnt <= krem) pre = trial;
+                    }
+                    low = pre;
+                }
+                const uint32_t key = klo[j] + ((uint32_t)b << shf[j]) + low;
+                const int len = sh->c_n[c] - sh->wlen[j];
+                sh->q_val[qi] = (len > sh->nan_first[j]) ? __builtin_nanf("") : key2f(key);
+                sh->q_k[qi] = -1;
+            }
+        }
+        __syncthreads();
+        // ---- finish: a wave per query (the long lists)
         {
             const LDS uint32_t *pool = (const LDS uint32_t *)sh->hist;
             for (int qi = wv; qi < nc * CS2_QPC; qi += NW) {
