@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP", "ADP_APK_STAGE", "ADP_CNN_PIPE")
+SWITCHES = ("ADP_CAND_STATS_OLD", "ADP_SERIES_PIPE", "ADP_VALIDATE_WG", "ADP_CNN_WG8", "ADP_CNN_OVERLAP", "ADP_APK_STAGE", "ADP_CNN_PIPE", "ADP_N1_S0", "ADP_SERIES_PIPE_LLR")
 
 
 def _with_env(env, fn):
@@ -106,6 +106,8 @@ def test_llr_path_with_the_workgroup_validation_gives_the_same_rows(window):
     eng = lib.Engine(spc, n, m, device=0)
     a, _ = _with_env({}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
     c, _ = _with_env({"ADP_APK_STAGE": "2048"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))  # (P1-P3 from LDS for short traces)
+    d, _ = _with_env({"ADP_N1_S0": "1", "ADP_SERIES_PIPE_LLR": "0"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))  # (every sampled row in N1's first level; the lane-per-read series kernel)
+    assert _canon(a, lib) == _canon(d, lib)
     b, _ = _with_env({"ADP_VALIDATE_WG": "1"}, lambda: eng.detect_llr_rows(sig, lens, n, 48, with_start_peak=True))
     why = eng.debug_fetch(9, n)
     eng.close()
