@@ -565,7 +565,9 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
     { Scope s(h, "k_partition_stats");
-      hipLaunchKernelGGL(k_partition_stats<SIG>, dim3(n), dim3(BS_THREADS), 0, h->stream, dsig, m, h->preq.as<PartReq>(),
+      // (the kernel is a template on the workgroup size: 512 threads x 2 and 1024 x 1 per CU, and the second pass walking a segment from its
+      // end, were measured and dropped in round 5 -- 28.2 / 38.5 against 24.5 ms; +-1 %: profiles/r05_tried_and_dropped.txt)
+      hipLaunchKernelGGL((k_partition_stats<SIG, BS_THREADS, 5>), dim3(n), dim3(BS_THREADS), sizeof(BlockScratch), h->stream, dsig, m, h->preq.as<PartReq>(),
                          h->rows.as<adp_row>()); }
     return 0;
 }

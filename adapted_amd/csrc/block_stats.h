@@ -44,15 +44,22 @@ extern __device__ unsigned long long g_dbg[ADP_NDBG]; // debug tallies (adp_debu
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-struct BlockScratch {
+// NT_: threads of the workgroup (NW waves, each with eight staging rows); INL_: the selections and bucket searches are inlined
+// into the caller (block_stats_res.h: nothing may be called while a read's resident slabs sit in registers)
+// STAGE_: floats of the staging area (eight rows per wave for the staged slabs; block_stats_res.h stages nothing and keeps only what
+// the bucket search and the selections use as scratch)
+template <int NT_, bool INL_ = false, int STAGE_ = (NT_ / 64) * 8 * BS_LEAF_STRIDE>
+struct BlockScratchT {
+    static constexpr int NT = NT_, NW = NT_ / 64, STAGE = STAGE_;
+    static constexpr bool INLINE = INL_;
     union {
-        float stage[32 * BS_LEAF_STRIDE];
+        float stage[STAGE_];
         WaveScratch ws; // generic wave-level fallbacks reuse the staging area
     } u;
     uint32_t hist[BS_BINS + 4]; // pass A: below-window cell, BS_BINS bins, above-window cell (bs_bins); pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
     float chunk_sum[BS_MAXCHUNK]; // sums of the whole numpy chunks of the segment under way
     float tleaf[128]; // leaf sums of a ragged chunk, by tree slot
-    int scan[8];
+    int scan[2 * NW];
     int bin, before, ncollect, nmad, flag;
     uint32_t below, cntb;
     uint32_t kmin, kmax; // smallest / largest key copied out of the median's bucket (equal: the bucket holds ONE value)
@@ -61,12 +68,26 @@ struct BlockScratch {
     short leaf_off[132], leaf_len[132], leaf_slot[132]; // numpy's pairwise leaves of a ragged (< 8192) chunk, and their tree slots
     unsigned char slot_used[128];
 };
+typedef BlockScratchT<BS_THREADS> BlockScratch;
+
+// The thread's index inside a helper.  For the scratch types whose helpers are inlined into ONE long persistent loop (block_stats_res.h)
+// it passes through an empty volatile asm: the compiler would otherwise hoist every address and constant a helper derives from the
+// index out of that loop and hold them in registers for the whole kernel (65 of 256 there), beside the resident slabs
+template <class BS>
+static __device__ __forceinline__ int bs_tid()
+{
+    int t = threadIdx.x;
+    if constexpr (BS::INLINE) asm volatile("" : "+v"(t));
+    return t;
+}
 
 // samples of the median's bucket: behind the MAD bracket's in the histogram's storage (BS_MADCAP + BS_MEDCAP <= BS_BINS)
-static __device__ __forceinline__ LDS float *bs_collect(LDS BlockScratch *bs) { return (LDS float *)bs->hist + BS_MADCAP; }
+template <class BS>
+static __device__ __forceinline__ LDS float *bs_collect(LDS BS *bs) { return (LDS float *)bs->hist + BS_MADCAP; }
 // pass A's histogram: hist[0] counts the samples in buckets BELOW the window, hist[1 .. BS_BINS] are the window's bins, hist[BS_BINS + 1]
 // counts those above -- so that a sample's cell is ONE signed clamp of (bucket - window start) to [-1, BS_BINS] (v_med3_i32) plus 1
-static __device__ __forceinline__ LDS uint32_t *bs_bins(LDS BlockScratch *bs) { return bs->hist + 1; }
+template <class BS>
+static __device__ __forceinline__ LDS uint32_t *bs_bins(LDS BS *bs) { return bs->hist + 1; }
 static __device__ __forceinline__ int bs_cell(float v, uint32_t wlo)
 {
     const int d = (int)((f2key(v) >> BS_KSH) - wlo); // (20-bit buckets: the difference fits an int; negative below the window)
@@ -86,9 +107,10 @@ static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
 // (MSB first); a node that is already a leaf stays on the all-zero continuation of its path, so after 7 steps the
 // occupied slots, in slot order, are the leaves in numpy's left-to-right order.  The table is kept per tail
 // length: the two passes over a segment (and equal tails of later segments) reuse it.
-static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BlockScratch *bs)
+template <class BS>
+static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BS *bs)
 {
-    const int tid = threadIdx.x;
+    const int tid = bs_tid<BS>();
     if (bs->tail_cached == tail) return; // (uniform: written by one thread behind a barrier)
     __syncthreads();
     int off = 0, len = tail;
@@ -108,7 +130,7 @@ static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BlockScratch
     if (tid == 0) bs->scan[0] = __popcll(m);
     __syncthreads();
     if (tid < 128) {
-        const int idx = (tid >= 64 ? bs->scan[0] : 0) + __popcll(m & ((1ull << (tid & 63)) - 1ull));
+        const int idx = (tid >= 64 ? bs->scan[0] : 0) + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (occupied) { bs->leaf_off[idx] = (short)off; bs->leaf_len[idx] = (short)len; bs->leaf_slot[idx] = (short)tid; }
         bs->tleaf[tid] = 0.0f;
         bs->slot_used[tid] = occupied ? 1 : 0;
@@ -120,9 +142,10 @@ static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BlockScratch
 
 // sum of the tree from the leaf sums stored by slot (bs->tleaf, bs->slot_used): seven levels bottom-up; an empty
 // right sibling means the left one is carried up unchanged.  Wave 0 works; lane 0 returns the root.
-static __device__ __forceinline__ float bs_tail_tree(LDS BlockScratch *bs)
+template <class BS>
+static __device__ __forceinline__ float bs_tail_tree(LDS BS *bs)
 {
-    const int ln = threadIdx.x; // (< 64)
+    const int ln = bs_tid<BS>(); // (< 64)
     float v0 = bs->tleaf[2 * ln], v1 = bs->tleaf[2 * ln + 1];
     bool u0 = bs->slot_used[2 * ln] != 0, u1 = bs->slot_used[2 * ln + 1] != 0;
     float v = u1 ? v0 + v1 : v0; // level 6 (64 nodes, one per lane)
@@ -144,8 +167,8 @@ struct SideParam { uint32_t key; float c, P, Q, hw; int do_mad; }; // hw: |v - c
 //   SIDE_HIST:    20-bit bucket histogram inside the window starting at p.key; aux counts samples below it
 //   SIDE_COLLECT: copy the samples of bucket p.key to LDS; with p.do_mad also classify by dt = |v - p.c|:
 //                 dt < P -> aux2++, P <= dt <= Q -> copy to the bracket buffer
-template <int SIDE>
-static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BlockScratch *bs, uint32_t &aux, uint32_t &aux2)
+template <int SIDE, class BS>
+static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS BS *bs, uint32_t &aux, uint32_t &aux2)
 {
     if (SIDE == SIDE_HIST) {
         __hip_atomic_fetch_add(&bs_bins(bs)[bs_cell(v, p.key)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -172,8 +195,8 @@ static __device__ __forceinline__ void bs_side(float v, const SideParam &p, LDS 
 // The same for four samples at once with the common path free of branches: out-of-window samples of the
 // histogram pass go to a dump cell, and the rare copies of the collect pass (about 1.6 % of the samples)
 // share ONE divergent branch per four samples.
-template <int SIDE>
-static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, float v3, const SideParam &p, LDS BlockScratch *bs,
+template <int SIDE, class BS>
+static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, float v3, const SideParam &p, LDS BS *bs,
                                                 uint32_t &aux, uint32_t &aux2)
 {
     if (SIDE == SIDE_HIST) {
@@ -188,7 +211,8 @@ static __device__ __forceinline__ void bs_side4(float v0, float v1, float v2, fl
 }
 
 // the copies of SIDE_COLLECT alone (dt < P is counted elsewhere)
-static __device__ __forceinline__ void bs_copy_exact(float v, const SideParam &p, LDS BlockScratch *bs)
+template <class BS>
+static __device__ __forceinline__ void bs_copy_exact(float v, const SideParam &p, LDS BS *bs)
 {
     const uint32_t key = f2key(v);
     if ((key >> BS_KSH) == p.key) {
@@ -224,11 +248,115 @@ static __device__ __forceinline__ uint32_t bs_flag4(float v0, float v1, float v2
     return f;
 }
 
+// One slab (1024 consecutive samples = eight of numpy's 128-sample leaves) of a summing pass, by one WAVE: lane ln holds samples
+// (u * 64 + ln) * 4 .. + 3 in v[u].  The wave stages them in its eight LDS rows, applies the pass's side effect, runs the 8 x 8
+// accumulator chains (lane = leaf ln >> 3, accumulator ln & 7, 16 samples each) and folds them by shuffles: the 8 accumulators of
+// a leaf, then the slab's 8 leaves (three levels of numpy's balanced tree).  Every lane returns the slab's sum.
+template <int SIDE, class BS>
+static __device__ __forceinline__ float bs_slab_sum(const float4 (&v)[4], int mode, float c, LDS BS *bs, LDS float *wstage, const SideParam &param,
+                                                    uint32_t &aux, uint32_t &aux2)
+{
+    const int ln = threadIdx.x & 63;
+    ws_sync(); // this wave's previous chain reads of its staging rows are done
+    uint32_t flags = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int e = (u * 64 + ln) * 4; // four consecutive samples of one leaf
+        if (SIDE == SIDE_COLLECT) flags |= bs_flag4(v[u].x, v[u].y, v[u].z, v[u].w, param, aux2) << (4 * u);
+        else bs_side4<SIDE>(v[u].x, v[u].y, v[u].z, v[u].w, param, bs, aux, aux2);
+        // RAW samples are staged (the transform is applied on the way out): the flagged ones are re-read here
+        v4f t4 = {v[u].x, v[u].y, v[u].z, v[u].w};
+        *reinterpret_cast<LDS v4f *>(wstage + (e >> 7) * BS_LEAF_STRIDE + (e & 127)) = t4;
+    }
+    ws_sync();
+    if (SIDE == SIDE_COLLECT && flags) { // the few flagged samples: exact classification and copies
+        do {
+            const int b = __ffs(flags) - 1;
+            flags &= flags - 1;
+            const int e = ((b >> 2) * 64 + ln) * 4 + (b & 3);
+            bs_copy_exact(wstage[(e >> 7) * BS_LEAF_STRIDE + (e & 127)], param, bs);
+        } while (flags);
+    }
+    const LDS float *qq = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
+    float r = bs_x2(qq[0], mode, c);
+#pragma unroll
+    for (int t = 1; t < 16; t++) r += bs_x2(qq[8 * t], mode, c);
+    r = r + __shfl_xor(r, 1);   // the 8 accumulators of a leaf
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    r = r + __shfl_xor(r, 8);   // the slab's 8 leaves: three levels of numpy's balanced tree
+    r = r + __shfl_xor(r, 16);
+    r = r + __shfl_xor(r, 32);
+    return r;
+}
+
+// numpy-ordered sum of xf(xt[0..tail)), 0 < tail < 8192 (the ragged chunk behind a segment's whole chunks), with the per-sample side
+// effect riding on its loads; lane 0 of wave 0 returns the sum (the other threads 0).  All threads of the workgroup call it.
+template <int SIDE, class X, class BS>
+static __device__ __forceinline__ float bs_ragged_sum(X xt, int tail, int mode, float c, LDS BS *bs, const SideParam &param, uint32_t &aux,
+                                                      uint32_t &aux2)
+{
+    constexpr int NW = BS::NW;
+    const int tid = threadIdx.x;
+    // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
+    bs_tail_leaves(tail, bs);
+    const int nleaf = bs->nleaf;
+    for (int g0 = 0; g0 < nleaf; g0 += 8 * NW) {
+        // stage 8 NW leaves: wave w loads leaves g0 + 8w .. g0 + 8w + 7 (coalesced, 2 loads per leaf)
+        __syncthreads();
+        const int w = tid >> 6, ln = tid & 63;
+        // (all sixteen loads of the wave's eight leaves first -- clamped indices, no conditions --, then the LDS writes:
+        // load, wait, write per leaf cost sixteen memory round trips per group of 32 leaves)
+        float va[8], vb[8];
+        int lens[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int l = g0 + w * 8 + q;
+            const bool have = l < nleaf;
+            const int off = have ? bs->leaf_off[l] : 0, len = have ? bs->leaf_len[l] : 0;
+            const int last = len > 0 ? len - 1 : 0;
+            lens[q] = len;
+            va[q] = xt[off + (ln < last ? ln : last)];
+            vb[q] = xt[off + (ln + 64 < last ? ln + 64 : last)];
+        }
+        // (the side effects of the ragged part ride on these loads: the leaves cover every sample of it exactly once)
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            LDS float *dst = bs->u.stage + (w * 8 + q) * BS_LEAF_STRIDE;
+            if (ln < lens[q]) { dst[ln] = bs_x2(va[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(va[q], param, bs, aux, aux2); }
+            if (ln + 64 < lens[q]) { dst[ln + 64] = bs_x2(vb[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(vb[q], param, bs, aux, aux2); }
+        }
+        __syncthreads();
+        // thread (leaf = tid >> 3, j = tid & 7): accumulator chain j of numpy's 8-accumulator leaf
+        const int ll = tid >> 3, j = tid & 7;
+        const int l = g0 + ll;
+        const int len = (l < nleaf) ? bs->leaf_len[l] : 0;
+        const LDS float *q = bs->u.stage + ll * BS_LEAF_STRIDE;
+        float r = 0.0f;
+        if (len >= 8) {
+            r = q[j];
+            const int lim = len - (len % 8);
+            for (int i = 8; i < lim; i += 8) r += q[i + j];
+        }
+        r = r + __shfl_xor(r, 1);
+        r = r + __shfl_xor(r, 2);
+        r = r + __shfl_xor(r, 4);
+        if (j == 0 && l < nleaf) {
+            float res;
+            if (len >= 8) { res = r; for (int i = len - (len % 8); i < len; i++) res += q[i]; }
+            else { res = 0.0f; for (int i = 0; i < len; i++) res += q[i]; }
+            bs->tleaf[bs->leaf_slot[l]] = res;
+        }
+    }
+    __syncthreads();
+    return tid < 64 ? bs_tail_tree(bs) : 0.0f; // (lane 0 holds the root)
+}
+
 // numpy-ordered sum of xf(x[0..n)) fused with a per-sample side effect; all threads return the sum and the
 // block-reduced aux (SIDE_HIST: count below the window; SIDE_COLLECT: max key below the bucket, aux2 = count
 // of samples closer to the centre than the bracket)
-template <int SIDE, class X>
-static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c, LDS BlockScratch *bs,
+template <int SIDE, class X, class BS>
+static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c, LDS BS *bs,
                                                    SideParam param)
 {
     const int tid = threadIdx.x;
@@ -245,18 +373,19 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
 #else
     auto phase = [](int) {};
 #endif
-    // Each WAVE owns whole numpy chunks (8192 samples; wave w takes chunks w, w+4, ...): it streams the chunk in eight
+    // Each WAVE owns whole numpy chunks (8192 samples; wave w takes chunks w, w+NW, ...): it streams the chunk in eight
     // slabs of 1024 samples (8 leaves), stages each slab in its own LDS rows, runs the 8 x 8 accumulator chains, folds
     // them by shuffles and keeps the slab sums in lanes 0..7; a last butterfly over those lanes is the top of numpy's
     // balanced tree.  No block-wide barrier inside the stream: the chunk sums meet once, in order, at the end.
+    constexpr int NW = BS::NW;
     const int w = tid >> 6, ln = tid & 63;
     LDS float *wstage = bs->u.stage + w * 8 * BS_LEAF_STRIDE;
     const int nchunk = n / 8192;
     // fewer chunks than waves (a short RNA part): the SLABS go round the waves instead -- wave w takes slabs w, w + 4, ... of the
     // 8 * nchunk -- so that all four stream; the slab sums then meet in LDS (bs->tleaf, free until the ragged part) for the chunks' trees
     const bool slabwise = nchunk <= 16; // (tleaf holds 128 slab sums)
-    const int myslabs = slabwise ? 2 * nchunk : (nchunk > w ? ((nchunk - w + 3) / 4) * 8 : 0); // slabs this wave streams
-    auto slab_off = [&](int q) { return slabwise ? (long long)(w + 4 * q) * 1024 : (long long)(w + 4 * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
+    const int myslabs = slabwise ? (8 * nchunk - w + NW - 1) / NW : (nchunk > w ? ((nchunk - w + NW - 1) / NW) * 8 : 0); // slabs this wave streams
+    auto slab_off = [&](int q) { return slabwise ? (long long)(w + NW * q) * 1024 : (long long)(w + NW * (q >> 3)) * 8192 + (q & 7) * 1024; }; // first sample of slab q
     // software pipeline: the loads of the next PF slabs fly (as raw samples) while this one is summed
     constexpr int PF = X::PREFETCH;
     typename X::Raw4 pf[PF][4];
@@ -281,44 +410,15 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
 #pragma unroll
             for (int u = 0; u < 4; u++) pf[PF - 1][u] = x.raw4u_in(p + (u * 64 + ln) * 4);
         }
-        ws_sync(); // this wave's previous chain reads of its staging rows are done
-        uint32_t flags = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = (u * 64 + ln) * 4; // four consecutive samples of one leaf
-            if (SIDE == SIDE_COLLECT) flags |= bs_flag4(v[u].x, v[u].y, v[u].z, v[u].w, param, aux2) << (4 * u);
-            else bs_side4<SIDE>(v[u].x, v[u].y, v[u].z, v[u].w, param, bs, aux, aux2);
-            // RAW samples are staged (the transform is applied on the way out): the flagged ones are re-read here
-            v4f t4 = {v[u].x, v[u].y, v[u].z, v[u].w};
-            *reinterpret_cast<LDS v4f *>(wstage + (e >> 7) * BS_LEAF_STRIDE + (e & 127)) = t4;
-        }
-        ws_sync();
-        if (SIDE == SIDE_COLLECT && flags) { // the few flagged samples: exact classification and copies
-            do {
-                const int b = __ffs(flags) - 1;
-                flags &= flags - 1;
-                const int e = ((b >> 2) * 64 + ln) * 4 + (b & 3);
-                bs_copy_exact(wstage[(e >> 7) * BS_LEAF_STRIDE + (e & 127)], param, bs);
-            } while (flags);
-        }
-        const LDS float *qq = wstage + (ln >> 3) * BS_LEAF_STRIDE + (ln & 7);
-        float r = bs_x2(qq[0], mode, c);
-#pragma unroll
-        for (int t = 1; t < 16; t++) r += bs_x2(qq[8 * t], mode, c);
-        r = r + __shfl_xor(r, 1);   // the 8 accumulators of a leaf
-        r = r + __shfl_xor(r, 2);
-        r = r + __shfl_xor(r, 4);
-        r = r + __shfl_xor(r, 8);   // the slab's 8 leaves: three levels of numpy's balanced tree
-        r = r + __shfl_xor(r, 16);
-        r = r + __shfl_xor(r, 32);
-        if (slabwise) { if (ln == 0) bs->tleaf[w + 4 * q] = r; continue; }
+        const float r = bs_slab_sum<SIDE>(v, mode, c, bs, wstage, param, aux, aux2);
+        if (slabwise) { if (ln == 0) bs->tleaf[w + NW * q] = r; continue; }
         if (ln == (q & 7)) slabsum = r;
         if ((q & 7) == 7) { // chunk complete: the top three levels over its 8 slab sums (lanes 0..7)
             float cs = slabsum;
             cs = cs + __shfl_xor(cs, 1);
             cs = cs + __shfl_xor(cs, 2);
             cs = cs + __shfl_xor(cs, 4);
-            const int ch = w + 4 * (q >> 3);
+            const int ch = w + NW * (q >> 3);
             if (ln == 0) bs->chunk_sum[ch & (BS_MAXCHUNK - 1)] = cs;
         }
     }
@@ -337,59 +437,8 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
     const int tail = n - s;
     if (tail > 0 && !(g_ablate & 4)) {
         phase(26);
-        // leaves of numpy's pairwise recursion over the ragged chunk (split n -> n2 = (n/2) & ~7, n - n2)
-        bs_tail_leaves(tail, bs);
-        const int nleaf = bs->nleaf;
-        const X xt = x + s;
-        for (int g0 = 0; g0 < nleaf; g0 += 32) {
-            // stage 32 leaves: wave w loads leaves g0 + 8w .. g0 + 8w + 7 (coalesced, 2 loads per leaf)
-            __syncthreads();
-            const int w = tid >> 6, ln = tid & 63;
-            // (all sixteen loads of the wave's eight leaves first -- clamped indices, no conditions --, then the LDS writes:
-            // load, wait, write per leaf cost sixteen memory round trips per group of 32 leaves)
-            float va[8], vb[8];
-            int lens[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int l = g0 + w * 8 + q;
-                const bool have = l < nleaf;
-                const int off = have ? bs->leaf_off[l] : 0, len = have ? bs->leaf_len[l] : 0;
-                const int last = len > 0 ? len - 1 : 0;
-                lens[q] = len;
-                va[q] = xt[off + (ln < last ? ln : last)];
-                vb[q] = xt[off + (ln + 64 < last ? ln + 64 : last)];
-            }
-            // (the side effects of the ragged part ride on these loads: the leaves cover every sample of it exactly once)
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                LDS float *dst = bs->u.stage + (w * 8 + q) * BS_LEAF_STRIDE;
-                if (ln < lens[q]) { dst[ln] = bs_x2(va[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(va[q], param, bs, aux, aux2); }
-                if (ln + 64 < lens[q]) { dst[ln + 64] = bs_x2(vb[q], mode, c); if (SIDE != SIDE_NONE) bs_side<SIDE>(vb[q], param, bs, aux, aux2); }
-            }
-            __syncthreads();
-            // thread (leaf = tid >> 3, j = tid & 7): accumulator chain j of numpy's 8-accumulator leaf
-            const int ll = tid >> 3, j = tid & 7;
-            const int l = g0 + ll;
-            const int len = (l < nleaf) ? bs->leaf_len[l] : 0;
-            const LDS float *q = bs->u.stage + ll * BS_LEAF_STRIDE;
-            float r = 0.0f;
-            if (len >= 8) {
-                r = q[j];
-                const int lim = len - (len % 8);
-                for (int i = 8; i < lim; i += 8) r += q[i + j];
-            }
-            r = r + __shfl_xor(r, 1);
-            r = r + __shfl_xor(r, 2);
-            r = r + __shfl_xor(r, 4);
-            if (j == 0 && l < nleaf) {
-                float res;
-                if (len >= 8) { res = r; for (int i = len - (len % 8); i < len; i++) res += q[i]; }
-                else { res = 0.0f; for (int i = 0; i < len; i++) res += q[i]; }
-                bs->tleaf[bs->leaf_slot[l]] = res;
-            }
-        }
-        __syncthreads();
-        if (tid < 64) total += bs_tail_tree(bs); // (lane 0 holds the root)
+        const float rt = bs_ragged_sum<SIDE>(x + s, tail, mode, c, bs, param, aux, aux2);
+        if (tid < 64) total += rt;
         phase(27);
     }
     __syncthreads();
@@ -420,17 +469,18 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
 // of a poly(A) slice and 30-60 k for the few dozen of a median bucket / MAD bracket: a quarter of this kernel's time at short windows.
 // Scratch: the head of the staging rows (x lives in the histogram's storage).  All threads return the values.
 #define BSEL_CAP 3072
-static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS BlockScratch *bs,
-                                                      float &vk, float &vkm1)
+template <class BS>
+static __device__ __forceinline__ void block_select2_lds_i(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs,
+                                                         float &vk, float &vkm1)
 {
-    const int tid = threadIdx.x, ln = tid & 63;
+    const int tid = bs_tid<BS>(), ln = tid & 63;
     LDS uint32_t *sc = (LDS uint32_t *)bs->u.stage; // [0, 512): two histograms; 512: min key, 513: max key, 514: below, 515: NaN seen
-    uint32_t key[BSEL_CAP / BS_THREADS];
+    uint32_t key[BSEL_CAP / BS::NT];
     uint32_t mn = 0xffffffffu, mx = 0u;
     bool has_nan = false;
 #pragma unroll
-    for (int u = 0; u < BSEL_CAP / BS_THREADS; u++) {
-        const int i = tid + u * BS_THREADS;
+    for (int u = 0; u < BSEL_CAP / BS::NT; u++) {
+        const int i = tid + u * BS::NT;
         key[u] = 0u;
         if (i < n) {
             const float xf = ws_xform(x[i], mode, c);
@@ -459,11 +509,11 @@ static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n,
         const int w = rb < 8 ? rb : 8;
         const int shift = rb - w;
         LDS uint32_t *hist = sc + par * 256;
-        hist[tid] = 0u;
+        if (tid < 256) hist[tid] = 0u;
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < BSEL_CAP / BS_THREADS; u++) {
-            const int i = tid + u * BS_THREADS;
+        for (int u = 0; u < BSEL_CAP / BS::NT; u++) {
+            const int i = tid + u * BS::NT;
             const uint32_t d = key[u] - mn;
             const uint32_t top = (rb >= 32) ? 0u : (d >> rb);
             if (i < n) {
@@ -525,31 +575,45 @@ static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n,
     __syncthreads();
 }
 
+template <class BS>
+static __device__ __noinline__ void block_select2_lds_call(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs, float &vk, float &vkm1)
+{
+    block_select2_lds_i(x, n, k, mode, c, bs, vk, vkm1);
+}
+// (a called function by default; inlined for the scratch types that ask for it: BlockScratchT<.., true>)
+template <class BS>
+static __device__ __forceinline__ void block_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs, float &vk, float &vkm1)
+{
+    if constexpr (BS::INLINE) block_select2_lds_i(x, n, k, mode, c, bs, vk, vkm1);
+    else block_select2_lds_call(x, n, k, mode, c, bs, vk, vkm1);
+}
+
 // A SHORT segment (the poly(A) slice, the adapter) is read from global memory ONCE, into LDS; its sums and selections run there.
 // BS_SMALLCAP: the staging rows and the histogram storage taken together (they are adjacent in BlockScratch).
-#define BS_SMALLCAP (32 * BS_LEAF_STRIDE + BS_BINS)
+#define BS_SMALLCAP (BS::STAGE + BS_BINS)
 static_assert(offsetof(BlockScratch, hist) == offsetof(BlockScratch, u) + 32 * BS_LEAF_STRIDE * 4, "the histogram's storage must follow the staging rows");
-template <class X>
+template <int NT, class X>
 static __device__ __forceinline__ void bs_copy_to_lds(X x, int n, LDS float *cp)
 {
     const int tid = threadIdx.x;
-    for (int base = 0; base < n; base += BS_THREADS * 8) { // eight loads in flight per thread
+    for (int base = 0; base < n; base += NT * 8) { // eight loads in flight per thread
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); }
+        for (int u = 0; u < 8; u++) { const int i = base + u * NT + tid; v[u] = ld_if(x, i, i < n); }
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = base + u * BS_THREADS + tid; if (i < n) cp[i] = v[u]; }
+        for (int u = 0; u < 8; u++) { const int i = base + u * NT + tid; if (i < n) cp[i] = v[u]; }
     }
 }
 // numpy-ordered sum of xf(cp[0..n)), n < 8192 (one ragged numpy chunk: the leaves of bs_tail_leaves, 8 accumulators each, the
 // balanced tree above them -- exactly the ragged part of block_np_sum, read from LDS instead of staged from global memory).
 // All threads return the sum.  The caller has a barrier between its writes of cp and this call.
-static __device__ __noinline__ float bs_lds_np_sum(const LDS float *cp, int n, int mode, float c, LDS BlockScratch *bs)
+template <class BS>
+static __device__ __noinline__ float bs_lds_np_sum(const LDS float *cp, int n, int mode, float c, LDS BS *bs)
 {
     const int tid = threadIdx.x;
     bs_tail_leaves(n, bs);
     const int nleaf = bs->nleaf;
-    for (int g0 = 0; g0 < nleaf; g0 += 32) {
+    for (int g0 = 0; g0 < nleaf; g0 += BS::NT / 8) {
         const int ll = tid >> 3, j = tid & 7; // accumulator chain j of leaf g0 + ll
         const int l = g0 + ll;
         const bool have = l < nleaf;
@@ -593,15 +657,15 @@ static __device__ __forceinline__ uint32_t bs_window_lo(float pivot)
 
 // locate the bucket holding rank k in h[0..NB) (with `under` samples before it); sets bs->bin/before,
 // bs->flag = 1 if the rank lies outside
-template <int NB>
-static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, const LDS uint32_t *hh, int k, int under)
+template <int NB, class BS>
+static __device__ __forceinline__ void block_find_bin_i(LDS BS *bs, const LDS uint32_t *hh, int k, int under)
 {
-    const int tid = threadIdx.x;
-    constexpr int PER = NB / BS_THREADS;
+    const int tid = bs_tid<BS>();
+    constexpr int PER = (NB + BS::NT - 1) / BS::NT;
     uint32_t h[PER];
     int s = 0;
 #pragma unroll
-    for (int j = 0; j < PER; j++) { h[j] = hh[tid * PER + j]; s += (int)h[j]; }
+    for (int j = 0; j < PER; j++) { h[j] = (NB % BS::NT == 0 || tid * PER + j < NB) ? hh[tid * PER + j] : 0u; s += (int)h[j]; }
     int incl = wave_scan_incl(s);
     if ((tid & 63) == 63) bs->scan[tid >> 6] = incl;
     if (tid == 0) { bs->flag = 1; bs->bin = 0; bs->before = 0; }
@@ -620,11 +684,21 @@ static __device__ __noinline__ void block_find_bin(LDS BlockScratch *bs, const L
     __syncthreads();
 }
 
+template <int NB, class BS>
+static __device__ __noinline__ void block_find_bin_call(LDS BS *bs, const LDS uint32_t *hh, int k, int under) { block_find_bin_i<NB>(bs, hh, k, under); }
+template <int NB, class BS>
+static __device__ __forceinline__ void block_find_bin(LDS BS *bs, const LDS uint32_t *hh, int k, int under)
+{
+    if constexpr (BS::INLINE) block_find_bin_i<NB>(bs, hh, k, under);
+    else block_find_bin_call<NB>(bs, hh, k, under);
+}
+
 struct SegStats { float mean, sd, med, mad; };
 
 // exact median from the collected bucket (wave 0), given the largest key below the bucket
-static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs, const LDS float *buf, int cnt, int n, int rk,
-                                                           uint32_t below_key)
+template <class BS>
+static __device__ __forceinline__ float bs_median_from_bucket_i(LDS BS *bs, const LDS float *buf, int cnt, int n, int rk,
+                                                              uint32_t below_key)
 {
     __syncthreads();
     float vk, vkm1;
@@ -637,16 +711,22 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BlockScratch *bs,
     return res;
 }
 
+template <class BS>
+static __device__ __noinline__ float bs_median_from_bucket(LDS BS *bs, const LDS float *buf, int cnt, int n, int rk, uint32_t below_key)
+{
+    return bs_median_from_bucket_i(bs, buf, cnt, n, rk, below_key);
+}
+
 // largest key below `key_lo` among x[0..n) (0 if none) -- all threads return it
-template <class X>
-static __device__ __noinline__ uint32_t bs_max_key_below(X x, int n, uint32_t key_lo, LDS BlockScratch *bs)
+template <class X, class BS>
+static __device__ __noinline__ uint32_t bs_max_key_below(X x, int n, uint32_t key_lo, LDS BS *bs)
 {
     const int tid = threadIdx.x;
     __syncthreads();
     if (tid == 0) bs->below = 0;
     __syncthreads();
     uint32_t best = 0;
-    for (int i = tid; i < n; i += BS_THREADS) { uint32_t key = f2key(x[i]); if (key < key_lo && key > best) best = key; }
+    for (int i = tid; i < n; i += BS::NT) { uint32_t key = f2key(x[i]); if (key < key_lo && key > best) best = key; }
     best = wave_max(best);
     if ((tid & 63) == 0 && best) __hip_atomic_fetch_max(&bs->below, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
@@ -659,24 +739,24 @@ static __device__ __noinline__ uint32_t bs_max_key_below(X x, int n, uint32_t ke
 // int16 ADC samples (a step of ~0.18 pA is wider than a bucket, so thousands of samples share one key).  One more pass
 // counts the bucket's samples by their exact key -- 4096 counters in the staging area -- and notes the largest key below
 // the bucket; the median follows from the counts, whatever the multiplicities.
-template <class X>
-static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS BlockScratch *bs, uint32_t key_lo, int rk)
+template <class X, class BS>
+static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS BS *bs, uint32_t key_lo, int rk)
 {
     const int tid = threadIdx.x;
     LDS uint32_t *sub = (LDS uint32_t *)bs->u.stage; // 4096 counters (16 KB of the 17 KB staging area)
-    static_assert(sizeof(((BlockScratch *)0)->u.stage) >= 4096 * 4, "staging area too small for the key counters");
+    static_assert(sizeof(((BS *)0)->u.stage) >= 4096 * 4, "staging area too small for the key counters");
     __syncthreads();
-    for (int i = tid; i < 4096; i += BS_THREADS) sub[i] = 0;
+    for (int i = tid; i < 4096; i += BS::NT) sub[i] = 0;
     if (tid == 0) bs->below = 0;
     __syncthreads();
     uint32_t best = 0;
-    for (int base = 0; base < n; base += BS_THREADS * 8) {
+    for (int base = 0; base < n; base += BS::NT * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
+        for (int u = 0; u < 8; u++) { int i = base + u * BS::NT + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = base + u * BS_THREADS + tid;
+            const int i = base + u * BS::NT + tid;
             if (i < n) {
                 const uint32_t key = f2key(v[u]);
                 const uint32_t d = key - key_lo; // wraps below the bucket
@@ -695,7 +775,7 @@ static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS Bloc
     if (tid == 0) bs->cntb = 0; // (largest occupied counter index below `bin`, + 1)
     __syncthreads();
     uint32_t lowb = 0;
-    for (int i = tid; i < bin; i += BS_THREADS) if (sub[i]) lowb = (uint32_t)i + 1u;
+    for (int i = tid; i < bin; i += BS::NT) if (sub[i]) lowb = (uint32_t)i + 1u;
     lowb = wave_max(lowb);
     if ((tid & 63) == 0 && lowb) __hip_atomic_fetch_max(&bs->cntb, lowb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
@@ -711,8 +791,8 @@ static __device__ __noinline__ float bs_median_dense_bucket(X x, int n, LDS Bloc
 }
 
 // passes C and D: exact median of |x - med| by an 18-bit window histogram + bucket collection
-template <class X>
-static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratch *bs, float med, float sd)
+template <class X, class BS>
+static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BS *bs, float med, float sd)
 {
     const int tid = threadIdx.x;
     const int k1 = n / 2;
@@ -722,16 +802,16 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
     if (!(pivot > 0.f)) pivot = 1.0f;
     const uint32_t wlo = bs_window_lo<14>(pivot) >= 512u ? bs_window_lo<14>(pivot) - 512u : 0u; // [pivot_oct/4, pivot_oct*4)
     __syncthreads();
-    for (int i = tid; i < BS_BINS18; i += BS_THREADS) h18[i] = 0;
+    for (int i = tid; i < BS_BINS18; i += BS::NT) h18[i] = 0;
     __syncthreads();
     int under = 0;
-    for (int base = 0; base < n; base += BS_THREADS * 8) {
+    for (int base = 0; base < n; base += BS::NT * 8) {
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
+        for (int u = 0; u < 8; u++) { int i = base + u * BS::NT + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            int i = base + u * BS_THREADS + tid;
+            int i = base + u * BS::NT + tid;
             if (i < n) {
                 uint32_t k18 = f2key(fabsf(v[u] - med)) >> 14;
                 if (k18 < wlo) under++;
@@ -741,9 +821,10 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
     }
     under = wave_sum(under);
     __syncthreads();
-    if ((tid & 63) == 0) bs->scan[4 + (tid >> 6)] = under;
+    if ((tid & 63) == 0) bs->scan[BS::NW + (tid >> 6)] = under;
     __syncthreads();
-    under = bs->scan[4] + bs->scan[5] + bs->scan[6] + bs->scan[7];
+    under = 0;
+    for (int w_ = 0; w_ < BS::NW; w_++) under += bs->scan[BS::NW + w_];
     block_find_bin<BS_BINS18>(bs, h18, k1, under);
     const bool miss = bs->flag != 0;
     const int bin = bs->bin, rk = k1 - bs->before;
@@ -753,13 +834,13 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
     if (!miss) {
         const uint32_t tgt = wlo + (uint32_t)bin;
         uint32_t below = 0;
-        for (int base = 0; base < n; base += BS_THREADS * 8) {
+        for (int base = 0; base < n; base += BS::NT * 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int i = base + u * BS_THREADS + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
+            for (int u = 0; u < 8; u++) { int i = base + u * BS::NT + tid; v[u] = ld_if(x, i, i < n); } // (entries beyond n are not used)
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                int i = base + u * BS_THREADS + tid;
+                int i = base + u * BS::NT + tid;
                 if (i < n) {
                     float d = fabsf(v[u] - med);
                     uint32_t key = f2key(d);
@@ -798,14 +879,15 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BlockScratc
 
 // After pass A: predict where the MAD lies from the bucket histogram.  Returns false if no prediction.
 // c = centre of the median's bucket, w0 = its width; [P, Q] = bracket of distances to c.
-static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
+template <class BS>
+static __device__ __forceinline__ bool bs_predict_mad_i(LDS BS *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
 {
-    const int tid = threadIdx.x;
+    const int tid = bs_tid<BS>();
     LDS uint32_t *dh = (LDS uint32_t *)bs->u.stage; // distance histogram, BS_BINS cells of width w0
     __syncthreads();
-    for (int i = tid; i < BS_BINS; i += BS_THREADS) dh[i] = 0;
+    for (int i = tid; i < BS_BINS; i += BS::NT) dh[i] = 0;
     __syncthreads();
-    for (int i = tid; i < BS_BINS; i += BS_THREADS) {
+    for (int i = tid; i < BS_BINS; i += BS::NT) {
         uint32_t h = bs_bins(bs)[i];
         if (h) {
             float xc = key2f(((wlo + (uint32_t)i) << BS_KSH) + (1u << (BS_KSH - 1)));
@@ -825,9 +907,15 @@ static __device__ __noinline__ bool bs_predict_mad(LDS BlockScratch *bs, uint32_
     return true;
 }
 
+template <class BS>
+static __device__ __noinline__ bool bs_predict_mad(LDS BS *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
+{
+    return bs_predict_mad_i(bs, wlo, k1, c, w0, P, Q);
+}
+
 // mean / std / median / MAD of x[0..n), n >= 1.  have_medmad: reuse med_in / mad_in (adapter partition).
-template <class X>
-static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs, bool have_medmad,
+template <class X, class BS>
+static __device__ SegStats block_segment_stats(X x, int n, LDS BS *bs, bool have_medmad,
                                                float med_in, float mad_in)
 {
     const int tid = threadIdx.x;
@@ -855,7 +943,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
 #endif
         LDS float *cp = (LDS float *)bs->hist;
         __syncthreads();
-        bs_copy_to_lds(x, n, cp);
+        bs_copy_to_lds<BS::NT>(x, n, cp);
         __syncthreads();
         sub(42);
         o.mean = bs_lds_np_sum(cp, n, 0, 0.f, bs) / (float)n;
@@ -876,7 +964,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         // the adapter (its median and MAD come from k_validate): one read into LDS, the two sums there
         LDS float *cp = (LDS float *)bs->u.stage; // (runs on into the histogram's storage)
         __syncthreads();
-        bs_copy_to_lds(x, n, cp);
+        bs_copy_to_lds<BS::NT>(x, n, cp);
         __syncthreads();
         o.mean = bs_lds_np_sum(cp, n, 0, 0.f, bs) / (float)n;
         if (o.mean != o.mean) { // (a NaN or infinities of both signs: np.std is NaN either way)
@@ -893,7 +981,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         { const uint32_t kb = f2key(pivot) >> BS_KSH; wlo = kb >= BS_BINS / 2 ? kb - BS_BINS / 2 : 0u; } // centred on the pivot
     }
     __syncthreads();
-    for (int i = tid; i < BS_BINS + 4; i += BS_THREADS) bs->hist[i] = 0; // (the bins and the dump cells behind them)
+    for (int i = tid; i < BS_BINS + 4; i += BS::NT) bs->hist[i] = 0; // (the bins and the dump cells behind them)
     __syncthreads();
     sp.key = wlo;
     SumAux p1 = (have_medmad || (g_ablate & 2048)) ? block_np_sum<SIDE_NONE>(x, n, 0, 0.f, bs, sp) : block_np_sum<SIDE_HIST>(x, n, 0, 0.f, bs, sp);
@@ -905,7 +993,7 @@ static __device__ SegStats block_segment_stats(X x, int n, LDS BlockScratch *bs,
         if (tid == 0) bs->flag = 0;
         __syncthreads();
         bool nanhere = false;
-        for (int i = tid; i < n; i += BS_THREADS) { const float v = x[i]; nanhere |= v != v; }
+        for (int i = tid; i < n; i += BS::NT) { const float v = x[i]; nanhere |= v != v; }
         if (__any(nanhere) && (tid & 63) == 0) bs->flag = 1;
         __syncthreads();
         const bool any_nan = bs->flag != 0;
@@ -1031,20 +1119,10 @@ struct PartReq {
     int32_t p_none;     // polya_end is None (mvs_detect_overwrite): poly(A) keeps its start only, the RNA partition is all None
 };
 
-// grid = n_reads blocks of 256 threads
-template <class SIG>
-__global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int m, const PartReq *__restrict__ req,
-                                                               adp_row *__restrict__ rows)
+// the three partitions of read r
+template <class ROW, class BS>
+static __device__ __forceinline__ void bs_partitions_of_read(const ROW sig, const PartReq &q, adp_row *row, LDS BS *bs)
 {
-    __shared__ BlockScratch bs_;
-    LDS BlockScratch *bs = (LDS BlockScratch *)&bs_;
-    const int r = blockIdx.x;
-    const PartReq q = req[r];
-    if (!q.valid) return;
-    if (threadIdx.x == 0) bs->tail_cached = -1;
-    __syncthreads();
-    const typename SIG::Row sig = sigs.row(r, m);
-    adp_row *row = rows + r;
     const int S = q.S;
     unsigned long long present = 0;
     const long long starts[3] = {q.a_s, q.a_e, q.p_e};
@@ -1073,6 +1151,21 @@ __global__ void __launch_bounds__(BS_THREADS, 5) k_partition_stats(SIG sigs, int
         __syncthreads();
     }
     if (threadIdx.x == 0) row->present |= present;
+}
+
+// grid = n_reads workgroups of NT threads, WPE waves per SIMD (256 x 5: five workgroups per CU; 512 x 4: two; 1024 x 4: one)
+template <class SIG, int NT, int WPE>
+__global__ void __launch_bounds__(NT, WPE) k_partition_stats(SIG sigs, int m, const PartReq *__restrict__ req, adp_row *__restrict__ rows)
+{
+    typedef BlockScratchT<NT> BS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bs_mem_[];
+    LDS BS *bs = (LDS BS *)bs_mem_;
+    const int r = blockIdx.x;
+    const PartReq q = req[r];
+    if (!q.valid) return;
+    if (threadIdx.x == 0) bs->tail_cached = -1;
+    __syncthreads();
+    bs_partitions_of_read(sigs.row(r, m), q, rows + r, bs);
 }
 
 // (Round 3, measured and dropped: a wave per SHORT read -- numpy-ordered sums and radix selects of wave_stats.h, no workgroup

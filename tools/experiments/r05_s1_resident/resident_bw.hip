@@ -1,0 +1,226 @@
+// resident_bw.hip -- ceiling of a two-pass row kernel (k_partition_stats: numpy-ordered sum, then squared deviations) that KEEPS
+// part of the row on chip between its passes: one persistent workgroup per CU, every wave holds the first KR slabs (1024 floats,
+// 16 registers per lane) of its share in registers; pass B sums those from the registers and re-reads only the rest, last
+// streamed first.  Serial phases (the bucket search between the passes, the selections behind pass B) are emulated by a delay;
+// NEXT: the next row's resident slabs are requested BEFORE the closing delay so that the CU streams through it.
+//   hipcc --offload-arch=gfx950 -O3 -o resident_bw tools/resident_bw.hip && ./resident_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void delay_us(float us)
+{
+    if (us <= 0.f) return;
+    const long long t0 = wall_clock64(); // 100 MHz
+    const long long dt = (long long)(us * 100.f);
+    while (wall_clock64() - t0 < dt) __builtin_amdgcn_s_sleep(8);
+}
+
+// CHAIN: a slab (1024 floats = 8 numpy leaves of 128) is loaded as the accumulator chains need it -- lane (leaf ln >> 3, accumulator
+// ln & 7) reads elements 8 t + (ln & 7) of its leaf, t = 0 .. 15: sixteen 4-byte loads whose lanes form 32-byte runs -- instead of
+// four coalesced 16-byte loads that then have to be transposed through LDS
+template <bool CHAIN>
+__device__ __forceinline__ void load_slab(const float *p, int ln, f4 (&dst)[4])
+{
+    if (CHAIN) {
+        const float *q = p + (ln >> 3) * 128 + (ln & 7);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { dst[u].x = q[(4 * u) * 8]; dst[u].y = q[(4 * u + 1) * 8]; dst[u].z = q[(4 * u + 2) * 8]; dst[u].w = q[(4 * u + 3) * 8]; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) dst[u] = *reinterpret_cast<const f4 *>(p + (u * 64 + ln) * 4);
+    }
+}
+
+// slabs of a row are dealt to the waves chunk-wise (8 slabs = one numpy chunk): wave w takes chunks w, w + NW, ...
+template <int NT, int KR, int PF, bool NEXT, bool REV, bool CHAIN = false>
+__global__ void __launch_bounds__(NT) k_res(const float *__restrict__ x, int m, int off, int T, int rows, float d_mid, float d_end, float *out)
+{
+    constexpr int NW = NT / 64;
+    const int w = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int nchunk = T / 8192;
+    const int myslabs = nchunk > w ? ((nchunk - w + NW - 1) / NW) * 8 : 0;
+    auto slab_off = [&](int q) { return (long long)(w + NW * (q >> 3)) * 8192 + (q & 7) * 1024; };
+    f4 keep[KR > 0 ? KR : 1][4];
+    float acc = 0.f;
+    auto issue_resident = [&](int r) {
+        const float *row = x + (size_t)r * m + off;
+#pragma unroll
+        for (int q = 0; q < KR; q++)
+            if (q < myslabs) {
+                load_slab<CHAIN>(row + slab_off(q), ln, keep[q]);
+            }
+    };
+    int r = blockIdx.x;
+    if (r < rows) issue_resident(r);
+    for (; r < rows; r += gridDim.x) {
+        const float *row = x + (size_t)r * m + off;
+        // ---- pass A
+        f4 pf[PF][4];
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < PF; d++)
+            if (KR + d < myslabs) {
+                load_slab<CHAIN>(row + slab_off(KR + d), ln, pf[d]);
+            }
+#pragma unroll
+        for (int q = 0; q < KR; q++)
+            if (q < myslabs) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) s += (keep[q][u].x + keep[q][u].y) + (keep[q][u].z + keep[q][u].w);
+            }
+        for (int q = KR; q < myslabs; q++) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = pf[0][u];
+#pragma unroll
+            for (int d = 0; d + 1 < PF; d++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) pf[d][u] = pf[d + 1][u];
+            if (q + PF < myslabs) {
+                load_slab<CHAIN>(row + slab_off(q + PF), ln, pf[PF - 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        }
+        // ---- between the passes: pass B's first slabs are requested before the serial phase
+        auto qb = [&](int i) { return REV ? myslabs - 1 - i : KR + i; }; // i-th non-resident slab of pass B
+        const int nb = myslabs > KR ? myslabs - KR : 0;
+#pragma unroll
+        for (int d = 0; d < PF; d++)
+            if (d < nb) {
+                load_slab<CHAIN>(row + slab_off(qb(d)), ln, pf[d]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        delay_us(d_mid);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const float mean = s * 1e-6f;
+        // ---- pass B
+        float s2 = 0.f;
+        for (int i = 0; i < nb; i++) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = pf[0][u];
+#pragma unroll
+            for (int d = 0; d + 1 < PF; d++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) pf[d][u] = pf[d + 1][u];
+            if (i + PF < nb) {
+                load_slab<CHAIN>(row + slab_off(qb(i + PF)), ln, pf[PF - 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const f4 d4 = v[u] - mean;
+                s2 += (d4.x * d4.x + d4.y * d4.y) + (d4.z * d4.z + d4.w * d4.w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KR; q++)
+            if (q < myslabs) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const f4 d4 = keep[q][u] - mean;
+                    s2 += (d4.x * d4.x + d4.y * d4.y) + (d4.z * d4.z + d4.w * d4.w);
+                }
+            }
+        const int rn = r + gridDim.x;
+        if (NEXT && rn < rows) issue_resident(rn);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        delay_us(d_end);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!NEXT && rn < rows) issue_resident(rn);
+        acc += s2;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+// the form the product has today: one 256-thread workgroup per row, five per CU, two full passes
+__global__ void __launch_bounds__(256) k_twice(const float *__restrict__ x, int m, int off, int T, float d_mid, float d_end, float *out)
+{
+    const f4 *row = reinterpret_cast<const f4 *>(x + (size_t)blockIdx.x * m + off);
+    f4 acc = {0, 0, 0, 0};
+    const int nrounds = (T / 4) / (4 * 256);
+    for (int p = 0; p < 2; p++) {
+        for (int rd = 0; rd < nrounds; rd++) {
+            const int i = rd * 4 * 256 + threadIdx.x;
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = row[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 4; u++) acc += v[u];
+        }
+        __syncthreads();
+        delay_us(p == 0 ? d_mid : d_end);
+        __syncthreads();
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123.456f) out[0] = s;
+}
+
+__global__ void k_fill(float *x, size_t n)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += 65536ull * 256ull) { unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; x[i] = 60.0f + (float)(h & 0xffff) * 0.001f; }
+}
+
+int main()
+{
+    const int m = 201500, T = 24 * 8192, off = 4000; // 24 whole chunks of the RNA part (196 608 samples)
+    const size_t bytes = (size_t)24 << 30;
+    const int rows = (int)(bytes / 4 / m);
+    float *d, *o;
+    if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&o, 4) != hipSuccess) return 1;
+    hipLaunchKernelGGL(k_fill, dim3(65536), dim3(256), 0, 0, d, bytes / 4);
+    (void)hipDeviceSynchronize();
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const double alg = (double)rows * T * 4.0;
+    auto report = [&](const char *name, float ms) {
+        printf("%-44s %7.2f ms  %5.2f TB/s of one pass's bytes  (%5.1f us per row and CU)\n", name, ms, alg / (ms * 1e-3) / 1e12, ms * 1e3 * 256 / rows);
+    };
+    for (int rep = 0; rep < 2; rep++)
+        for (float dl : {0.f, 3.f, 6.f}) {
+            const float d_mid = dl, d_end = 2.f * dl;
+            printf("--- emulated serial phases: %.0f us between the passes, %.0f us behind pass B\n", d_mid, d_end);
+            auto time = [&](auto launch) {
+                launch(); (void)hipDeviceSynchronize();
+                (void)hipEventRecord(a); launch(); (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+                float ms; (void)hipEventElapsedTime(&ms, a, b); return ms;
+            };
+            report("256 threads x 5 per CU, two full passes", time([&] { hipLaunchKernelGGL(k_twice, dim3(rows), dim3(256), 30 * 1024, 0, d, m, off, T, d_mid, d_end, o); }));
+#define RUN(NT, KR, PF, NEXT, REV, PERCU, LDS) RUNC(NT, KR, PF, NEXT, REV, PERCU, LDS, false)
+#define RUNC(NT, KR, PF, NEXT, REV, PERCU, LDS, CH)                                                                                               \
+    {                                                                                                                                       \
+        char nm[96];                                                                                                                        \
+        snprintf(nm, sizeof nm, "%d thr x %d/CU keep %2d pf %d %s %s%s", NT, PERCU, KR, PF, NEXT ? "next" : "    ", REV ? "rev" : "fwd", CH ? " chain" : "");       \
+        (void)hipFuncSetAttribute((const void *)k_res<NT, KR, PF, NEXT, REV, CH>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);               \
+        report(nm, time([&] { hipLaunchKernelGGL((k_res<NT, KR, PF, NEXT, REV, CH>), dim3(256 * PERCU), dim3(NT), LDS, 0, d, m, off, T, rows, d_mid, d_end, o); })); \
+    }
+            RUN(512, 0, 2, false, false, 1, 100 * 1024)
+            RUN(512, 0, 2, false, true, 1, 100 * 1024)
+            RUN(512, 8, 2, false, true, 1, 100 * 1024)
+            RUN(512, 11, 2, false, true, 1, 100 * 1024)
+            RUN(512, 11, 2, true, true, 1, 100 * 1024)
+            RUN(512, 11, 2, true, false, 1, 100 * 1024)
+            RUN(512, 12, 1, true, true, 1, 100 * 1024)
+            RUN(512, 13, 1, true, true, 1, 100 * 1024)
+            RUN(256, 11, 2, true, true, 2, 70 * 1024)
+            RUN(256, 12, 2, true, true, 2, 70 * 1024)
+            RUN(1024, 4, 1, true, true, 1, 100 * 1024)
+            RUN(1024, 5, 1, true, true, 1, 100 * 1024)
+            RUN(256, 4, 2, true, true, 4, 36 * 1024)
+            RUN(256, 0, 2, false, true, 5, 30 * 1024)
+            RUN(256, 0, 2, false, true, 4, 38 * 1024)
+            RUN(256, 0, 2, false, true, 3, 50 * 1024)
+            RUN(256, 0, 2, false, true, 2, 70 * 1024)
+            RUN(512, 0, 2, false, true, 2, 70 * 1024)
+            RUN(512, 0, 2, false, false, 2, 70 * 1024)
+            RUN(1024, 0, 2, false, true, 1, 100 * 1024)
+            RUN(1024, 0, 1, false, true, 1, 100 * 1024)
+            RUNC(512, 0, 2, false, false, 1, 100 * 1024, true)
+            RUNC(512, 11, 2, true, true, 1, 100 * 1024, true)
+            RUNC(512, 8, 2, true, true, 1, 100 * 1024, true)
+            RUNC(256, 0, 2, false, false, 5, 30 * 1024, true)
+            RUNC(256, 0, 1, false, false, 5, 30 * 1024, true)
+            RUN(256, 0, 2, false, false, 5, 30 * 1024)
+        }
+    return 0;
+}
