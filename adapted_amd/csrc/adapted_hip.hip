@@ -23,7 +23,6 @@ __device__ unsigned long long g_bs_tally[ADP_NTALLY][8] = {{0}};
 #include "synth.h"
 #include "validate.h"
 #include "cand_stats2.h"
-#include "validate_wg.h"
 #include "series_pipe.h"
 #include "cnn_topk.h"
 #include "cnn_conv.h"
@@ -85,7 +84,7 @@ struct adp_handle {
     int pos_off = 0;  // added to pooled indices * ds for sample positions
     DevBuf rng0;      // per-read [0, T) ranges of the single-read layout
     // CNN head (cnn_conv.h): weights of the four layers, two activation buffers [chunk][64][Lpad]
-    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used, series_plan, vtodo;
+    DevBuf cnn_w, cnn_act[2], cnn_x, cnn_sc, ct_st, ct_lnz, ct_ap, cstat, op_arena, op_used, series_plan;
     DevBuf tr_buf, tr_meta; // adp_c_llr_trace: staging of host arrays
     unsigned int op_last_used = 0;
     bool cnn_have_w = false;
@@ -96,9 +95,6 @@ struct adp_handle {
     DevBuf cnn_actf[2];                                  // the exact-float32 stack's activations [chunk][64][Lpad] (cnn_act: the split rows)
     int cnn_f_Lpad = 0, cnn_f_L1 = 0, cnn_f_chunk = 0;
     bool cnn_redo_f32 = false;
-    bool cnn_wg8 = false;     // ADP_CNN_WG8=1: the 64 -> 64 layers with two waves per SIMD (k_cnn_conv64s8)
-    bool cnn_pipe = false;    // ADP_CNN_PIPE=1: the 64 -> 64 layers with a tile's epilogue under the next tile's MFMAs (k_cnn_conv64p)
-    bool cnn_fuse_in = false; // ADP_CNN_FUSE_IN=1: layer 0 computed inside layer 1's kernel (measured: no gain at the 200 k window, see below)
     DevBuf cnn_wsp;          // split B fragments of layers 1 and 2
     float cnn_sw[2] = {1.f, 1.f};
     // grouped execution of the LLR path (llr_grouped): child handles ("lanes") with their own streams and a workspace for ONE
@@ -266,9 +262,6 @@ int adp_create(int device, const adp_cfg *cfg, int max_reads, int m, adp_handle 
     if (hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) { adp_destroy(h); g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) h->n_cu = pr.multiProcessorCount; }
     { const char *cv = getenv("ADP_CNN_CONV"); if (cv && !strcmp(cv, "f32")) h->cnn_mode = 0; } // the exact-float32 conv stack (cnn_conv.h)
-    { const char *cv = getenv("ADP_CNN_FUSE_IN"); h->cnn_fuse_in = cv && *cv == '1'; }
-    { const char *cv = getenv("ADP_CNN_WG8"); h->cnn_wg8 = cv && *cv == '1'; }
-    { const char *cv = getenv("ADP_CNN_PIPE"); h->cnn_pipe = cv && *cv == '1'; }
     *out = h;
     return ADP_OK;
 }
@@ -282,7 +275,7 @@ int adp_destroy(adp_handle *h)
     for (hipEvent_t e : h->ev_sync) (void)hipEventDestroy(e);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     h->mbstat.release(); h->mbparams.release(); h->sphead.release();
-    DevBuf *all[] = {&h->cnn_actf[0], &h->cnn_actf[1], &h->vtodo, &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
+    DevBuf *all[] = {&h->cnn_actf[0], &h->cnn_actf[1], &h->series_plan, &h->cnn_wsp, &h->tr_buf, &h->tr_meta, &h->op_arena, &h->op_used, &h->cstat, &h->cnn_w, &h->cnn_act[0], &h->cnn_act[1], &h->cnn_x, &h->cnn_sc, &h->ct_st, &h->ct_lnz, &h->ct_ap, &h->rng0, &h->mbs, &h->ghist, &h->gbelow, &h->gcnt, &h->cbuf, &h->fz, &h->fcnt, &h->n1heavy, &h->ct_pk, &h->ct_pv, &h->ct_out, &h->gstat, &h->down, &h->nvalid, &h->ck, &h->tail, &h->trace, &h->bmax, &h->bmin,
                      &h->t1, &h->adapter_idx, &h->polya_idx, &h->bounds, &h->topk_none, &h->rows, &h->preq, &h->series, &h->have_series, &h->vscratch, &h->pk, &h->pkv, &h->npk,
                      &h->mk, &h->st, &h->sp, &h->any_none, &h->sig_stage, &h->len_stage, &h->bounds_stage};
     for (DevBuf *b : all) b->release();
@@ -449,17 +442,6 @@ static int arena_end(adp_handle *h, bool cnn = false)
     return 1;
 }
 
-template <int THREADS, int L0, int LN>
-static int launch_cand_stats(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
-{
-    typedef CsSharedT<L0, LN> Sh;
-    const unsigned bit = THREADS == 1024 ? 1u : 2u;
-    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cand_stats<THREADS, L0, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Sh))); h->attr_done |= bit; }
-    hipLaunchKernelGGL((k_cand_stats<THREADS, L0, LN>), dim3(n), dim3(THREADS), sizeof(Sh), h->stream, sig, dlen, n, m, h->bounds.as<int64_t>(), kmax, h->cfg,
-                       (const float *)h->series.as<float>(), cap, (const int8_t *)h->have_series.as<int8_t>(), h->cstat.as<CandStat>());
-    return 0;
-}
-
 template <int THREADS, int HB, int U>
 static int launch_cand_stats2(adp_handle *h, const float *sig, const int32_t *dlen, int n, int m, int kmax, int cap)
 {
@@ -527,12 +509,8 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
         if constexpr (std::is_same<SIG, SigF32>::value) {
         if (multi) {
             Scope s(h, "k_cand_stats");
-            // round 4: two sweeps per array (cand_stats2.h); ADP_CAND_STATS=old keeps the multi-level sweeps of cand_stats.h (cross-check)
+            // two sweeps per array (cand_stats2.h)
             int rc;
-            if (env_int("ADP_CAND_STATS_OLD", 0))
-                rc = h->m > 32768 ? launch_cand_stats<1024, CS_BIG_L0, 8>(h, dsig.base, dlen, n, m, kmax, cap)
-                                  : launch_cand_stats<256, 8, 6>(h, dsig.base, dlen, n, m, kmax, cap);
-            else
                 // (shapes tried on one box, 24 000 reads at the 200 k window / 32 000 at the default one: 512 threads x 8 loads in flight 14.3 ms,
                 // x 4 14.7, 1024 threads 18.9-19.8; 256 threads x 4 3.5 ms, x 8 4.4, x 2 3.45, 128 threads 4.1-4.2)
                 rc = h->m > 32768 ? launch_cand_stats2<512, 12, 8>(h, dsig.base, dlen, n, m, kmax, cap)
@@ -549,19 +527,6 @@ static int launch_validate(adp_handle *h, SIG dsig, const int32_t *dlen, int n, 
     // launch of the call, shared by the lanes of a grouped call; a call that overflowed it is repeated on a larger one)
     adp_handle *a = h->owner ? h->owner : h;
     in.op_arena = a->op_arena.as<int32_t>(); in.op_used = a->op_used.as<unsigned int>(); in.op_cap = (unsigned int)(a->op_arena.cap / 4);
-    // ADP_VALIDATE_WG=1 (opt-in; measured slower, profiles/r04_tried_and_dropped.txt): a workgroup per read with the slices staged in
-    // LDS takes every read that fits its plan (validate_wg.h) and flags the others; k_validate follows over the flagged ones
-    in.todo = nullptr;
-    if (!h->cfg.mvs_detect_overwrite && env_int("ADP_VALIDATE_WG", 0)) {
-        if (h->vtodo.ensure((size_t)n)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
-        const unsigned vbit = std::is_same<SIG, SigF32>::value ? 16384u : 32768u;
-        if (!(h->attr_done & vbit)) { HIPCHK(hipFuncSetAttribute((const void *)k_validate_wg<SIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(VwSh))); h->attr_done |= vbit; }
-        const int wg = n < 8 * h->n_cu ? n : 8 * h->n_cu;
-        { Scope s(h, "k_validate_wg");
-          hipLaunchKernelGGL(k_validate_wg<SIG>, dim3(wg), dim3(VW_THREADS), sizeof(VwSh), h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>(),
-                             h->vtodo.as<int8_t>()); }
-        in.todo = h->vtodo.as<int8_t>();
-    }
     { Scope s(h, "k_validate");
       hipLaunchKernelGGL(k_validate<SIG>, dim3(grid), dim3(64), 0, h->stream, in, h->cfg, h->rows.as<adp_row>(), h->preq.as<PartReq>()); }
     { Scope s(h, "k_partition_stats");
@@ -769,22 +734,10 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         }
         if (upto >= 5) {
             Scope s(h, "k_adapter_peak");
-            // ADP_APK_STAGE=k (opt-in; k = 2048 is 16.5 KB of LDS per wave): traces of at most k points are walked from LDS by a launch of their
-            // own.  Measured (96 000 reads): 2.57 against 2.68 ms at the preset's 16 k window, 3.2 against 2.65 on heavy-tailed lengths at
-            // the 200 k window (two launches): the walks are bound by their serial steps, not by where the samples come from.
-            int cap = env_int("ADP_APK_STAGE", 0);
-            if (cap < 0) cap = 0;
-            if (cap > 6144) cap = 6144;
-            if (cap > h->Lp) cap = (h->Lp + 63) / 64 * 64;
-            if (cap)
-                hipLaunchKernelGGL(k_adapter_peak<true>, dim3(n), dim3(64), (size_t)APK_LDS_DOUBLES(cap) * 8, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
-                                   h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), minibatch, mbs,
-                                   h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
-                                   h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>(), cap);
-            hipLaunchKernelGGL(k_adapter_peak<false>, dim3(n), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
+            hipLaunchKernelGGL(k_adapter_peak, dim3(n), dim3(64), 0, st, h->trace.as<double>(), h->nvalid.as<int32_t>(), h->Lp,
                                h->bmax.as<double>(), h->bmin.as<double>(), h->nsum, h->t1.as<int2>(), minibatch, mbs,
                                h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
-                               h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>(), cap);
+                               h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>());
         }
         double *pkvp = env_int("ADP_PK_VALUES", 1) ? h->pkv.as<double>() : nullptr; // (0: k_polya_peak gathers the heights from the trace, as before)
         if (upto >= 6) {
@@ -1390,18 +1343,17 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 } // extern "C++"
 
 extern "C++" {
-template <int NT, bool FIRST>
+template <int NT>
 static int launch_conv64s(adp_handle *h, const _Float16 *in, _Float16 *out, const _Float16 *wsp, const float *b, float sw, int n, int L1,
-                          int Lrows, int tiles, int32_t *flag, const float *x, int Lc, const float *w0, const float *b0)
+                          int Lrows, int tiles, int32_t *flag)
 {
     const size_t lds = (size_t)2 * (((size_t)(64 * NT + 6) * CNS_ROWB + 1023) / 1024 * 1024);
-    const unsigned bit = (FIRST ? 512u : 64u) << (NT - 2);
-    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
+    const unsigned bit = 64u << (NT - 2);
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
     long long total = (long long)n * tiles;
     if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64s"; return ADP_ERR_UNSUPPORTED; }
     int grid = (int)(total < h->n_cu ? total : h->n_cu);
-    hipLaunchKernelGGL((k_cnn_conv64s<NT, FIRST>), dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag,
-                       x, Lc, w0, b0);
+    hipLaunchKernelGGL((k_cnn_conv64s<NT>), dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
     return 0;
 }
 } // extern "C++"
@@ -1409,11 +1361,7 @@ static int launch_conv64s(adp_handle *h, const _Float16 *in, _Float16 *out, cons
 // the conv stack on split float16 operands (cnn_conv_split.h); the out-of-range flag is the second word of the call's arena counter
 static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepared, int n_reads, int Lc, int L1, int Lo, int NT, float *scores_out)
 {
-    // ADP_CNN_WG8=1 (round 4): the 64 -> 64 layers by k_cnn_conv64s8 -- eight waves per workgroup, two per SIMD, tiles of 128 positions
-    const bool wg8 = wh->cnn_wg8 && !wh->cnn_fuse_in; // (the fused first layer belongs to k_cnn_conv64s's tile geometry)
-    const bool pipe = wh->cnn_pipe && !wh->cnn_fuse_in && !wg8;
-    static_assert(CNP_PB == CNS8_PB, "the two 128-position kernels share the row geometry");
-    const int PB = (wg8 || pipe) ? CNS8_PB : 64 * NT, tiles = (L1 + PB - 1) / PB, Lrows = CNS_FRONT + tiles * PB + 4;
+    const int PB = 64 * NT, tiles = (L1 + PB - 1) / PB, Lrows = CNS_FRONT + tiles * PB + 4;
     const size_t per_read = (size_t)Lrows * CNS_ROWB;
     size_t cap_reads = ((size_t)4 << 30) / per_read; // two activation buffers of at most 4 GiB each
     if (cap_reads < 1) cap_reads = 1;
@@ -1437,7 +1385,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     // two activation buffers swap roles from chunk to chunk (X: layer 0's output and layer 2's; Y: layer 1's), so layer 0 of chunk c + 1
     // writes what layer 2 of chunk c has just finished READING while layer 3 of chunk c reads the other buffer; layer 1 of chunk c + 1 waits
     // for that layer 3 (it overwrites its input).  ADP_CNN_OVERLAP=0: everything in turn on one stream, as before.
-    const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0 && !wh->cnn_fuse_in;
+    const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0;
     if (overlap && !h->ev_conv[0]) {
         for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_conv[i], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     }
@@ -1448,47 +1396,18 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
         _Float16 *A = bufs[overlap ? (chunk & 1) : 0], *B = bufs[overlap ? 1 - (chunk & 1) : 1];
-        // ADP_CNN_FUSE_IN=1 (opt-in): layer 0 inside layer 1 (k_cnn_conv64s<NT, true>), no rows of layer 0 in HBM.  Measured per 2000
-        // reads of the 200 k window: 3.69 ms against 1.33 (1.04 since its row copy has no holes) + 2.25 for the two kernels (the rows cost the single wave per SIMD ~5 us per
-        // step in front of its MFMAs -- scalar weight loads, four dependent row rounds -- as much as the HBM round trip saved);
-        // 0.63 against 0.21 + 0.43 at the default window.
-        const bool fuse_in = wh->cnn_fuse_in;
-        if (!fuse_in) {
-            Scope s(h, "k_cnn_conv_in");
-            hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag);
-        }
+        { Scope s(h, "k_cnn_conv_in");
+          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
         if (out_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0)); out_pending = false; } // (layer 1 overwrites what that layer 3 reads)
         for (int layer = 0; layer < 2; layer++) {
-            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : (fuse_in ? "k_cnn_conv64 (layers 0 + 1)" : "k_cnn_conv64 (layer 1)"));
+            Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
             const _Float16 *in = layer ? B : A; _Float16 *out = layer ? A : B;
             const _Float16 *w = wsp + (size_t)layer * CNS_WSP_LAYER;
             const float *b = W + (layer ? CNN_B2 : CNN_B1);
             const float sw = wh->cnn_sw[layer];
-            int rc;
-            if (pipe) {
-                if (!(h->attr_done & 131072u)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64p, hipFuncAttributeMaxDynamicSharedMemorySize, CNP_LDS)); h->attr_done |= 131072u; }
-                const long long total = (long long)n * tiles;
-                if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64p"; return ADP_ERR_UNSUPPORTED; }
-                const int grid = (int)(total < h->n_cu ? total : h->n_cu);
-                hipLaunchKernelGGL(k_cnn_conv64p, dim3(grid), dim3(256), CNP_LDS, h->stream, in, out, w, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
-                rc = 0;
-            } else
-            if (wg8 && !fuse_in) {
-                if (!(h->attr_done & 65536u)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s8, hipFuncAttributeMaxDynamicSharedMemorySize, CNS8_LDS)); h->attr_done |= 65536u; }
-                const long long total = (long long)n * tiles;
-                if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64s8"; return ADP_ERR_UNSUPPORTED; }
-                const int grid = (int)(total < h->n_cu ? total : h->n_cu);
-                hipLaunchKernelGGL(k_cnn_conv64s8, dim3(grid), dim3(512), CNS8_LDS, h->stream, in, out, w, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag);
-                rc = 0;
-            } else
-            if (layer == 0 && fuse_in)
-                rc = NT == 4 ? launch_conv64s<4, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0)
-                   : NT == 3 ? launch_conv64s<3, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0)
-                             : launch_conv64s<2, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, x, Lc, W + CNN_W0, W + CNN_B0);
-            else
-                rc = NT == 4 ? launch_conv64s<4, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr)
-                   : NT == 3 ? launch_conv64s<3, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr)
-                             : launch_conv64s<2, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, 0, nullptr, nullptr);
+            const int rc = NT == 4 ? launch_conv64s<4>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
+                         : NT == 3 ? launch_conv64s<3>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
+                                   : launch_conv64s<2>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag);
             if (rc) return rc;
         }
         const bool last = s0 + C >= n_reads;
@@ -1959,7 +1878,7 @@ int adp_debug_fetch(adp_handle *h, int what, void *host_out, uint64_t bytes)
     case 5: src = h->polya_idx.p; break;
     case 6: { int32_t lp = h->Lp; if (bytes < 4) return ADP_ERR_INVALID; memcpy(host_out, &lp, 4); return ADP_OK; }
     case 7: src = h->t1.p; break;
-    case 9: src = h->vtodo.p; if (bytes > h->vtodo.cap) return ADP_ERR_INVALID; break; // k_validate_wg: 0 = handled, else VW_WHY_*
+    case 9: src = h->have_series.p; if (bytes > h->have_series.cap) return ADP_ERR_INVALID; break; // 1: the read's moving-window series were prepared by a series kernel
     case 8: { if (bytes < 64 || bytes > sizeof(unsigned long long) * ADP_NDBG) return ADP_ERR_INVALID;
               HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dbg), bytes, 0, hipMemcpyDeviceToHost));
               static unsigned long long tally[ADP_NTALLY][8];

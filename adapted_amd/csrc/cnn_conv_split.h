@@ -163,15 +163,11 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // Synchronisation per step: the tile's DMA is the OLDEST of the wave's outstanding vector-memory operations (it was issued before
 // the previous step's stores), so a counted s_waitcnt leaves those stores in flight; every store of the epilogue is issued
 // unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
-// FIRST: layer 1 with layer 0 inside -- no input rows in HBM at all: the workgroup makes the tile's rows itself, Conv1d(1 -> 64,
-// k 7, stride 3) + ReLU + split from the prepared signal x (the arithmetic of k_cnn_conv_in_s: wave q the channels 16 q .. 16 q + 15,
-// a lane a row), straight into the LDS tile.  Layer 0 as a kernel of its own writes 1.9 MB per read that layer 1 reads back.
-template <int NT, bool FIRST>
+template <int NT>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
-                                                        int32_t *__restrict__ flag, const float *__restrict__ x, int Lc,
-                                                        const float *__restrict__ w0 /* [64][1][7] */, const float *__restrict__ b0)
+                                                        int32_t *__restrict__ flag)
 {
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
@@ -214,64 +210,20 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     // hold what real neighbours hold, and a needless flag only costs the float32 repeat.)
     cnn_us2 hmax = {0, 0};
     const float cx = inv_sw * (1.0f / 2048.0f);
-    // FIRST: rows tile * PB - 3 .. of read n made from x into buffer b (rows outside [0, L1) are the zero padding)
-    auto make_rows = [&](int tix, int b) {
-        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
-        const float *xr = x + (size_t)n * Lc;
-        const float *wq = w0 + 16 * wave * CNN_K, *bq = b0 + 16 * wave;
-        for (int r = lane; r < R; r += 64) {
-            const int p = tile * PB - 3 + r;
-            const bool inside = p >= 0 && p < L1;
-            float v[CNN_K];
-#pragma unroll
-            for (int t = 0; t < CNN_K; t++) { const int i = 3 * p + t - 3; v[t] = (inside && i >= 0 && i < Lc) ? xr[i] : 0.f; }
-            LDS _Float16 *o = (LDS _Float16 *)(lds + b * TILE_B + r * CNS_ROWB) + 16 * wave;
-#pragma unroll
-            for (int c8 = 0; c8 < 2; c8++) {
-                cnn_h2 hq[4], lq[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int c = c8 * 8 + 2 * e;
-                    cnn_f2 acc = {bq[c], bq[c + 1]};
-#pragma unroll
-                    for (int t = 0; t < CNN_K; t++) acc = __builtin_elementwise_fma((cnn_f2){wq[c * CNN_K + t], wq[(c + 1) * CNN_K + t]}, (cnn_f2){v[t], v[t]}, acc);
-                    acc = __builtin_elementwise_max(acc, (cnn_f2){0.f, 0.f}) * CNS_ASCALE;
-                    if (!inside) acc = (cnn_f2){0.f, 0.f};
-                    const cnn_h2 hi = __builtin_convertvector(acc, cnn_h2);
-                    const cnn_f2 rs = (acc - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
-                    hq[e] = hi; lq[e] = __builtin_convertvector(rs, cnn_h2);
-                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
-                }
-                const cnn_h8 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1], hq[2][0], hq[2][1], hq[3][0], hq[3][1]};
-                const cnn_h8 ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1], lq[2][0], lq[2][1], lq[3][0], lq[3][1]};
-                *reinterpret_cast<LDS cnn_h8 *>(o + c8 * 8) = hh;
-                *reinterpret_cast<LDS cnn_h8 *>(o + 64 + c8 * 8) = ll;
-            }
-        }
-    };
-    if (!FIRST) {
-        if (it < total) dma(it, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (it < total) dma(it, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; it < total; it += gridDim.x) {
         // every wave has waited for its own share of tile `it` (before the loop / at the end of the previous step) and has
         // finished reading the other buffer
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (FIRST) {
-            // (one buffer: the staging rows of the step before have left it -- the barrier above -- and nothing is in flight)
-            make_rows(it, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
         // the next tile's LDS-DMA pieces are issued INSIDE the k-loop, one per k-step (a piece costs ~60 cycles of issue among MFMAs,
         // 100-185 in a burst in front of them: MI355X_MICROARCH.md), still older than this step's stores for the counted wait below
         // (NT = 4 sits at the register limit -- 512 with the accumulators of four tiles: there the pieces stay a burst at the step's top)
         constexpr bool INLOOP = NT < 4;
-        if (!FIRST && !INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
-        const bool more = !FIRST && INLOOP && it + gridDim.x < total;
+        if (!INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        const bool more = INLOOP && it + gridDim.x < total;
         const GLB char *nsrc = nullptr;
         if (more) {
             const int tix = it + gridDim.x, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
@@ -371,340 +323,17 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                 *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
             }
         }
-        if (!FIRST) {
-            // the DMA issued at the top of this step is older than these NSTORE stores
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
-            buf ^= 1;
-        }
-    }
-    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
-    if (__any(bad) && lane == 0) atomicOr(flag, 1);
-}
-
-// ---------------------------------------------------------------- layers 1, 2 with TWO waves per SIMD (round 4)
-// k_cnn_conv64s keeps one wave per SIMD (369 registers: both weight planes of 28 k-steps, the accumulators of four position tiles), and
-// that wave runs its phases in turn: DMA issue, 336 MFMAs, an epilogue of ~700 vector instructions, the copy-out -- the matrix pipe works
-// 0.37 of the time.  Here a workgroup has EIGHT waves = 2 channel halves x 4 position quarters of 32, two per SIMD, so that one's epilogue
-// and barrier waits lie under the other's MFMAs.  What makes a wave fit 256 registers: one position tile per wave (PB = 128 positions per
-// step), the hi weight plane in registers (112) and the lo plane in LDS (56 KB beside two 36 KB tiles = 128 KB per workgroup), read
-// per k-step like the activations.  Same GEMM orientation, fragments, accumulation order and epilogue arithmetic as k_cnn_conv64s: the
-// same scores, bit for bit.
-#define CNS8_PB 128
-#define CNS8_R (CNS8_PB + 6)
-#define CNS8_TILE_B ((CNS8_R * CNS_ROWB + 1023) / 1024 * 1024)
-#define CNS8_NDMA (CNS8_TILE_B / 1024)
-#define CNS8_WL_B (2 * CNS_KSTEPS * 64 * 16)
-#define CNS8_LDS (2 * CNS8_TILE_B + CNS8_WL_B)
-#define CNS8_NSTORE ((CNS8_PB * 17 + 511) / 512)
-__global__ void __launch_bounds__(512, 2) k_cnn_conv64s8(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
-                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
-                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
-                                                         int32_t *__restrict__ flag)
-{
-    extern __shared__ float cns_lds_raw[];
-    LDS char *lds = (LDS char *)cns_lds_raw;
-    LDS char *wl_lds = lds + 2 * CNS8_TILE_B;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mh = wave & 1, pq = wave >> 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    // A fragments: lane l holds W[o = 32 mh + (l & 31)][c = 16 cg + 8 (l >> 5) + e][t] of k-step 4 t + cg; hi plane in registers, lo plane in LDS
-    cnn_h8 wh[CNS_KSTEPS];
-    {
-        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(wsp) + (size_t)(mh * CNS_KSTEPS) * 2 * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < CNS_KSTEPS; k++) wh[k] = wp[(size_t)(k * 2) * 64];
-        // lo planes of both channel halves: [mh][k][lane] 16-byte pieces
-        const cnn_h8 *wa = reinterpret_cast<const cnn_h8 *>(wsp);
-        for (int i = threadIdx.x; i < 2 * CNS_KSTEPS * 64; i += 512) {
-            const int l = i & 63, k = (i >> 6) % CNS_KSTEPS, h2 = i / (64 * CNS_KSTEPS);
-            *reinterpret_cast<LDS cnn_h8 *>(wl_lds + (size_t)i * 16) = wa[((size_t)(h2 * CNS_KSTEPS + k) * 2 + 1) * 64 + l];
-        }
-    }
-    const LDS char *wlp = wl_lds + ((size_t)mh * CNS_KSTEPS * 64 + lane) * 16;
-    float bs[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE);
-
-    const int total = n_reads * tiles_per_read;
-    auto dma = [&](int tix, int b) {
-        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
-        const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * CNS8_PB) * CNS_ROWB + lane * 16;
-        for (int inst = wave; inst < CNS8_NDMA; inst += 8)
-            __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + b * CNS8_TILE_B + inst * 1024), 16, 0, 0);
-    };
-    int it = blockIdx.x;
-    int buf = 0;
-    cnn_us2 hmax = {0, 0};
-    const float cx = inv_sw * (1.0f / 2048.0f);
-    if (it < total) dma(it, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (; it < total; it += gridDim.x) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
-        // B fragment of k-step (t, cg): row pq * 32 + (lane & 31) + t, channels 16 cg + 8 (lane >> 5) ..
-        const LDS char *tb = lds + buf * CNS8_TILE_B + (pq * 32 + l31) * CNS_ROWB + lh * 16;
-        cnn_f32x16 am, ax;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { am[r] = bs[r]; ax[r] = 0.f; }
-        cnn_h8 fh[2], fl[2], wl[2];
-        fh[0] = *reinterpret_cast<const LDS cnn_h8 *>(tb);
-        fl[0] = *reinterpret_cast<const LDS cnn_h8 *>(tb + 128);
-        wl[0] = *reinterpret_cast<const LDS cnn_h8 *>(wlp);
-#pragma unroll
-        for (int k = 0; k < CNS_KSTEPS; k++) {
-            if (k + 1 < CNS_KSTEPS) {
-                const int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
-                fh[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(tb + t1 * CNS_ROWB + cg1 * 32);
-                fl[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(tb + t1 * CNS_ROWB + cg1 * 32 + 128);
-                wl[(k + 1) & 1] = *reinterpret_cast<const LDS cnn_h8 *>(wlp + (size_t)(k + 1) * 64 * 16);
-            }
-            am = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1], am, 0, 0, 0);
-            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k & 1], fh[k & 1], ax, 0, 0, 0);
-            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1], ax, 0, 0, 0);
-            asm volatile("" ::: "memory");
-        }
-        const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // every wave has read its last fragment of this buffer
-        asm volatile("" ::: "memory");
-        LDS char *stg = lds + buf * CNS8_TILE_B;
-        {
-            LDS char *srow = stg + (pq * 32 + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                cnn_h2 hq[2], lq[2];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const cnn_f2 a2 = {am[4 * g + 2 * q], am[4 * g + 2 * q + 1]}, x2 = {ax[4 * g + 2 * q], ax[4 * g + 2 * q + 1]};
-                    cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
-                    v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f});
-                    const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
-                    const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
-                    hq[q] = hi; lq[q] = __builtin_convertvector(rs, cnn_h2);
-                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
-                }
-                const cnn_h4 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1]};
-                *reinterpret_cast<LDS cnn_h4 *>(srow + 16 * g) = hh;
-                *reinterpret_cast<LDS cnn_h4 *>(srow + 128 + 16 * g) = ll;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        {
-            // rows tile * PB .. of read n; pieces of rows at or beyond L1 (and the pieces a thread has no row for) go to the read's row 0,
-            // which nothing reads, so that every store is issued and the count below stays exact
-            const int nvalid = (L1 - tile * CNS8_PB < CNS8_PB ? L1 - tile * CNS8_PB : CNS8_PB) * 17;
-            char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
-            char *obase = rbase + (size_t)(CNS_FRONT + tile * CNS8_PB) * CNS_ROWB;
-            cnn_h8 piece[CNS8_NSTORE];
-#pragma unroll
-            for (int c = 0; c < CNS8_NSTORE; c++) {
-                const int i = c * 512 + (int)threadIdx.x;
-                piece[c] = *reinterpret_cast<const LDS cnn_h8 *>(stg + (i < CNS8_PB * 17 ? i : 0) * 16);
-            }
-#pragma unroll
-            for (int c = 0; c < CNS8_NSTORE; c++) {
-                const int i = c * 512 + (int)threadIdx.x;
-                char *dst = i < nvalid ? obase + (size_t)i * 16 : rbase + (i % 17) * 16;
-                *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
-            }
-        }
-        // the DMA issued at the top of this step is older than these CNS8_NSTORE stores
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNS8_NSTORE) : "memory");
+        // the DMA issued at the top of this step is older than these NSTORE stores
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
         buf ^= 1;
     }
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
-// ---------------------------------------------------------------- layers 1, 2 with the EPILOGUE UNDER THE NEXT TILE'S MFMAs (round 4)
-// k_cnn_conv64s runs a tile's phases in turn in its one wave per SIMD: 252 MFMAs, then ~700 vector instructions of epilogue (fold the
-// cross terms, bias, ReLU, split, staging rows), then the copy-out -- the matrix pipe rests during a third of the step.  Here the
-// accumulators are DOUBLE: while the MFMAs of tile t fill one set, the epilogue arithmetic of tile t - 1 works through the other, cut
-// into 16 pieces that sit between the MFMAs of the first 16 k-steps (a 32 x 32 x 16 MFMA occupies the matrix pipe for 32 cycles; the
-// wave issues ~4 vector instructions in its shadow).  What makes the second set fit: PB = 128 positions per step (two position
-// tiles per wave: 2 x 64 accumulator registers beside the 224 of the weights) and a staging area of its own in LDS (the consumed tile
-// is the next DMA's target now): 2 x 36 KB of tiles + 34 KB.  Same fragments, same order of accumulation, same epilogue arithmetic
-// as k_cnn_conv64s: the same rows, bit for bit (tests/test_gpu_variants.py).
-#ifndef CNP_ABL
-#define CNP_ABL 0 // (development, timing only: 1 = no epilogue pieces, 2 = no copy-out, 4 = no MFMAs, 8 = no DMA)
-#endif
-#define CNP_NT 2
-#define CNP_PB (64 * CNP_NT)
-#define CNP_R (CNP_PB + 6)
-#define CNP_TILE_B ((CNP_R * CNS_ROWB + 1023) / 1024 * 1024)
-#define CNP_NDMA (CNP_TILE_B / 1024)
-#define CNP_STG_B (CNP_PB * CNS_ROWB)
-#define CNP_LDS (2 * CNP_TILE_B + CNP_STG_B)
-#define CNP_NSTORE ((CNP_PB * 17 + 255) / 256)
-#define CNP_NEPI (8 * CNP_NT) // epilogue pieces: (position tile, register group of four, pair)
-static_assert((CNP_NDMA + 3) / 4 <= CNS_KSTEPS && CNP_NEPI <= CNS_KSTEPS, "one DMA piece and one epilogue piece per k-step");
-__global__ void __launch_bounds__(256, 1) k_cnn_conv64p(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
-                                                        const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
-                                                        float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
-                                                        int32_t *__restrict__ flag)
-{
-    constexpr int NT = CNP_NT, PB = CNP_PB;
-    extern __shared__ float cns_lds_raw[];
-    LDS char *lds = (LDS char *)cns_lds_raw;
-    LDS char *stg = lds + 2 * CNP_TILE_B;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int mh = wave & 1, ph = wave >> 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-    cnn_h8 wh[CNS_KSTEPS], wl[CNS_KSTEPS];
-    {
-        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(wsp) + (size_t)(mh * CNS_KSTEPS) * 2 * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < CNS_KSTEPS; k++) { wh[k] = wp[(size_t)(k * 2) * 64]; wl[k] = wp[(size_t)(k * 2 + 1) * 64]; }
-    }
-    float bs[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) bs[r] = bias[32 * mh + (r & 3) + 8 * (r >> 2) + 4 * lh] * (sw * CNS_ASCALE);
-    const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
-    const int G = gridDim.x;
-    cnn_us2 hmax = {0, 0};
-    const float cx = inv_sw * (1.0f / 2048.0f);
-    cnn_f32x16 am[2][NT], ax[2][NT];
-    // this lane's staging rows (position tile j: + 32 j rows)
-    LDS char *srow0 = stg + (ph * (NT * 32) + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
-
-    // piece e of the epilogue of accumulator set S: position tile e >> 3, registers 4 g + 2 q, 4 g + 2 q + 1 (g = (e >> 1) & 3, q = e & 1)
-    auto epi = [&](auto Sc, auto Ec) {
-        constexpr int S = decltype(Sc)::value, e = decltype(Ec)::value, j = e >> 3, g = (e >> 1) & 3, q = e & 1;
-        const cnn_f2 a2 = {am[S][j][4 * g + 2 * q], am[S][j][4 * g + 2 * q + 1]}, x2 = {ax[S][j][4 * g + 2 * q], ax[S][j][4 * g + 2 * q + 1]};
-        cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
-        v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f});
-        const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
-        const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
-        const cnn_h2 lo = __builtin_convertvector(rs, cnn_h2);
-        hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
-        LDS char *d = srow0 + (32 * j) * CNS_ROWB + 16 * g + 4 * q;
-        *reinterpret_cast<LDS cnn_h2 *>(d) = hi;
-        *reinterpret_cast<LDS cnn_h2 *>(d + 128) = lo;
-    };
-    // the staged rows of tile (n, tile) leave as one contiguous range (rows at or beyond L1: to the read's dump row, as in k_cnn_conv64s)
-    auto copy_out = [&](int n, int tile) {
-        const int nvalid = (L1 - tile * PB < PB ? L1 - tile * PB : PB) * 17;
-        char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
-        char *obase = rbase + (size_t)(CNS_FRONT + tile * PB) * CNS_ROWB;
-        cnn_h8 piece[CNP_NSTORE];
-#pragma unroll
-        for (int c = 0; c < CNP_NSTORE; c++) {
-            const int i = c * 256 + (int)threadIdx.x;
-            piece[c] = *reinterpret_cast<const LDS cnn_h8 *>(stg + (i < PB * 17 ? i : 0) * 16);
-        }
-#pragma unroll
-        for (int c = 0; c < CNP_NSTORE; c++) {
-            const int i = c * 256 + (int)threadIdx.x;
-            char *dst = i < nvalid ? obase + (size_t)i * 16 : rbase + (i % 17) * 16;
-            *reinterpret_cast<cnn_h8 *>(dst) = piece[c];
-        }
-    };
-    int it = blockIdx.x, buf = 0;
-    int pn = 0, ptile = 0; // the tile whose results wait in the other accumulator set
-    // one tile: MFMAs into set P; EPI: the epilogue of the tile before (set 1 - P) in pieces among them, its copy-out behind them
-    auto step = [&](auto Pc, auto EPIc) {
-        constexpr int P = decltype(Pc)::value;
-        constexpr bool EPI = decltype(EPIc)::value;
-        // every wave has waited for its own share of tile `it`, has finished reading the other buffer and the staging rows
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool more = it + G < total;
-        const GLB char *nsrc = nullptr;
-        if (more) {
-            const int tix = it + G, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
-            nsrc = (const GLB char *)in + ((size_t)nn * Lrows + CNS_FRONT - 3 + (size_t)tile2 * PB) * CNS_ROWB + lane * 16;
-        }
-        LDS char *ndst = lds + (buf ^ 1) * CNP_TILE_B;
-        const LDS char *tb = lds + buf * CNP_TILE_B + (ph * (NT * 32) + l31) * CNS_ROWB + lh * 16;
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { am[P][j][r] = bs[r]; ax[P][j][r] = 0.f; }
-        cnn_h8 fh[2][NT], fl[2][NT];
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            fh[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB);
-            fl[0][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j) * CNS_ROWB + 128);
-        }
-        auto kstep = [&](auto Kc) {
-            constexpr int k = decltype(Kc)::value;
-            if (!(CNP_ABL & 8) && more && wave + 4 * k < CNP_NDMA)
-                __builtin_amdgcn_global_load_lds((const GLB float *)(nsrc + (wave + 4 * k) * 1024), (LDS float *)(ndst + (wave + 4 * k) * 1024), 16, 0, 0);
-            if (k + 1 < CNS_KSTEPS) {
-                constexpr int t1 = (k + 1) >> 2, cg1 = (k + 1) & 3;
-#pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    fh[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32);
-                    fl[(k + 1) & 1][j] = *reinterpret_cast<const LDS cnn_h8 *>(tb + (32 * j + t1) * CNS_ROWB + cg1 * 32 + 128);
-                }
-            }
-#if !(CNP_ABL & 4)
-#pragma unroll
-            for (int j = 0; j < NT; j++) am[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fh[k & 1][j], am[P][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; j++) ax[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[k], fh[k & 1][j], ax[P][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NT; j++) ax[P][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[k], fl[k & 1][j], ax[P][j], 0, 0, 0);
-#else
-#pragma unroll
-            for (int j = 0; j < NT; j++) { am[P][j][k & 15] += (float)fh[k & 1][j][0] * (float)wh[k][0]; ax[P][j][k & 15] += (float)fl[k & 1][j][0] * (float)wl[k][0]; }
-#endif
-            if constexpr (EPI && k < CNP_NEPI && !(CNP_ABL & 1)) epi(std::integral_constant<int, 1 - P>{}, std::integral_constant<int, k>{});
-            asm volatile("" ::: "memory");
-        };
-        cns_static_for<CNS_KSTEPS>(kstep);
-        if constexpr (EPI) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier(); // the staging rows are complete
-            asm volatile("" ::: "memory");
-            if constexpr (!(CNP_ABL & 2)) copy_out(pn, ptile);
-            // this step's DMA pieces are older than these stores
-            if constexpr (!(CNP_ABL & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNP_NSTORE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        pn = it / tiles_per_read; ptile = it - pn * tiles_per_read;
-        buf ^= 1;
-        it += G;
-    };
-    // the last tile's epilogue, nothing beside it
-    auto finish = [&](auto Sc) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier(); // (the copy-out before has read the staging rows)
-        asm volatile("" ::: "memory");
-        cns_static_for<CNP_NEPI>([&](auto Ec) { epi(Sc, Ec); });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        copy_out(pn, ptile);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    if (it < total) {
-        {   // the first tile: a burst, waited for
-            const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
-            const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * PB) * CNS_ROWB + lane * 16;
-            for (int inst = wave; inst < CNP_NDMA; inst += 4)
-                __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + inst * 1024), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        step(I0{}, std::false_type{});
-        for (;;) {
-            if (it >= total) { finish(I0{}); break; }
-            step(I1{}, std::true_type{});
-            if (it >= total) { finish(I1{}); break; }
-            step(I0{}, std::true_type{});
-        }
-    }
-    const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
-    if (__any(bad) && lane == 0) atomicOr(flag, 1);
-}
+// (Round 4, measured and dropped: the same layers with two waves per SIMD -- k_cnn_conv64s8, no gain -- and with a tile's epilogue under
+// the next tile's MFMAs -- k_cnn_conv64p, slower; layer 0 computed inside layer 1's kernel -- no gain.  Sources and records:
+// tools/experiments/r05_pruned_variants.patch, profiles/r04_tried_and_dropped.txt.)
 
 // ---------------------------------------------------------------- layer 3: ConvTranspose1d(64 -> 2, k 7, stride 3, pad 3) from split rows
 // the arithmetic of k_cnn_conv_out on a = hi + lo 2^-11; thread j makes the outputs 3 j, 3 j + 1, 3 j + 2 of both channels.

@@ -393,24 +393,19 @@ static __device__ int adapter_peak_read(P g, P bmx, P bmn, int n, int2 se, doubl
 }
 
 // grid = n_reads waves.  adapter_idx[r] = candidate in pooled units, or -1.
-// Two launches share the reads by trace length (round 4): STAGED takes the reads of at most stage_cap points -- trace and block
-// summaries copied into LDS first (dynamic LDS = APK_LDS_DOUBLES(stage_cap) doubles), the walks' dependent loads then cost an LDS
-// access instead of a trip to L2 / HBM -- and the other launch (which also answers for dropped minibatches) those beyond it;
-// stage_cap = 0: no staged launch, every read here.
-#define APK_LDS_DOUBLES(cap) ((cap) + 2 * (((cap) + 63) / 64))
-template <bool STAGED>
+// (Round 4, measured and dropped: traces of at most 2048 points walked from an LDS copy by a launch of their own -- 2.57 against
+// 2.68 ms at the 16 k window, 3.2 against 2.65 on heavy-tailed lengths: the walks are bound by their serial steps, not by where
+// the samples come from.  tools/experiments/r05_pruned_variants.patch)
 __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ trace, const int32_t *__restrict__ nvalid, int Lp,
                                                      const double *__restrict__ bmax, const double *__restrict__ bmin, int nsum,
                                                      const int2 *__restrict__ t1, int mbsize, const MbState *__restrict__ mbs,
                                                      double prominence, double rel_height, int width,
-                                                     int32_t *__restrict__ adapter_idx, const double *__restrict__ gstat, int stage_cap)
+                                                     int32_t *__restrict__ adapter_idx, const double *__restrict__ gstat)
 {
-    extern __shared__ double apk_raw[];
     const int r = blockIdx.x;
     const int ln = lane_id();
-    if (mbs[r / mbsize].status != ADP_MB_OK) { if (!STAGED && ln == 0) adapter_idx[r] = -1; return; }
+    if (mbs[r / mbsize].status != ADP_MB_OK) { if (ln == 0) adapter_idx[r] = -1; return; }
     const int n = nvalid[r];
-    if (STAGED ? n > stage_cap : n <= stage_cap) return; // the other launch's read
     int result = -1;
     if (n >= 3) {
         const double *g = trace + (size_t)r * Lp;
@@ -418,23 +413,7 @@ __global__ void __launch_bounds__(64) k_adapter_peak(const double *__restrict__ 
         const int2 se = t1[r];
         const double s1 = gstat[3 * r], s2 = gstat[3 * r + 1];
         const int nnan = (int)gstat[3 * r + 2];
-        if (STAGED) {
-            LDS double *xs = (LDS double *)apk_raw, *bxs = xs + stage_cap, *bns = bxs + (stage_cap + 63) / 64;
-            if (se.y - se.x >= 3) { // (else nothing is looked at)
-                for (int i0 = 0; i0 < n; i0 += 512) {
-                    double v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; v[u] = i < n ? g[i] : 0.0; }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + ln; if (i < n) xs[i] = v[u]; }
-                }
-                const int nb = (n + 63) / 64 < nsum ? (n + 63) / 64 : nsum;
-                for (int b = ln; b < nb; b += 64) { bxs[b] = bx[b]; bns[b] = bn[b]; }
-                ws_sync();
-            }
-            result = adapter_peak_read<const LDS double *>(xs, bxs, bns, n, se, s1, s2, nnan, prominence, rel_height, width);
-        } else
-            result = adapter_peak_read<const double *>(g, bx, bn, n, se, s1, s2, nnan, prominence, rel_height, width);
+        result = adapter_peak_read<const double *>(g, bx, bn, n, se, s1, s2, nnan, prominence, rel_height, width);
     }
     if (ln == 0) adapter_idx[r] = result;
 }

@@ -34,13 +34,15 @@ struct ValidateInT {
     float *scratch;            // [slots, 2, scratch_stride]
     int scratch_stride;
     const float *series;       // [n_reads, 2, series_cap] moving mean / var up to the largest candidate (k_mvs_series) or nullptr
-    const int8_t *have_series; // [n_reads]
+    const int8_t *have_series; // [n_reads] 1: `series` holds the read's moving mean / variance.  INVARIANT every series producer keeps
+                               // (k_mvs_series, k_mvs_series_wave, k_mvs_series_pipe): have = 0 for a slice with a NaN in it -- mvs_check
+                               // skips its own NaN scan for slices whose series came from a series kernel (tests/test_gpu_variants.py
+                               // plants NaN holes early in a slice and inside its last window and reads this flag back)
     int series_cap;
     const CandStat *cstat;     // [n_reads, kmax] the candidates' order statistics (k_cand_stats) or nullptr
     int32_t *op_arena;         // whole open_pores lists of the reads with more than ADP_MAX_OPEN_PORES entries
     unsigned int *op_used;     // entries handed out (may exceed op_cap: the host then grows the arena and repeats the kernel)
     unsigned int op_cap;
-    const int8_t *todo;        // nullptr: every read; else only the reads flagged 1 (what k_validate_wg, validate_wg.h, left alone)
 };
 
 static __device__ __forceinline__ bool in_range_d(double v, double lo, double hi) { return lo <= v && v <= hi; }
@@ -932,7 +934,6 @@ __global__ void __launch_bounds__(64, VAL_WPE) __attribute__((amdgpu_waves_per_e
     float *scr_mean = in.scratch + (size_t)blockIdx.x * 2 * in.scratch_stride;
     float *scr_var = scr_mean + in.scratch_stride;
     for (int r = blockIdx.x; r < in.n_reads; r += gridDim.x) {
-        if (in.todo && !in.todo[r]) continue; // (the workgroup kernel has finished this read)
         adp_row *row = rows + r;
         row_clear(row);
         if (ln == 0) { preq[r].valid = 0; if (sc) { sc->src = 0; sc->n = 0; } }

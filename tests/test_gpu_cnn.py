@@ -278,7 +278,7 @@ def test_device_topk_behind_given_argmaxes():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("conv", ["split", "split_fused", "f32"])
+@pytest.mark.parametrize("conv", ["split", "f32"])
 @pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4)])
 def test_hip_conv_stack_equals_torch(Lc, n, conv, monkeypatch):
     """C2: the hand-written conv stacks (adp_cnn_forward) against torch's float32 conv1d / conv_transpose1d on the same device
@@ -288,8 +288,7 @@ def test_hip_conv_stack_equals_torch(Lc, n, conv, monkeypatch):
     scale for both (the golden test pins the scores themselves)."""
     import torch
 
-    monkeypatch.setenv("ADP_CNN_CONV", conv.split("_")[0])
-    monkeypatch.setenv("ADP_CNN_FUSE_IN", "1" if conv.endswith("fused") else "0")  # (layer 0 inside layer 1's kernel: opt-in)
+    monkeypatch.setenv("ADP_CNN_CONV", conv)
 
     from adapted_amd import lib
     from adapted_amd.detect import cnn

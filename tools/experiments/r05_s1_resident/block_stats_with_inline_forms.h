@@ -44,13 +44,16 @@ extern __device__ unsigned long long g_dbg[ADP_NDBG]; // debug tallies (adp_debu
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// NT_: threads of the workgroup (NW waves, each with eight staging rows).  The product runs 256 x 5 per CU; 512 x 2 and 1024 x 1
-// were measured slower (profiles/r05_tried_and_dropped.txt)
-template <int NT_>
+// NT_: threads of the workgroup (NW waves, each with eight staging rows); INL_: the selections and bucket searches are inlined
+// into the caller (block_stats_res.h: nothing may be called while a read's resident slabs sit in registers)
+// STAGE_: floats of the staging area (eight rows per wave for the staged slabs; block_stats_res.h stages nothing and keeps only what
+// the bucket search and the selections use as scratch)
+template <int NT_, bool INL_ = false, int STAGE_ = (NT_ / 64) * 8 * BS_LEAF_STRIDE>
 struct BlockScratchT {
-    static constexpr int NT = NT_, NW = NT_ / 64, STAGE = NW * 8 * BS_LEAF_STRIDE;
+    static constexpr int NT = NT_, NW = NT_ / 64, STAGE = STAGE_;
+    static constexpr bool INLINE = INL_;
     union {
-        float stage[STAGE];
+        float stage[STAGE_];
         WaveScratch ws; // generic wave-level fallbacks reuse the staging area
     } u;
     uint32_t hist[BS_BINS + 4]; // pass A: below-window cell, BS_BINS bins, above-window cell (bs_bins); pass B: MAD bracket samples (as float); passes C/D: hist18 + collect18
@@ -66,6 +69,17 @@ struct BlockScratchT {
     unsigned char slot_used[128];
 };
 typedef BlockScratchT<BS_THREADS> BlockScratch;
+
+// The thread's index inside a helper.  For the scratch types whose helpers are inlined into ONE long persistent loop (block_stats_res.h)
+// it passes through an empty volatile asm: the compiler would otherwise hoist every address and constant a helper derives from the
+// index out of that loop and hold them in registers for the whole kernel (65 of 256 there), beside the resident slabs
+template <class BS>
+static __device__ __forceinline__ int bs_tid()
+{
+    int t = threadIdx.x;
+    if constexpr (BS::INLINE) asm volatile("" : "+v"(t));
+    return t;
+}
 
 // samples of the median's bucket: behind the MAD bracket's in the histogram's storage (BS_MADCAP + BS_MEDCAP <= BS_BINS)
 template <class BS>
@@ -96,7 +110,7 @@ static __device__ __forceinline__ float bs_x2(float x, int mode, float c)
 template <class BS>
 static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BS *bs)
 {
-    const int tid = threadIdx.x;
+    const int tid = bs_tid<BS>();
     if (bs->tail_cached == tail) return; // (uniform: written by one thread behind a barrier)
     __syncthreads();
     int off = 0, len = tail;
@@ -131,7 +145,7 @@ static __device__ __forceinline__ void bs_tail_leaves(int tail, LDS BS *bs)
 template <class BS>
 static __device__ __forceinline__ float bs_tail_tree(LDS BS *bs)
 {
-    const int ln = threadIdx.x; // (< 64)
+    const int ln = bs_tid<BS>(); // (< 64)
     float v0 = bs->tleaf[2 * ln], v1 = bs->tleaf[2 * ln + 1];
     bool u0 = bs->slot_used[2 * ln] != 0, u1 = bs->slot_used[2 * ln + 1] != 0;
     float v = u1 ? v0 + v1 : v0; // level 6 (64 nodes, one per lane)
@@ -456,10 +470,10 @@ static __device__ __noinline__ SumAux block_np_sum(X x, int n, int mode, float c
 // Scratch: the head of the staging rows (x lives in the histogram's storage).  All threads return the values.
 #define BSEL_CAP 3072
 template <class BS>
-static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs,
-                                                      float &vk, float &vkm1)
+static __device__ __forceinline__ void block_select2_lds_i(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs,
+                                                         float &vk, float &vkm1)
 {
-    const int tid = threadIdx.x, ln = tid & 63;
+    const int tid = bs_tid<BS>(), ln = tid & 63;
     LDS uint32_t *sc = (LDS uint32_t *)bs->u.stage; // [0, 512): two histograms; 512: min key, 513: max key, 514: below, 515: NaN seen
     uint32_t key[BSEL_CAP / BS::NT];
     uint32_t mn = 0xffffffffu, mx = 0u;
@@ -561,6 +575,19 @@ static __device__ __noinline__ void block_select2_lds(const LDS float *x, int n,
     __syncthreads();
 }
 
+template <class BS>
+static __device__ __noinline__ void block_select2_lds_call(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs, float &vk, float &vkm1)
+{
+    block_select2_lds_i(x, n, k, mode, c, bs, vk, vkm1);
+}
+// (a called function by default; inlined for the scratch types that ask for it: BlockScratchT<.., true>)
+template <class BS>
+static __device__ __forceinline__ void block_select2_lds(const LDS float *x, int n, int k, int mode, float c, LDS BS *bs, float &vk, float &vkm1)
+{
+    if constexpr (BS::INLINE) block_select2_lds_i(x, n, k, mode, c, bs, vk, vkm1);
+    else block_select2_lds_call(x, n, k, mode, c, bs, vk, vkm1);
+}
+
 // A SHORT segment (the poly(A) slice, the adapter) is read from global memory ONCE, into LDS; its sums and selections run there.
 // BS_SMALLCAP: the staging rows and the histogram storage taken together (they are adjacent in BlockScratch).
 #define BS_SMALLCAP (BS::STAGE + BS_BINS)
@@ -631,9 +658,9 @@ static __device__ __forceinline__ uint32_t bs_window_lo(float pivot)
 // locate the bucket holding rank k in h[0..NB) (with `under` samples before it); sets bs->bin/before,
 // bs->flag = 1 if the rank lies outside
 template <int NB, class BS>
-static __device__ __noinline__ void block_find_bin(LDS BS *bs, const LDS uint32_t *hh, int k, int under)
+static __device__ __forceinline__ void block_find_bin_i(LDS BS *bs, const LDS uint32_t *hh, int k, int under)
 {
-    const int tid = threadIdx.x;
+    const int tid = bs_tid<BS>();
     constexpr int PER = (NB + BS::NT - 1) / BS::NT;
     uint32_t h[PER];
     int s = 0;
@@ -657,12 +684,21 @@ static __device__ __noinline__ void block_find_bin(LDS BS *bs, const LDS uint32_
     __syncthreads();
 }
 
+template <int NB, class BS>
+static __device__ __noinline__ void block_find_bin_call(LDS BS *bs, const LDS uint32_t *hh, int k, int under) { block_find_bin_i<NB>(bs, hh, k, under); }
+template <int NB, class BS>
+static __device__ __forceinline__ void block_find_bin(LDS BS *bs, const LDS uint32_t *hh, int k, int under)
+{
+    if constexpr (BS::INLINE) block_find_bin_i<NB>(bs, hh, k, under);
+    else block_find_bin_call<NB>(bs, hh, k, under);
+}
+
 struct SegStats { float mean, sd, med, mad; };
 
 // exact median from the collected bucket (wave 0), given the largest key below the bucket
 template <class BS>
-static __device__ __noinline__ float bs_median_from_bucket(LDS BS *bs, const LDS float *buf, int cnt, int n, int rk,
-                                                           uint32_t below_key)
+static __device__ __forceinline__ float bs_median_from_bucket_i(LDS BS *bs, const LDS float *buf, int cnt, int n, int rk,
+                                                              uint32_t below_key)
 {
     __syncthreads();
     float vk, vkm1;
@@ -673,6 +709,12 @@ static __device__ __noinline__ float bs_median_from_bucket(LDS BS *bs, const LDS
         res = (lo + vk) / 2.0f;
     }
     return res;
+}
+
+template <class BS>
+static __device__ __noinline__ float bs_median_from_bucket(LDS BS *bs, const LDS float *buf, int cnt, int n, int rk, uint32_t below_key)
+{
+    return bs_median_from_bucket_i(bs, buf, cnt, n, rk, below_key);
 }
 
 // largest key below `key_lo` among x[0..n) (0 if none) -- all threads return it
@@ -838,9 +880,9 @@ static __device__ __noinline__ float bs_mad_two_pass(X x, int n, LDS BS *bs, flo
 // After pass A: predict where the MAD lies from the bucket histogram.  Returns false if no prediction.
 // c = centre of the median's bucket, w0 = its width; [P, Q] = bracket of distances to c.
 template <class BS>
-static __device__ __noinline__ bool bs_predict_mad(LDS BS *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
+static __device__ __forceinline__ bool bs_predict_mad_i(LDS BS *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
 {
-    const int tid = threadIdx.x;
+    const int tid = bs_tid<BS>();
     LDS uint32_t *dh = (LDS uint32_t *)bs->u.stage; // distance histogram, BS_BINS cells of width w0
     __syncthreads();
     for (int i = tid; i < BS_BINS; i += BS::NT) dh[i] = 0;
@@ -863,6 +905,12 @@ static __device__ __noinline__ bool bs_predict_mad(LDS BS *bs, uint32_t wlo, int
     if (P < 0.f) P = 0.f;
     Q = (float)(j + 4) * w0;
     return true;
+}
+
+template <class BS>
+static __device__ __noinline__ bool bs_predict_mad(LDS BS *bs, uint32_t wlo, int k1, float c, float w0, float &P, float &Q)
+{
+    return bs_predict_mad_i(bs, wlo, k1, c, w0, P, Q);
 }
 
 // mean / std / median / MAD of x[0..n), n >= 1.  have_medmad: reuse med_in / mad_in (adapter partition).
