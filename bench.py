@@ -204,7 +204,8 @@ def cpu_worker_count(requested):
 
 def host_pipeline_bench(args, spc, device):
     """PCIe-inclusive rate: minibatches assembled in host memory (a memcpy per minibatch out of a small pool stands in for
-    the reader), pinned staging, H2D, detect, rows back.  One JSON line of its own."""
+    the reader), pinned staging, H2D, detect, rows back.  Returns the JSON object (--host-pipeline prints it as a line of its
+    own; the default run attaches three of them as secondary.host_pipeline)."""
     import threading
 
     import torch
@@ -295,13 +296,15 @@ def host_pipeline_bench(args, spc, device):
     bps = 2 if i16 else 4
     per_read = (float(offs[-1]) / mb) if ragged else float(m)  # samples that cross PCIe per read
     gb = total * per_read * bps / 1e9
-    print(json.dumps({"metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads, HOST buffers (PCIe-inclusive; not the headline)",
+    del pool, d
+    torch.cuda.empty_cache()
+    return ({"metric": "reads/sec (adapter+polyA detect), RNA004 200k-sample reads, HOST buffers (PCIe-inclusive; not the headline)",
                       "value": total / dt, "unit": "reads/s", "n_gpus": 1, "minibatches": args.host_pipeline,
                       "h2d_GB_per_s": gb / dt, "pass_rate": n_ok[0] / max(total + total2, 1),
                       "without_host_assembly": {"value": total2 / dt2, "h2d_GB_per_s": total2 * per_read * bps / 1e9 / dt2},
                       "input": ("int16 ADC + device calibration" if i16 else "float32 pA") + (", reads packed back to back (ragged)" if ragged else ", padded [N, m] matrix"),
                       "lens": "%s (mean %.0f of m = %d samples preloaded)" % (args.lens, float(take.mean()), m), "fill_threads": K,
-                      "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}}))
+                      "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}})
 
 
 CNN_FLOP_PER_POS = 2.0 * (64 * 7 + 2 * 64 * 64 * 7 + 64 * 2 * 7)  # F_alg = this x L1 per read
@@ -455,9 +458,16 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS workload shape, where one was taken (else null)
         traffic = None
         shape = None
-        if w.primary == "llr" and w.lens == "full" and w.adc_step == 0 and NS == 1 and os.environ.get("ADP_GROUPS", "1") == "1":
-            shape = "int16" if getattr(w, "int16", False) else "f32"
-        tnames = {"f32": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "int16": ("r04_traffic_int16.json", "r03_traffic_int16.json", "r02_traffic_int16.json")}.get(shape, ())
+        if w.primary == "llr" and w.adc_step == 0 and NS == 1 and os.environ.get("ADP_GROUPS", "1") == "1" and not w.no_start_peak:
+            if w.lens == "full" and w.max_obs_trace == 200000:
+                shape = "int16" if getattr(w, "int16", False) else "f32"
+            elif w.lens == "pareto" and w.max_obs_trace == 200000 and not getattr(w, "int16", False):
+                shape = "pareto"
+            elif w.lens == "full" and w.max_obs_trace == 16000 and not getattr(w, "int16", False):
+                shape = "default_window"
+        tnames = {"f32": ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"),
+                  "int16": ("r05_traffic_int16.json", "r04_traffic_int16.json", "r03_traffic_int16.json", "r02_traffic_int16.json"),
+                  "pareto": ("r05_traffic_pareto.json",), "default_window": ("r05_traffic_default_window.json",)}.get(shape, ())
         for tname in tnames:
             tfile = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tfile):
@@ -531,9 +541,14 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                                    "frac": 3.0 * f64l / (ms64 * 1e-3) / 1e12 / F16_MFMA_PEAK_TF, "traffic": None,
                                    "kernel_ms": ms64, "executed_flop_per_launch": 3.0 * f64l, "algorithmic_flop_per_launch": f_alg,
                                    "hbm_GBps_of_the_two_layers": 4.0 * rows_b / (ms64 * 1e-3) / 1e9,
-                                   "conv_stack_ms": conv_ms, "f32_equivalent_tflops": f_eq, "vs_f32_matrix_peak": f_eq / F32_MFMA_PEAK_TF,
-                                   "whole_path_frac": CNN_FLOP_PER_POS * L1 * R / step_s / 1e12 / F32_MFMA_PEAK_TF,
-                                   "whole_path_frac_note": "float32-equivalent FLOP/s of the whole step over the FLOAT32 matrix peak (157.3), the bound SURVEY 8(d) names; above 1 is possible since the stack left that pipe",
+                                   "conv_stack_ms": conv_ms, "f32_equivalent_tflops": f_eq,
+                                   # the step's float32-equivalent FLOP/s over the rate this stack can reach at best: three float16 MFMAs per
+                                   # block of products = a third of the float16 matrix peak (833 TF); never above 1
+                                   "whole_path_frac": CNN_FLOP_PER_POS * L1 * R / step_s / 1e12 / (F16_MFMA_PEAK_TF / 3.0),
+                                   # the same rates over the FLOAT32 matrix pipe's peak (157.3 TF, the bound SURVEY 8(d) names): speed-ups, not
+                                   # fractions -- the stack left that pipe
+                                   "conv_stack_speed_vs_f32_matrix_pipe": f_eq / F32_MFMA_PEAK_TF,
+                                   "whole_path_speed_vs_f32_matrix_pipe": CNN_FLOP_PER_POS * L1 * R / step_s / 1e12 / F32_MFMA_PEAK_TF,
                                    "whole_path_hbm_frac": (4.0 * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS,
                                    "slowest_kernel": dom, "slowest_kernel_ms": kavg[dom]}
                 out["dtype"] = "f32 (conv net: split float16 MFMA at float32 accuracy; statistics f32)"
@@ -642,7 +657,7 @@ def main():
                     help="llr: BASELINE configs[1] (default, the headline); cnn: configs[2] (hand-written conv head)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary workloads (configs[2] at the 200 k and the default window, configs[4]'s Pareto lengths, int16 input, two streams) that a "
-                         "default 1-GPU run attaches to its JSON line")
+                         "default 1-GPU run attaches to its JSON line (and the three PCIe-inclusive host-pipeline runs)")
     ap.add_argument("--with-grouped", action="store_true", help="add the grouped-execution timeline experiment (ADP_GROUPS=9 over 3 lanes) to the secondaries")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines (HIP streams) per GPU; each owns reads/streams whole minibatches and runs in its own host thread")
@@ -720,7 +735,8 @@ def main():
             os.close(saved_fd)
 
     if args.host_pipeline > 0:
-        return host_pipeline_bench(args, make_spc(args.max_obs_trace), local)
+        print(json.dumps(host_pipeline_bench(args, make_spc(args.max_obs_trace), local)))
+        return
     out = run_workload(args, rank, world, local, dist, backend, cpu_pool, cpu_procs)
     if cpu_pool is not None:
         cpu_pool.close()
@@ -741,8 +757,9 @@ def main():
                 ("cnn_default", dict(primary="cnn", max_obs_trace=16000, reads=32000, steps=4, warmup=1)),
                 ("pareto", dict(lens="pareto", steps=4, warmup=1)),
                 # the reference's own defaults: the preset's 16 000-sample window, 1000 reads per minibatch
-                ("llr_default_window", dict(max_obs_trace=16000, steps=4, warmup=1)),
-                ("int16", dict(int16=True, steps=4, warmup=1))]
+                ("llr_default_window", dict(max_obs_trace=16000, steps=4, warmup=1))]
+        # (the int16-resident workload left the line in round 5: its rows equal the float32 path's, its step takes the same time --
+        # `--int16` still runs it)
         if args.with_grouped:
             # the headline cut into groups of minibatches software-pipelined over three internal streams (adp_detect_llr's opt-in
             # grouped execution): a TIMELINE experiment -- its kernels overlap each other, so it carries no roofline object
@@ -768,8 +785,24 @@ def main():
                          "workload": o["config"]["workload"], "pass_rate": o["config"]["pass_rate"],
                          "roofline": None if name == "grouped" else
                          {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "whole_path_frac",
-                                             "f32_equivalent_tflops", "vs_f32_matrix_peak", "slowest_kernel", "slowest_kernel_ms") if k in rf}}
+                                             "f32_equivalent_tflops", "conv_stack_speed_vs_f32_matrix_pipe", "whole_path_speed_vs_f32_matrix_pipe",
+                                             "slowest_kernel", "slowest_kernel_ms") if k in rf}}
         out["secondary"] = sec
+        # PCIe-inclusive (SURVEY 8(d) "report H2D-inclusive end-to-end separately"): 12 minibatches from pinned host staging through
+        # adapted_amd.pipeline -- the padded float32 matrix, raw int16 samples + device calibration, and Pareto lengths packed back to back
+        hp = {}
+        for name, kw in (("f32_padded", dict()), ("int16_padded", dict(int16=True)), ("int16_ragged_pareto", dict(int16=True, ragged=True, lens="pareto"))):
+            w = argparse.Namespace(**vars(args))
+            w.host_pipeline, w.fill_threads, w.group = 12, 4, 4
+            for k, v in kw.items():
+                setattr(w, k, v)
+            try:
+                o = host_pipeline_bench(w, make_spc(args.max_obs_trace), local)
+                hp[name] = {"value": o["value"], "unit": o["unit"], "h2d_GB_per_s": o["h2d_GB_per_s"], "input": o["input"], "lens": o["lens"],
+                            "minibatches": o["minibatches"], "without_host_assembly": o["without_host_assembly"], "pass_rate": o["pass_rate"]}
+            except Exception as e:  # (a box short of pinnable host memory: the headline stands without it)
+                hp[name] = {"error": repr(e)[:200]}
+        sec["host_pipeline"] = hp
         # per-kernel times of every workload of this run: a file beside the line (the line itself must survive a log tail)
         try:
             ddir = os.path.join(ROOT, "gpurun_out")
@@ -783,9 +816,13 @@ def main():
         # (roofline: HBM for the LLR workloads, the matrix cores for the CNN ones -- the objects above say which)
         out["summary"] = {"headline": [round(out["value"]), round(out["roofline"]["frac"], 4), round(out["roofline"]["whole_path_frac"], 4)]}
         for name, o in sec.items():
+            if name == "host_pipeline":
+                continue
             rf = o["roofline"] or {}
             out["summary"][name] = [round(o["value"]), round(rf["frac"], 4) if "frac" in rf else None,
                                     round(rf["whole_path_frac"], 4) if "whole_path_frac" in rf else None]
+        # PCIe-inclusive entries: [reads/s, GB/s across PCIe] -- never the headline value
+        out["summary"]["host_pipeline"] = {k: ([round(v["value"]), round(v["h2d_GB_per_s"], 1)] if "value" in v else None) for k, v in sec["host_pipeline"].items()}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -39,7 +39,19 @@ def test_bench_json_contract():
     tail = lines[0][-2000:]
     assert '"summary"' in tail, tail[:200]
     sm = json.loads(tail[tail.index('"summary"') + len('"summary": '):-1])
-    for k in ("headline", "cnn_200k", "cnn_200k_f32_stack", "cnn_default", "pareto", "llr_default_window", "int16"):
+    for k in ("headline", "cnn_200k", "cnn_200k_f32_stack", "cnn_default", "pareto", "llr_default_window"):
         assert k in sm and sm[k][0] > 0, k
         assert d["secondary"][k]["roofline"]["frac"] == pytest.approx(sm[k][1], abs=1e-4) if k != "headline" else True
-    assert len(json.dumps(sm)) < 1200 and "grouped" not in d["secondary"]
+        # no fraction of a peak above 1 anywhere on the line
+        assert 0 < sm[k][1] <= 1.0 and 0 < sm[k][2] <= 1.0, (k, sm[k])
+        if k != "headline":
+            for name, v in d["secondary"][k]["roofline"].items():
+                if name.endswith("frac"):
+                    assert v <= 1.0, (k, name, v)
+    # the PCIe-inclusive runs: [reads/s, GB/s across PCIe] each, below what PCIe Gen5 x16 can carry
+    hp = sm["host_pipeline"]
+    for k in ("f32_padded", "int16_padded", "int16_ragged_pareto"):
+        assert hp[k] is not None and hp[k][0] > 0 and 0 < hp[k][1] < 64.0, (k, hp[k])
+        assert d["secondary"]["host_pipeline"][k]["minibatches"] == 12
+    assert hp["f32_padded"][0] < sm["headline"][0]  # (never the headline)
+    assert len(json.dumps(sm)) < 1400 and "grouped" not in d["secondary"] and "int16" not in sm
