@@ -112,6 +112,8 @@ struct adp_handle {
     size_t lds_series_set = 0;
 };
 
+static int env_int(const char *name, int dflt);
+
 static int geom(adp_handle *h)
 {
     const adp_cfg &c = h->cfg;
@@ -184,7 +186,7 @@ static int alloc_all(adp_handle *h, int reads, bool llr)
     h->pslots = (int)(R < 8192 ? R : 8192);
     if (llr) {
     bad |= h->pk.ensure(R * (Lp / 2 + 1) * 4);   // per-read peak lists (k_gains -> k_polya_peak)
-    bad |= h->pkv.ensure(R * (Lp / 2 + 1) * 8);  // ... and the maxima's heights
+    if (env_int("ADP_PK_VALUES", 1)) bad |= h->pkv.ensure(R * (Lp / 2 + 1) * 8);  // ... and the maxima's heights (twice the list's size: only when they are used)
     bad |= h->npk.ensure(R * 4);
     bad |= h->mk.ensure((size_t)h->pslots * (Lp / 2 + 1) * 4);
     }
@@ -739,7 +741,8 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
                                h->cfg.adapter_peak_prominence, h->cfg.adapter_peak_rel_height,
                                h->cfg.adapter_peak_width / h->ds, h->adapter_idx.as<int32_t>(), h->gstat.as<double>());
         }
-        double *pkvp = env_int("ADP_PK_VALUES", 1) ? h->pkv.as<double>() : nullptr; // (0: k_polya_peak gathers the heights from the trace, as before)
+        // (ADP_PK_VALUES=0: k_polya_peak gathers the heights from the trace, as before round 4; a handle made without the buffer keeps doing so)
+        double *pkvp = (env_int("ADP_PK_VALUES", 1) && h->pkv.cap >= (size_t)n * (h->Lp / 2 + 1) * 8) ? h->pkv.as<double>() : nullptr;
         if (upto >= 6) {
             Scope s(h, "k_gains<2>");
             hipLaunchKernelGGL(k_gains<2>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,
@@ -1391,6 +1394,9 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     }
     int chunk = 0;
     bool out_pending = false; // a layer 3 on the side stream that the main stream has not waited for yet
+    // an error return from inside the chunk loop must not leave that layer 3 running: the caller's repeat (or its float32 fallback)
+    // reuses the activation buffers and the scores on the main stream
+    struct SideJoin { hipStream_t side; bool *pending; ~SideJoin() { if (*pending) (void)hipStreamSynchronize(side); } } side_join{h->stream2, &out_pending};
     for (int s0 = 0; s0 < n_reads; s0 += C, chunk++) {
         const int n = n_reads - s0 < C ? n_reads - s0 : C;
         const float *x = prepared + (size_t)s0 * Lc;
@@ -1417,7 +1423,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
           hipLaunchKernelGGL(k_cnn_conv_out_s, dim3((L1 + CNS_OUT_P - 1) / CNS_OUT_P, n), dim3(CNS_OUT_P), 0, so, A, L1, Lrows, Lo, W + CNN_W3S, W + CNN_B3, sc); }
         if (so != h->stream) { HIPCHK(hipEventRecord(h->ev_conv[1 + (chunk & 1)], so)); out_pending = true; }
     }
-    if (out_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0));
+    if (out_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0)); out_pending = false; }
     return 0;
 }
 

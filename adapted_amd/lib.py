@@ -138,44 +138,56 @@ def hip_runtimes() -> List[str]:
 
 
 def _elf_dynamic(path: str):
-    """(SONAME or None, [DT_NEEDED names]) of a little-endian ELF64 shared object -- read from the file, nothing is loaded"""
+    """(SONAME or None, [DT_NEEDED names]) of a little-endian ELF64 shared object -- read from the file, nothing is loaded
+    (the ELF header, the program headers, the dynamic section and the strings it names: a few KB of a multi-MB runtime)"""
     import struct
 
     with open(path, "rb") as fh:
-        data = fh.read()
-    if data[:6] != b"\x7fELF\x02\x01":
-        raise ValueError("not a little-endian ELF64 file: %s" % path)
-    e_phoff, = struct.unpack_from("<Q", data, 0x20)
-    e_phentsize, e_phnum = struct.unpack_from("<HH", data, 0x36)
-    loads, dyn = [], None
-    for i in range(e_phnum):
-        p_type, _flags, p_offset, p_vaddr, _paddr, p_filesz = struct.unpack_from("<IIQQQQ", data, e_phoff + i * e_phentsize)
-        if p_type == 1:
-            loads.append((p_vaddr, p_offset, p_filesz))
-        elif p_type == 2:
-            dyn = (p_offset, p_filesz)
-    if dyn is None:
-        return None, []
+        def at(off, size):
+            fh.seek(off)
+            return fh.read(size)
 
-    def off_of(vaddr):
-        for va, off, sz in loads:
-            if va <= vaddr < va + sz:
-                return off + (vaddr - va)
-        raise ValueError("address outside the file's segments")
+        head = at(0, 0x40)
+        if head[:6] != b"\x7fELF\x02\x01":
+            raise ValueError("not a little-endian ELF64 file: %s" % path)
+        e_phoff, = struct.unpack_from("<Q", head, 0x20)
+        e_phentsize, e_phnum = struct.unpack_from("<HH", head, 0x36)
+        ph = at(e_phoff, e_phentsize * e_phnum)
+        loads, dyn = [], None
+        for i in range(e_phnum):
+            p_type, _flags, p_offset, p_vaddr, _paddr, p_filesz = struct.unpack_from("<IIQQQQ", ph, i * e_phentsize)
+            if p_type == 1:
+                loads.append((p_vaddr, p_offset, p_filesz))
+            elif p_type == 2:
+                dyn = (p_offset, p_filesz)
+        if dyn is None:
+            return None, []
 
-    tags = []
-    for o in range(dyn[0], dyn[0] + dyn[1], 16):
-        tag, val = struct.unpack_from("<qQ", data, o)
-        if tag == 0:
-            break
-        tags.append((tag, val))
-    strtab = off_of(next(v for t, v in tags if t == 5))
+        def off_of(vaddr):
+            for va, off, sz in loads:
+                if va <= vaddr < va + sz:
+                    return off + (vaddr - va)
+            raise ValueError("address outside the file's segments")
 
-    def name(v):
-        end = data.index(b"\0", strtab + v)
-        return data[strtab + v:end].decode()
+        tags = []
+        dsec = at(dyn[0], dyn[1])
+        for o in range(0, len(dsec) - 15, 16):
+            tag, val = struct.unpack_from("<qQ", dsec, o)
+            if tag == 0:
+                break
+            tags.append((tag, val))
+        strtab = off_of(next(v for t, v in tags if t == 5))
 
-    return next((name(v) for t, v in tags if t == 14), None), [name(v) for t, v in tags if t == 1]
+        def name(v):
+            buf = b""
+            while b"\0" not in buf:  # (names are short: one or two reads)
+                more = at(strtab + v + len(buf), 256)
+                if not more:
+                    break
+                buf += more
+            return buf.split(b"\0", 1)[0].decode()
+
+        return next((name(v) for t, v in tags if t == 14), None), [name(v) for t, v in tags if t == 1]
 
 
 def _share_torch_runtime(lib_path: Optional[str] = None):
@@ -207,6 +219,30 @@ def _share_torch_runtime(lib_path: Optional[str] = None):
         pass
 
 
+def assert_one_runtime():
+    """Raise HipLibraryError when two HIP runtimes are mapped into this process AND torch is imported: torch's device context and
+    this library's would not see each other (RCCL, events, allocations).  Without torch a second mapped copy is idle and harmless.
+    Checked when the library is loaded and again at every entry point that hands torch's device memory to the library or the
+    library's rows to torch.distributed (Engine calls with device pointers, parallel.gather_rows, bench.py's process group): a
+    torch imported AFTER the library was loaded on another runtime is caught there instead of failing silently."""
+    rts = hip_runtimes()
+    if len(rts) > 1 and "torch" in sys.modules:
+        raise HipLibraryError("two HIP runtimes are mapped into this process (%s) and torch is imported: import torch BEFORE anything "
+                              "that links /opt/rocm's libamdhip64, or -- for a process that does not need torch on the GPU -- set "
+                              "ADAPTED_HIP_RUNTIME=system before adapted_amd.lib is loaded and do not import torch" % ", ".join(rts))
+
+
+_RUNTIME_CHECKED_WITH_TORCH = False
+
+
+def _check_runtime_once_torch_is_here():
+    """assert_one_runtime, once per process after torch has appeared (reading /proc/self/maps per call would cost a detect call ~1 ms)"""
+    global _RUNTIME_CHECKED_WITH_TORCH
+    if not _RUNTIME_CHECKED_WITH_TORCH and "torch" in sys.modules:
+        assert_one_runtime()
+        _RUNTIME_CHECKED_WITH_TORCH = True
+
+
 def load():
     """Load (building if needed) libadapted_hip.so.  Raises HipLibraryError if impossible."""
     global _LIB
@@ -218,13 +254,7 @@ def load():
         lib = C.CDLL(path)
     except Exception as e:  # no CPU fallback by design
         raise HipLibraryError("libadapted_hip.so is required (hipcc build or load failed): %s" % e) from e
-    if len(hip_runtimes()) > 1 and "torch" in sys.modules:
-        # (two runtimes with torch in the process: torch's device context and this library's would not see each other.  Without
-        # torch imported a second mapped copy is idle and harmless.)
-        raise HipLibraryError("two HIP runtimes are mapped into this process (%s) and torch is imported: import torch BEFORE anything "
-                              "that links /opt/rocm's libamdhip64, or -- for a process that does not need torch on the GPU -- set "
-                              "ADAPTED_HIP_RUNTIME=system before adapted_amd.lib is loaded and do not import torch"
-                              % ", ".join(hip_runtimes()))
+    assert_one_runtime()
     if lib.adp_sizeof_cfg() != C.sizeof(AdpCfg) or lib.adp_sizeof_row() != ROW_DTYPE.itemsize:
         raise HipLibraryError("ABI mismatch between adapted_amd/lib.py and libadapted_hip.so")
     lib.adp_last_error.restype = C.c_char_p
@@ -513,6 +543,7 @@ class Engine:
 
     def _in_ptrs(self, signals, full_lens, n, device_ptrs):
         if device_ptrs:
+            _check_runtime_once_torch_is_here()  # (device pointers come from torch: its runtime must be this library's)
             return C.c_void_p(int(signals)), C.c_void_p(int(full_lens)), ADP_IN_DEVICE, None
         sig = np.ascontiguousarray(signals, dtype=np.float32)
         lens = np.ascontiguousarray(full_lens, dtype=np.int32)

@@ -39,6 +39,10 @@ def gather_rows(rows, dst: int = 0, group=None, always: bool = False):
     import torch
     import torch.distributed as dist
 
+    from . import lib as _lib
+
+    _lib.assert_one_runtime()  # (rows of the library's device context go to torch.distributed's)
+
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not always):
         return rows
     ws, rk = dist.get_world_size(group), dist.get_rank(group)

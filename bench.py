@@ -447,6 +447,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
     dt = time.perf_counter() - t0
     for e in engines:
         e.set_profiling(False)
+    lib.assert_one_runtime()  # (torch's device memory went through the library all along: one HIP runtime, or fail loudly)
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

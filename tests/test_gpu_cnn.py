@@ -482,10 +482,10 @@ def test_split_conv_keeps_large_in_range_activations(monkeypatch):
 # reference's cnn_detect (adapted/detect/cnn.py:165-182: torch CPU / oneDNN scores, cnn_predict) returns for 16 000 reads at the
 # preset's window and 1 600 at the 200 k window (oracle/gen_golden.py preds), with its own scores at the predicted positions.
 # Any two float32-accurate conv stacks order near-tied peaks differently on about one read in 10^4; what is asserted: the adapter
-# end never moves, the split-float16 stack (the default) does not flip more reads than the exact-float32 MFMA stack (+2), and every
+# end and the BEST poly(A) candidate (columns 0 and 1: adapter_end, polya_end) never move, the split-float16 stack (the default) does not flip more reads than the exact-float32 MFMA stack (+2), and every
 # flipped read's candidates differ by less than 1e-5 of the read's score scale (device scores of the flipped reads).
 @pytest.mark.parametrize("name", ["rna004_cnn_preds_default", "rna004_cnn_preds_200k"])
-def test_conv_stack_flips_against_the_reference(name):
+def test_conv_stack_flips_against_the_reference(name, tmp_path):
     import os
 
     from golden_cases import PREDS_CASES, preds_lens
@@ -537,6 +537,7 @@ def test_conv_stack_flips_against_the_reference(name):
                                   "reference scores there %s" % (i, ref[i].tolist(), got[i].tolist(), np.flatnonzero(got[i] != ref[i]).tolist(), max(gaps), max(gaps) / scale, scale,
                                                                    np.round(ref_at[i][got[i] != ref[i]], 6).tolist()))
                     assert got[i, 0] == ref[i, 0], (stack, i, "the adapter end moved", got[i], ref[i])
+                    assert got[i, 1] == ref[i, 1], (stack, i, "the BEST poly(A) candidate (-> polya_end) moved", got[i], ref[i])
                     assert max(gaps) < 1e-5 * scale, (stack, i, gaps, scale)
             finally:
                 eng.dev_free(dsig); eng.dev_free(dlen)
@@ -547,8 +548,9 @@ def test_conv_stack_flips_against_the_reference(name):
             os.environ["ADP_CNN_CONV"] = saved
     text = "\n".join(report)
     print(text)
-    out = os.path.join(os.path.dirname(GOLD), os.pardir, "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "conv_stack_flips_vs_reference_%s.txt" % name), "w") as fh:
-        fh.write(text + "\n")
+    # (the census goes to the test's own directory; ADP_FLIPS_REPORT_DIR=<dir> -- the profiling script -- keeps a copy for profiles/)
+    for out in filter(None, (str(tmp_path), os.environ.get("ADP_FLIPS_REPORT_DIR"))):
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "conv_stack_flips_vs_reference_%s.txt" % name), "w") as fh:
+            fh.write(text + "\n")
     assert flips_of["split"].size <= flips_of["f32"].size + 2, text

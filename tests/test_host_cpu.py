@@ -15,6 +15,16 @@ from util import GOLD
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+
+
+def _free_port() -> str:
+    """a free TCP port on 127.0.0.1 (bind to port 0), as bench.spawn_ranks picks its rendezvous port"""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 def test_presets_and_derived_fields():
     from adapted_amd.config import get_chemistry_specific_config
 
@@ -235,7 +245,7 @@ def test_row_gather_two_ranks_gloo(tmp_path):
     script.write_text(_GLOO_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER_OK 7300" in r.stdout and "EMPTY_RANK_OK 500" in r.stdout
@@ -530,7 +540,7 @@ def test_row_gather_eight_ranks_gloo(tmp_path):
     script.write_text(_GLOO_WORKER_8 % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
-                        "--master-addr", "127.0.0.1", "--master-port", "29741", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "GATHER8_OK 5300 [(5000, 5300), (5300, 5300), (5300, 5300)]" in r.stdout
