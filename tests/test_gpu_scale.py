@@ -257,7 +257,7 @@ def test_cnn_path_at_the_200k_window_vs_oracle(oracle_mod):
     """BASELINE configs[2] at its size: the FULL CNN path (prepare -> hand-written conv stack -> predict -> the candidate
     loop of validate_boundaries -> short-read fallback) at m = 201 500.  The shipped weights are off-distribution there:
     most reads fail and run all 10 candidates over slices of up to ~190 k samples -- the shared-sweep statistics of
-    cand_stats.h.  The oracle validates the DEVICE's predictions (the conv stacks differ in summation order, so the
+    cand_stats2.h.  The oracle validates the DEVICE's predictions (the conv stacks differ in summation order, so the
     predictions themselves are pinned at the default window by the golden case): every field of every row identical."""
     from adapted_amd import lib, synth
     from adapted_amd.config import get_chemistry_specific_config
