@@ -23,9 +23,10 @@ c0 = eng.debug_counters(48).astype(np.int64)
 run()
 c1 = eng.debug_counters(48).astype(np.int64)
 d = c1 - c0
-print("finished here", d[22], "left to the list mode", d[23])
-names = ["pivot wait + zero hist", "A: register slabs", "A: streamed slabs", "A: ragged chunk", "fold, bucket search, MAD prediction", "B: ragged chunk",
-         "B: streamed slabs", "B: LDS slabs", "B: register slabs", "next read requested", "fold, median, MAD, row"]
+print("passes done here", d[22], "left to k_partition_stats", d[23])
+names = ["pivot wait, zero hist, leaf table", "A: register groups, a streamed one behind each", "A: the other streamed groups", "A: ragged chunk",
+         "fold, bucket search, MAD prediction", "B: ragged chunk", "B: register groups + streamed", "B: LDS groups + streamed", "B: the other streamed groups",
+         "next read: first part requested", "fold, record, second part requested"]
 ph = d[32:43].astype(float) * 0.01 / max(d[22] + d[23], 1)  # us per read (256 workgroups, each thread 0)
 for nme, v in zip(names, ph):
     print("  %-40s %6.2f us per read" % (nme, v))
