@@ -307,6 +307,17 @@ def host_pipeline_bench(args, spc, device):
                       "config": {"workload": "LLR + start_peak + validate from pinned host staging, m=%d, minibatch=%d, %d minibatches per call" % (m, args.minibatch, G)}})
 
 
+def _traffic_of(traffic, kernel, reads):
+    """HBM bytes per launch of `kernel` from a rocprofv3 --pmc summary (profiles/rNN_traffic*.json), scaled to `reads` reads; the profile
+    names a kernel with its template arguments (k_partition_stats<256, 5>), the bench by the name of its launch scope"""
+    if not traffic:
+        return None
+    hit = [k for k in traffic if not k.startswith("_") and (k == kernel or k.split("<")[0] == kernel)]
+    if len(hit) != 1:
+        return None
+    return traffic[hit[0]]["hbm_bytes"] * (reads / traffic["_reads_per_launch"])
+
+
 CNN_FLOP_PER_POS = 2.0 * (64 * 7 + 2 * 64 * 64 * 7 + 64 * 2 * 7)  # SURVEY.md 8(d): F_alg = this x L1 per read
 F32_MFMA_PEAK_TF = 157.3  # MI355X float32 matrix peak (/opt/skills/guides/MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TF = 2500.0  # dense float16 / bfloat16 matrix peak (same guide: ~2.5 PF, sparsity not counted)
@@ -510,8 +521,7 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                        "grouping": {k: os.environ.get(k) for k in ("ADP_GROUPS", "ADP_LANES", "ADP_STAGGER") if os.environ.get(k)} or "one group (phases in turn on one stream)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic.get(dom, {}).get("hbm_bytes") * (Rs / traffic["_reads_per_launch"])
-                                     if traffic and dom in traffic else None),
+                         "traffic": _traffic_of(traffic, dom, Rs),
                          "traffic_source": (traffic["_file"] + " (rocprofv3 --pmc, FETCH_SIZE doubled per MI355X_MICROARCH.md)") if traffic else None,
                          "kernel_ms": kavg[dom], "algorithmic_bytes_per_launch": b_alg,
                          "whole_path_frac": (bps * mean_samples * R / step_s) / 1e9 / HBM_PEAK_GBS},
