@@ -573,3 +573,47 @@ def test_bench_refuses_more_ranks_than_devices_before_touching_a_gpu():
     assert r.returncode == 2, (r.returncode, r.stdout[-500:], r.stderr[-500:])
     assert "EXIT 2 GPU_INITIALISED False LIB False" in r.stdout
     assert "--gpus 8 but only" in r.stderr
+
+
+def test_assert_one_runtime_catches_torch_imported_after_a_system_runtime_load():
+    """(advisor, round 4) the two-runtimes guard used to look only when the library was loaded: ADAPTED_HIP_RUNTIME=system (or a torch
+    wheel with another SONAME), the library first, torch later -- two runtimes, silently.  assert_one_runtime() is called again at the
+    entry points that hand torch's memory to the library (Engine calls with device pointers), parallel.gather_rows and bench.py."""
+    code = ("from adapted_amd import lib\n"
+            "lib.load()\n"                      # /opt/rocm's runtime, no torch yet: fine
+            "lib.assert_one_runtime()\n"
+            "import torch\n"                    # the wheel's bundled runtime joins it
+            "n = len(lib.hip_runtimes())\n"
+            "try:\n"
+            "    lib.assert_one_runtime()\n"
+            "    print('NO_ERROR', n)\n"
+            "except lib.HipLibraryError as e:\n"
+            "    print('RAISED', n)\n"
+            "try:\n"
+            "    lib._check_runtime_once_torch_is_here()\n"
+            "    print('ENTRY_OK')\n"
+            "except lib.HipLibraryError:\n"
+            "    print('ENTRY_RAISED')\n")
+    env = dict(os.environ, ADAPTED_HIP_RUNTIME="system")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.split()
+    n = int(lines[1])
+    if n > 1:  # (this image: the wheel bundles its own libamdhip64) the later import is caught, at the explicit check and at an entry point
+        assert lines[0] == "RAISED" and "ENTRY_RAISED" in lines, out.stdout
+    else:      # (a torch that links the system runtime: one runtime, nothing to catch)
+        assert lines[0] == "NO_ERROR" and "ENTRY_OK" in lines, out.stdout
+
+
+def test_bench_finds_a_kernels_traffic_whatever_its_template_arguments():
+    """profiles/rNN_traffic*.json name a kernel with its template arguments (k_partition_stats<256, 5>), bench.py by its launch scope"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    t = {"_reads_per_launch": 96000, "_note": "x", "k_partition_stats<256, 5>": {"hbm_bytes": 96.0e9}, "k_gains<1>": {"hbm_bytes": 1.0}, "k_gains<2>": {"hbm_bytes": 2.0},
+         "k_validate": {"hbm_bytes": 30.0e9}}
+    assert bench._traffic_of(t, "k_partition_stats", 48000) == 48.0e9
+    assert bench._traffic_of(t, "k_validate", 96000) == 30.0e9
+    assert bench._traffic_of(t, "k_gains<2>", 96000) == 2.0
+    assert bench._traffic_of(t, "k_gains", 96000) is None          # ambiguous: two instantiations
+    assert bench._traffic_of(t, "k_norm_pool", 96000) is None and bench._traffic_of(None, "k_validate", 1) is None
