@@ -51,7 +51,8 @@ static __device__ __forceinline__ void cns_static_for(F &&f)
 #define CNS_LIMIT 32768.0f   // a STORED activation at or beyond it (or non-finite) repeats the call on the float32 kernels ...
 #define CNS_ASCALE 0.0625f   // ... and activations are stored times 2^-4: real values up to 5.2e5 stay in range (exact scaling; it
                              // rides through the 64 -> 64 layers with the bias and leaves in layer 3)
-#define CNS_SLACK 65536      // bytes behind the last read's rows that a tile DMA may read (k_cnn_conv_out_s: up to 130 rows from a row below L1)
+#define CNS_SLACK 131072     // bytes behind the last read's rows that a tile DMA may read (k_cnn_conv_out_s: up to 130 rows from a row below L1;
+                             // the overlapping tiles of the folded last layer: up to 64 NT rows)
 #define CNS_WSP_LAYER (2 * CNS_KSTEPS * 2 * 64 * 8) // float16 per layer in the split-weight buffer
 // Row 0 of a read's front padding is the DUMP row: the epilogues store the pieces of rows at or beyond L1 there so that every store is issued
 // and the counted s_waitcnt stays exact.  Nothing may read it: a tile's DMA starts at row CNS_FRONT - 3, layer 3's block at CNS_FRONT - 1.
@@ -77,6 +78,28 @@ __global__ void k_cns_split_weights(const float *__restrict__ w /* [64][64][7] *
     _Float16 *dl = wsp + ((size_t)((mh * CNS_KSTEPS + k) * 2 + 1) * 64 + lane) * 8;
     for (int e = 0; e < 8; e++) {
         const float v = w[((size_t)o * CNN_C + c0 + e) * CNN_K + t] * sw;
+        _Float16 hi, lo;
+        cns_split(v, hi, lo);
+        dh[e] = hi; dl[e] = lo;
+    }
+}
+
+// ---------------------------------------------------------------- weights of layer 3 (ConvTranspose1d 64 -> 2, k 7) as A fragments
+// For the fold of layer 3 into layer 2's kernel: one more GEMM per tile with M = 16 rows (of the instruction's 32), K = the 64 channels,
+// N = positions.  Row m stands for (output channel o = (m >> 2) & 1, tap t = (m & 3) + 4 (m >> 3)), t = 7 and the rows from 16 on are
+// zero: in the accumulator layout of v_mfma_f32_32x32x16 (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) lane half `lane >> 5` then holds
+// output channel o = lane >> 5 and register t the partial sum of tap t -- the seven taps of one position and channel in registers 0..6.
+// w3sp [k-step 4][plane 2][lane 64][8]: lane l holds W3[c = 16 cg + 8 (l >> 5) + e][o][t] for row m = l & 31, scaled by s3 and split.
+#define CNS_W3SP (4 * 2 * 64 * 8) // float16
+__global__ void k_cns_split_w3(const float *__restrict__ w3 /* [64][2][7] */, float s3, _Float16 *__restrict__ w3sp)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 4 * 64) return;
+    const int lane = idx & 63, cg = idx >> 6;
+    const int m = lane & 31, o = (m >> 2) & 1, t = (m & 3) + 4 * (m >> 3), c0 = 16 * cg + 8 * (lane >> 5);
+    _Float16 *dh = w3sp + ((size_t)(cg * 2 + 0) * 64 + lane) * 8, *dl = w3sp + ((size_t)(cg * 2 + 1) * 64 + lane) * 8;
+    for (int e = 0; e < 8; e++) {
+        const float v = (m < 16 && t < CNN_K) ? w3[((size_t)(c0 + e) * 2 + o) * CNN_K + t] * s3 : 0.0f;
         _Float16 hi, lo;
         cns_split(v, hi, lo);
         dh[e] = hi; dl[e] = lo;
@@ -163,13 +186,22 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // Synchronisation per step: the tile's DMA is the OLDEST of the wave's outstanding vector-memory operations (it was issued before
 // the previous step's stores), so a counted s_waitcnt leaves those stores in flight; every store of the epilogue is issued
 // unconditionally (rows at or beyond L1 go to the read's row 0, which nothing reads) to keep that count exact.
-template <int NT>
+// LAST (round 5): layer 3 -- ConvTranspose1d(64 -> 2, k 7, stride 3, pad 3) -- in this kernel's epilogue.  The tile's output rows are
+// laid down in LDS as before (with the rows outside [0, L1) zeroed: layer 3 reads them as its padding), but instead of leaving for HBM
+// they are the B operand of one more GEMM (k_cns_split_w3's A fragments: 12 MFMAs per 32 positions); the partial sums of a position's
+// seven taps go to LDS, and output 3 j + d of channel o is b + P[j - 1][6] + P[j][3] + P[j + 1][0] (d = 0), P[j][3 + d] + P[j + 1][d]
+// (d = 1, 2).  A tile's first and last position only lend their partial sums: tiles advance by PB - 2 positions and start at -1.
+// No rows of layer 2 in HBM (1.8 MB per read written and read back) and no k_cnn_conv_out_s.
+template <int NT, bool LAST = false>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
-                                                        int32_t *__restrict__ flag)
+                                                        int32_t *__restrict__ flag, const _Float16 *__restrict__ w3sp = nullptr,
+                                                        const float *__restrict__ b3 = nullptr, float inv_s3 = 0.f,
+                                                        float *__restrict__ scores = nullptr, int Lo = 0)
 {
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
+    constexpr int PBS = LAST ? PB - 2 : PB; // positions a tile advances by
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
     static_assert(NSTORE * 256 >= PB * 17 && (NSTORE - 1) * 256 < PB * 17, "the epilogue issues exactly NSTORE stores per thread: the s_waitcnt below counts them");
     extern __shared__ float cns_lds_raw[];
@@ -199,10 +231,18 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
         // rows (position tile * PB - 3) ... of read n: one contiguous range (the instructions of the last KB read a little past it,
         // into the next rows or the buffer's slack)
-        const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 + (size_t)tile * PB) * CNS_ROWB + lane * 16;
+        const GLB char *src = (const GLB char *)in + ((size_t)n * Lrows + CNS_FRONT - 3 - (LAST ? 1 : 0) + (size_t)tile * PBS) * CNS_ROWB + lane * 16;
         for (int inst = wave; inst < NDMA; inst += 4)
             __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + b * TILE_B + inst * 1024), 16, 0, 0);
     };
+    // LAST: layer 3's A fragments (32 registers) stay resident where the tile shape leaves room (NT = 4 is at the limit: fetched per tile)
+    constexpr bool W3_RESIDENT = LAST && NT < 4;
+    cnn_h8 ah[4], al[4];
+    if constexpr (W3_RESIDENT) {
+        const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(w3sp) + lane;
+#pragma unroll
+        for (int cg = 0; cg < 4; cg++) { ah[cg] = wp[(size_t)(cg * 2) * 64]; al[cg] = wp[(size_t)(cg * 2 + 1) * 64]; }
+    }
     int it = blockIdx.x;
     int buf = 0;
     // out of range = a float16 hi part of 32768 or more (or infinite), looked for as the largest bit pattern seen: the values are
@@ -227,7 +267,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         const GLB char *nsrc = nullptr;
         if (more) {
             const int tix = it + gridDim.x, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
-            nsrc = (const GLB char *)in + ((size_t)nn * Lrows + CNS_FRONT - 3 + (size_t)tile2 * PB) * CNS_ROWB + lane * 16;
+            nsrc = (const GLB char *)in + ((size_t)nn * Lrows + CNS_FRONT - 3 - (LAST ? 1 : 0) + (size_t)tile2 * PBS) * CNS_ROWB + lane * 16;
         }
         LDS char *ndst = lds + (buf ^ 1) * TILE_B;
         static_assert((NDMA + 3) / 4 <= CNS_KSTEPS, "one DMA piece per k-step and wave");
@@ -278,6 +318,9 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             LDS char *srow = stg + (ph * (NT * 32) + 32 * j + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
+            // LAST: a row outside the read is layer 3's zero padding (its activation of the padded input is not zero)
+            const int pos_ = tile * PBS - 1 + ph * (NT * 32) + 32 * j + l31;
+            const bool keep_ = !LAST || (pos_ >= 0 && pos_ < L1); // (a select, not a factor: position -1 is computed from the dump row in front of the read)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 // two values per instruction where the hardware has a packed form (v_pk_mul / v_pk_fma / v_cvt_pk_f16_f32 / v_pk_add):
@@ -288,6 +331,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                     const cnn_f2 a2 = {am[j][4 * g + 2 * q], am[j][4 * g + 2 * q + 1]}, x2 = {ax[j][4 * g + 2 * q], ax[j][4 * g + 2 * q + 1]};
                     cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
                     v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f}); // (a NaN becomes 0, as `v > 0 ? v : 0` makes it in k_cnn_conv64)
+                    if (LAST && !keep_) v = (cnn_f2){0.f, 0.f};
                     const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
                     const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
                     hq[q] = hi; lq[q] = __builtin_convertvector(rs, cnn_h2);
@@ -301,6 +345,55 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (LAST) {
+            // ---- layer 3 on the tile's rows in LDS: wave q takes the 32-position subtiles q, q + 4, ... of the tile's 2 NT
+            LDS float *psum = (LDS float *)(lds + 2 * TILE_B); // [o 2][t 7][position PB] partial sums of the taps
+            if constexpr (!W3_RESIDENT) {
+                const cnn_h8 *wp = reinterpret_cast<const cnn_h8 *>(w3sp) + lane;
+#pragma unroll
+                for (int cg = 0; cg < 4; cg++) { ah[cg] = wp[(size_t)(cg * 2) * 64]; al[cg] = wp[(size_t)(cg * 2 + 1) * 64]; }
+            }
+            for (int st = wave; st < 2 * NT; st += 4) {
+                const LDS char *rb = stg + (32 * st + l31) * CNS_ROWB + lh * 16;
+                cnn_f32x16 pm = zero16, px = zero16;
+#pragma unroll
+                for (int cg = 0; cg < 4; cg++) {
+                    const cnn_h8 bh = *reinterpret_cast<const LDS cnn_h8 *>(rb + cg * 32), bl = *reinterpret_cast<const LDS cnn_h8 *>(rb + cg * 32 + 128);
+                    pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cg], bh, pm, 0, 0, 0);
+                    px = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cg], bh, px, 0, 0, 0);
+                    px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cg], bl, px, 0, 0, 0);
+                }
+                // lane (position 32 st + l31, output channel lh): registers 0 .. 6 are the taps' partial sums (k_cns_split_w3)
+#pragma unroll
+                for (int t = 0; t < CNN_K; t++) psum[(lh * CNN_K + t) * PB + 32 * st + l31] = __builtin_fmaf(px[t], 1.0f / 2048.0f, pm[t]) * inv_s3;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // outputs 3 jg + d of the tile's interior positions jg = tile * PBS + (j - 1), j = 1 .. PB - 2.  Every thread issues the same
+            // number of stores (those without an output go to the dump row of `out`, which this layer does not write otherwise), so that
+            // the counted wait below leaves them in flight and only makes sure of the next tile's DMA, which is older
+            constexpr int NIT = (2 * PBS + 255) / 256;
+            float *dumpf = reinterpret_cast<float *>(out) + lane;
+#pragma unroll
+            for (int k2 = 0; k2 < NIT; k2++) {
+                const int i = k2 * 256 + (int)threadIdx.x;
+                const bool have = i < 2 * PBS;
+                const int o = have ? i / PBS : 0, j = have ? i - o * PBS + 1 : 1;
+                const int jg = tile * PBS + j - 1;
+                const bool ok = have && jg < L1;
+                const LDS float *pq = psum + (o * CNN_K) * PB + j;
+                const float bo = b3[o];
+                const float y0 = bo + ((pq[6 * PB - 1] + pq[3 * PB]) + pq[0 * PB + 1]);
+                const float y1 = bo + (pq[4 * PB] + pq[1 * PB + 1]);
+                const float y2 = bo + (pq[5 * PB] + pq[2 * PB + 1]);
+                float *so = scores + ((size_t)n * 2 + o) * Lo + 3 * (size_t)(ok ? jg : 0);
+                *((ok && 3 * jg < Lo) ? so : dumpf) = y0;
+                *((ok && 3 * jg + 1 < Lo) ? so + 1 : dumpf) = y1;
+                *((ok && 3 * jg + 2 < Lo) ? so + 2 : dumpf) = y2;
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NIT) : "memory");
+        } else {
         {
             // rows tile * PB .. of read n; pieces of rows at or beyond L1 go to the read's row 0 (which nothing reads), so that
             // every store is issued and the count below stays exact
@@ -325,6 +418,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         }
         // the DMA issued at the top of this step is older than these NSTORE stores
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+        }
         buf ^= 1;
     }
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;

@@ -544,6 +544,10 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                 # split float32 operands, cnn_conv_split.h), the first / last layer stay float32 vector code -- priced against the
                 # float16 matrix peak for what the matrix cores execute, with the float32-equivalent rate beside it
                 f64l = 2.0 * (2 * 64 * 64 * 7) * L1 * Rs
+                if os.environ.get("ADP_CNN_FOLD", "1") != "0":
+                    # layer 3 rides in layer 2's kernel as one more GEMM on the matrix cores: 16 (of the instruction's 32) rows x 64 channels per
+                    # position, on tiles that overlap by 2 of their 64 NT positions -- counted as executed (the padded rows, not the overlap)
+                    f64l += 2.0 * (32 * 64) * L1 * Rs
                 ms64 = sum(v for k, v in kavg.items() if k.startswith("k_cnn_conv64"))
                 rows_b = 272.0 * L1 * Rs  # one split activation row per position: read once and written once per layer
                 out["roofline"] = {"bound": "mfma", "dtype": "f16 x 3 (split float32 operands, float32 accumulate)",
