@@ -96,7 +96,7 @@ struct adp_handle {
     int cnn_f_Lpad = 0, cnn_f_L1 = 0, cnn_f_chunk = 0;
     bool cnn_redo_f32 = false;
     DevBuf cnn_wsp;          // split B fragments of layers 1 and 2
-    float cnn_sw[3] = {1.f, 1.f, 1.f}; // scales of the split weights: layers 1, 2 and (folded into layer 2's kernel) 3
+    float cnn_sw[4] = {1.f, 1.f, 1.f, 1.f}; // scales of the split weights: layers 1, 2, 3 (folded into layer 2's kernel) and 0 (into layer 1's)
     // grouped execution of the LLR path (llr_grouped): child handles ("lanes") with their own streams and a workspace for ONE
     // group of minibatches; consecutive groups go to alternating lanes so that the phases of neighbouring groups overlap
     adp_handle *lane[ADP_MAX_LANES] = {};
@@ -1311,7 +1311,7 @@ int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const f
     HIPCHK(hipMemcpyAsync(h->cnn_w.p, all.data(), (size_t)CNN_WTOTAL * 4, hipMemcpyHostToDevice, h->stream));
     // the 64 -> 64 layers once more as split float16 B fragments (cnn_conv_split.h), scaled by a power of two per layer so that the
     // largest weight lands in [2^13, 2^14)
-    if (h->cnn_wsp.ensure(((size_t)2 * CNS_WSP_LAYER + CNS_W3SP) * 2)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
+    if (h->cnn_wsp.ensure(((size_t)2 * CNS_WSP_LAYER + CNS_W3SP + CNS_W0SP) * 2)) { g_err = "device allocation failed"; return ADP_ERR_HIP; }
     for (int layer = 0; layer < 2; layer++) {
         const float *wl = &all[layer ? CNN_W2 : CNN_W1];
         float mx = 0.f;
@@ -1336,6 +1336,18 @@ int adp_cnn_set_weights(adp_handle *h, const float *w0, const float *b0, const f
         h->cnn_sw[2] = ldexpf(1.0f, se);
         hipLaunchKernelGGL(k_cns_split_w3, dim3(1), dim3(256), 0, h->stream, h->cnn_w.as<float>() + CNN_W3, h->cnn_sw[2], h->cnn_wsp.as<_Float16>() + (size_t)2 * CNS_WSP_LAYER);
     }
+    { // layer 0 as A fragments of a small GEMM in layer 1's prologue (k_cns_split_w0)
+        float mx = 0.f;
+        for (int i = 0; i < CNN_C * CNN_K; i++) { const float a = fabsf(w0[i]); if (a > mx && a < INFINITY) mx = a; }
+        int e = 0;
+        if (mx > 0.f) (void)frexpf(mx, &e);
+        int se = 14 - e;
+        if (se > 100) se = 100;
+        if (se < -100) se = -100;
+        h->cnn_sw[3] = ldexpf(1.0f, se);
+        hipLaunchKernelGGL(k_cns_split_w0, dim3(1), dim3(128), 0, h->stream, h->cnn_w.as<float>() + CNN_W0, h->cnn_sw[3],
+                           h->cnn_wsp.as<_Float16>() + (size_t)2 * CNS_WSP_LAYER + CNS_W3SP);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     h->cnn_have_w = true;
@@ -1357,20 +1369,20 @@ static int launch_conv64(adp_handle *h, const float *in, float *out, const float
 } // extern "C++"
 
 extern "C++" {
-template <int NT, bool LAST>
+template <int NT, bool LAST, bool FIRST = false>
 static int launch_conv64s(adp_handle *h, const _Float16 *in, _Float16 *out, const _Float16 *wsp, const float *b, float sw, int n, int L1,
                           int Lrows, int tiles, int32_t *flag, const _Float16 *w3sp = nullptr, const float *b3 = nullptr, float inv_s3 = 0.f,
-                          float *scores = nullptr, int Lo = 0)
+                          float *scores = nullptr, int Lo = 0, CnsFirst first = CnsFirst{})
 {
     // (LAST: layer 3 in the epilogue -- tiles that advance by 64 NT - 2 positions, the taps' partial sums of a tile in LDS behind the two tile buffers)
     const size_t lds = (size_t)2 * (((size_t)(64 * NT + 6) * CNS_ROWB + 1023) / 1024 * 1024) + (LAST ? (size_t)2 * CNN_K * 64 * NT * 4 : 0);
-    const unsigned bit = (LAST ? 512u : 64u) << (NT - 2);
-    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT, LAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
+    const unsigned bit = (FIRST ? 16384u : LAST ? 512u : 64u) << (NT - 2);
+    if (!(h->attr_done & bit)) { HIPCHK(hipFuncSetAttribute((const void *)k_cnn_conv64s<NT, LAST, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); h->attr_done |= bit; }
     long long total = (long long)n * tiles;
     if (total >= (1ll << 31)) { g_err = "too many tiles for one launch of k_cnn_conv64s"; return ADP_ERR_UNSUPPORTED; }
     int grid = (int)(total < h->n_cu ? total : h->n_cu);
-    hipLaunchKernelGGL((k_cnn_conv64s<NT, LAST>), dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag,
-                       w3sp, b3, inv_s3, scores, Lo);
+    hipLaunchKernelGGL((k_cnn_conv64s<NT, LAST, FIRST>), dim3(grid), dim3(256), lds, h->stream, in, out, wsp, b, sw, 1.0f / sw, n, L1, Lrows, tiles, flag,
+                       w3sp, b3, inv_s3, scores, Lo, first);
     return 0;
 }
 } // extern "C++"
@@ -1405,8 +1417,11 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     // ADP_CNN_FOLD=1 (round 5): layer 3 in layer 2's epilogue (k_cnn_conv64s<NT, true>): no rows of layer 2 in HBM, no k_cnn_conv_out_s, nothing
     // left to run beside the next chunk's first layer -- one stream, the buffers keep their roles
     const bool fold = env_int("ADP_CNN_FOLD", 1) != 0;
+    // ADP_CNN_FUSE_IN=1 (round 5): layer 0 in layer 1's prologue, on the matrix cores (k_cnn_conv64s<NT, false, true>): no k_cnn_conv_in_s, no
+    // rows of layer 0 in HBM
+    const bool fuse_in = env_int("ADP_CNN_FUSE_IN", 1) != 0;
     const int tiles_last = (L1 + PB - 3) / (PB - 2); // tiles of the folded layer: they advance by PB - 2 positions
-    const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0 && !fold;
+    const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0 && !fold && !fuse_in;
     if (overlap && !h->ev_conv[0]) {
         for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_conv[i], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
     }
@@ -1420,8 +1435,10 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
         const float *x = prepared + (size_t)s0 * Lc;
         float *sc = scores_out + (size_t)s0 * 2 * Lo;
         _Float16 *A = bufs[overlap ? (chunk & 1) : 0], *B = bufs[overlap ? 1 - (chunk & 1) : 1];
-        { Scope s(h, "k_cnn_conv_in");
-          hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag); }
+        if (!fuse_in) {
+            Scope s(h, "k_cnn_conv_in");
+            hipLaunchKernelGGL(k_cnn_conv_in_s, dim3((L1 + CNS_IN_P * CNS_IN_T - 1) / (CNS_IN_P * CNS_IN_T), n), dim3(256), 0, h->stream, x, Lc, L1, Lrows, W + CNN_W0, W + CNN_B0, A, flag);
+        }
         if (out_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_conv[1 + ((chunk - 1) & 1)], 0)); out_pending = false; } // (layer 1 overwrites what that layer 3 reads)
         for (int layer = 0; layer < 2; layer++) {
             Scope s(h, layer ? "k_cnn_conv64 (layer 2)" : "k_cnn_conv64 (layer 1)");
@@ -1436,6 +1453,11 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
                 rc = NT == 4 ? launch_conv64s<4, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_last, flag, w3sp, W + CNN_B3, inv_s3, sc, Lo)
                    : NT == 3 ? launch_conv64s<3, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_last, flag, w3sp, W + CNN_B3, inv_s3, sc, Lo)
                              : launch_conv64s<2, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_last, flag, w3sp, W + CNN_B3, inv_s3, sc, Lo);
+            } else if (layer == 0 && fuse_in) {
+                const CnsFirst first{x, Lc, wsp + (size_t)2 * CNS_WSP_LAYER + CNS_W3SP, W + CNN_B0, wh->cnn_sw[3]};
+                rc = NT == 4 ? launch_conv64s<4, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
+                   : NT == 3 ? launch_conv64s<3, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
+                             : launch_conv64s<2, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first);
             } else
                 rc = NT == 4 ? launch_conv64s<4, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
                    : NT == 3 ? launch_conv64s<3, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)

@@ -33,6 +33,7 @@ typedef _Float16 cnn_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cnn_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 cnn_h2 __attribute__((ext_vector_type(2)));
 typedef float cnn_f2 __attribute__((ext_vector_type(2)));
+typedef float cnn_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned short cnn_us2 __attribute__((ext_vector_type(2)));
 #ifndef CNS_ABL
 #define CNS_ABL 0 // (development: 1 = no MFMAs, 2 = no epilogue stores)
@@ -105,6 +106,27 @@ __global__ void k_cns_split_w3(const float *__restrict__ w3 /* [64][2][7] */, fl
         dh[e] = hi; dl[e] = lo;
     }
 }
+
+// ---------------------------------------------------------------- weights of layer 0 (Conv1d 1 -> 64, k 7, stride 3) as A fragments
+// For layer 0 INSIDE layer 1's kernel (FIRST): the tile's input rows are one small GEMM per 32 rows -- M = 32 channels of the wave's half,
+// K = the 7 taps padded to 16 (the second k-half is zero), N = rows; B = the samples x[3 p - 3 + tap], split like every other operand.
+// w0sp [plane 2][mh 2][lane 64][8]: lane l holds W0[c = 32 mh + (l & 31)][tap e] for l < 32 and e < 7 (zeros elsewhere), times s0, split.
+#define CNS_W0SP (2 * 2 * 64 * 8) // float16
+__global__ void k_cns_split_w0(const float *__restrict__ w0 /* [64][1][7] */, float s0, _Float16 *__restrict__ w0sp)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * 64) return;
+    const int lane = idx & 63, mh = idx >> 6;
+    const int c = 32 * mh + (lane & 31);
+    _Float16 *dh = w0sp + ((size_t)(0 * 2 + mh) * 64 + lane) * 8, *dl = w0sp + ((size_t)(1 * 2 + mh) * 64 + lane) * 8;
+    for (int e = 0; e < 8; e++) {
+        const float v = (lane < 32 && e < CNN_K) ? w0[(size_t)c * CNN_K + e] * s0 : 0.0f;
+        _Float16 hi, lo;
+        cns_split(v, hi, lo);
+        dh[e] = hi; dl[e] = lo;
+    }
+}
+struct CnsFirst { const float *x; int Lc; const _Float16 *w0sp; const float *b0; float s0; }; // the prepared signal [n][Lc], layer 0's fragments, bias, scale
 
 // ---------------------------------------------------------------- layer 0: Conv1d(1 -> 64, k 7, stride 3, pad 3) + ReLU, split rows out
 // grid = (ceil(L1 / 64), n); block = 256: 64 positions, wave q makes channels 16 q .. 16 q + 15 of all of them (weights wave-uniform:
@@ -192,14 +214,20 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // seven taps go to LDS, and output 3 j + d of channel o is b + P[j - 1][6] + P[j][3] + P[j + 1][0] (d = 0), P[j][3 + d] + P[j + 1][d]
 // (d = 1, 2).  A tile's first and last position only lend their partial sums: tiles advance by PB - 2 positions and start at -1.
 // No rows of layer 2 in HBM (1.8 MB per read written and read back) and no k_cnn_conv_out_s.
-template <int NT, bool LAST = false>
+// FIRST (round 5): layer 0 -- Conv1d(1 -> 64, k 7, stride 3, pad 3) + ReLU -- in this kernel's prologue.  No input rows in HBM: the
+// tile's PB + 6 rows are made in LDS from the prepared signal by 3 MFMAs per 32 rows and channel half (k_cns_split_w0's A fragments;
+// the samples of a row are its B fragment, loaded a tile ahead), converted like an epilogue's results; rows outside [0, L1) are the
+// zero padding.  (Round 3 made these rows with float32 fmaf chains in the one wave per SIMD: no gain; on the matrix cores they cost
+// 11 MFMAs per wave and tile.)  No k_cnn_conv_in_s, 1.8 MB per read not written and not read back.
+template <int NT, bool LAST = false, bool FIRST = false>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
                                                         const _Float16 *__restrict__ wsp, const float *__restrict__ bias, float sw,
                                                         float inv_sw, int n_reads, int L1, int Lrows, int tiles_per_read,
                                                         int32_t *__restrict__ flag, const _Float16 *__restrict__ w3sp = nullptr,
                                                         const float *__restrict__ b3 = nullptr, float inv_s3 = 0.f,
-                                                        float *__restrict__ scores = nullptr, int Lo = 0)
+                                                        float *__restrict__ scores = nullptr, int Lo = 0, CnsFirst F = CnsFirst{})
 {
+    static_assert(!(FIRST && LAST), "layer 1 takes layer 0 in, layer 2 takes layer 3 in");
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
     constexpr int PBS = LAST ? PB - 2 : PB; // positions a tile advances by
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
@@ -225,6 +253,8 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     cnn_f32x16 bsv;
 #pragma unroll
     for (int r = 0; r < 16; r++) bsv[r] = bs[r];
+    // (FIRST at NT = 4 is over the register limit by about this vector: there it waits in LDS and is fetched per tile)
+    constexpr bool BS_LDS = FIRST && NT == 4;
     const cnn_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int total = n_reads * tiles_per_read; // (the host keeps it below 2^31)
     auto dma = [&](int tix, int b) {
@@ -243,6 +273,30 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 #pragma unroll
         for (int cg = 0; cg < 4; cg++) { ah[cg] = wp[(size_t)(cg * 2) * 64]; al[cg] = wp[(size_t)(cg * 2 + 1) * 64]; }
     }
+    // FIRST: the second tile buffer is not one (the rows are made in place): it holds the samples of the next tile's rows (LDS-DMA, a dword
+    // per lane: x[3 (tile PB - 3) - 3 ..], 3 R + 4 of them), layer 0's A fragments and its bias vector -- nothing of layer 0 in registers
+    // across the k-loop
+    constexpr int NRS = (R + 31) / 32, NXD = (3 * R + 4 + 63) / 64;
+    constexpr int XOFF = (32 * NRS * CNS_ROWB + 1023) / 1024 * 1024; // (whole 32-row subtiles are written: no branch around the last one's stores)
+    constexpr int W0OFF = XOFF + 4096, B0OFF = XOFF + 8192;
+    static_assert(NXD * 256 + 7 * 4 + 3 * 32 * 4 <= 4096 && B0OFF + 512 <= 2 * TILE_B, "layer 0's operands fit in the second tile buffer");
+    float k1_ = 0.f, k2_ = 0.f;
+    if constexpr (FIRST) {
+        reinterpret_cast<LDS cnn_h8 *>(lds + W0OFF)[threadIdx.x] = reinterpret_cast<const cnn_h8 *>(F.w0sp)[threadIdx.x]; // [plane][mh][lane]
+        if (threadIdx.x < CNN_C) reinterpret_cast<LDS float *>(lds + B0OFF)[threadIdx.x] = F.b0[threadIdx.x] * F.s0;
+        else if (BS_LDS && threadIdx.x < 2 * CNN_C) reinterpret_cast<LDS float *>(lds + B0OFF)[threadIdx.x] = bias[threadIdx.x - CNN_C] * (sw * CNS_ASCALE);
+        k1_ = CNS_ASCALE / F.s0; k2_ = k1_ * (1.0f / 2048.0f);
+    }
+    auto load_x = [&](int tix) { // (every piece is issued: an index outside the signal reads its nearest sample, and make_rows puts the zero in)
+        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
+        const float *xr = F.x + (size_t)n * F.Lc;
+        const int base = 3 * (tile * PB - 3) - 3;
+        for (int inst = wave; inst < NXD; inst += 4) {
+            int i = base + inst * 64 + lane;
+            i = i < 0 ? 0 : i >= F.Lc ? F.Lc - 1 : i;
+            __builtin_amdgcn_global_load_lds((const GLB float *)(xr + i), (LDS float *)(lds + XOFF + inst * 256), 4, 0, 0);
+        }
+    };
     int it = blockIdx.x;
     int buf = 0;
     // out of range = a float16 hi part of 32768 or more (or infinite), looked for as the largest bit pattern seen: the values are
@@ -250,7 +304,72 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     // hold what real neighbours hold, and a needless flag only costs the float32 repeat.)
     cnn_us2 hmax = {0, 0};
     const float cx = inv_sw * (1.0f / 2048.0f);
-    if (it < total) dma(it, 0);
+    // FIRST: the rows of tile tix -- positions tile PB - 3 .. -- from the samples load_x(tix) brought, into tile buffer 0: wave (mh, ph)
+    // makes channels 32 mh .. of the row subtiles ph, ph + 2, ...; B fragment: lane = (row 32 rs + l31, k-half lh), the second k-half zeros
+    auto make_rows = [&](int tix) {
+        const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
+        (void)n;
+        // (the lane index made opaque per call: the compiler otherwise keeps every subtile's row, sample and store address in registers
+        // across the k-loop, which at NT = 4 has none to spare -- they went to scratch, and a scratch reload waits for the previous
+        // step's stores)
+        int ln_ = lane;
+        asm volatile("" : "+v"(ln_));
+        const int l31 = ln_ & 31, lh = ln_ >> 5;
+        const cnn_h8 w0h = reinterpret_cast<const LDS cnn_h8 *>(lds + W0OFF)[(0 * 2 + mh) * 64 + lane];
+        const cnn_h8 w0l = reinterpret_cast<const LDS cnn_h8 *>(lds + W0OFF)[(1 * 2 + mh) * 64 + lane];
+        cnn_f32x16 bs0v;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const cnn_f4 b4 = *reinterpret_cast<const LDS cnn_f4 *>(lds + B0OFF + (32 * mh + 8 * g + 4 * lh) * 4);
+            bs0v[4 * g] = b4[0]; bs0v[4 * g + 1] = b4[1]; bs0v[4 * g + 2] = b4[2]; bs0v[4 * g + 3] = b4[3];
+        }
+        const LDS float *xs = reinterpret_cast<const LDS float *>(lds + XOFF);
+#pragma unroll
+        for (int rs = ph; rs < NRS; rs += 2) {
+            const int r = 32 * rs + l31, p = tile * PB - 3 + r;
+            const bool inside = p >= 0 && p < L1; // (a row outside the read is layer 1's zero padding)
+            cnn_h8 xh, xl;
+            float mxx = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = 3 * p - 3 + e;
+                float v = 0.0f;
+                if (e < CNN_K) { v = xs[3 * r + e]; asm volatile("" : "+v"(v)); } // (read by every lane: a select, not a branch per sample)
+                v = (e < CNN_K && lh == 0 && inside && i >= 0 && i < F.Lc) ? v : 0.0f;
+                _Float16 hi, lo;
+                cns_split(v, hi, lo);
+                xh[e] = hi; xl[e] = lo;
+                if (e < CNN_K) mxx = __builtin_fmaxf(mxx, __builtin_fabsf(v));
+            }
+            // a sample beyond the float16 range (or infinite): the call is repeated on the float32 kernels, like an activation beyond it.
+            // (A NaN sample makes its rows zero here as there: max(NaN, 0) = 0.)
+            if (mxx >= 32768.0f) hmax[0] = 0x7c00;
+            // (a row outside the read: zero factors instead of a select per pair of values)
+            const float k1 = inside ? k1_ : 0.0f, k2 = inside ? k2_ : 0.0f;
+            cnn_f32x16 am = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xh, bs0v, 0, 0, 0);
+            cnn_f32x16 ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, xh, zero16, 0, 0, 0);
+            ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, xl, ax, 0, 0, 0);
+            LDS char *srow = lds + r * CNS_ROWB + (32 * mh + 4 * lh) * 2;
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                cnn_h2 hq[2], lq[2];
+#pragma unroll
+                for (int q2 = 0; q2 < 2; q2++) {
+                    const cnn_f2 a2 = {am[4 * g + 2 * q2], am[4 * g + 2 * q2 + 1]}, x2 = {ax[4 * g + 2 * q2], ax[4 * g + 2 * q2 + 1]};
+                    cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){k2, k2}, a2 * k1);
+                    v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f});
+                    const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
+                    const cnn_f2 rs2 = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
+                    hq[q2] = hi; lq[q2] = __builtin_convertvector(rs2, cnn_h2);
+                    hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(cnn_us2, hi));
+                }
+                const cnn_h4 hh = {hq[0][0], hq[0][1], hq[1][0], hq[1][1]}, ll = {lq[0][0], lq[0][1], lq[1][0], lq[1][1]};
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 16 * g) = hh;
+                *reinterpret_cast<LDS cnn_h4 *>(srow + 128 + 16 * g) = ll;
+            }
+        }
+    };
+    if (it < total) { if constexpr (FIRST) load_x(it); else dma(it, 0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; it < total; it += gridDim.x) {
         // every wave has waited for its own share of tile `it` (before the loop / at the end of the previous step) and has
@@ -258,12 +377,27 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if constexpr (FIRST) {
+            // (one buffer: the staging rows of the step before have left it -- the barrier above -- and nothing else is in flight)
+            make_rows(it);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (it + gridDim.x < total) load_x(it + gridDim.x); // the next tile's samples arrive during this tile's k-loop
+            if constexpr (BS_LDS) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const cnn_f4 b4 = *reinterpret_cast<const LDS cnn_f4 *>(lds + B0OFF + (CNN_C + 32 * mh + 8 * g + 4 * lh) * 4);
+                    bsv[4 * g] = b4[0]; bsv[4 * g + 1] = b4[1]; bsv[4 * g + 2] = b4[2]; bsv[4 * g + 3] = b4[3];
+                }
+            }
+        }
         // the next tile's LDS-DMA pieces are issued INSIDE the k-loop, one per k-step (a piece costs ~60 cycles of issue among MFMAs,
         // 100-185 in a burst in front of them: MI355X_MICROARCH.md), still older than this step's stores for the counted wait below
         // (NT = 4 sits at the register limit -- 512 with the accumulators of four tiles: there the pieces stay a burst at the step's top)
         constexpr bool INLOOP = NT < 4;
-        if (!INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
-        const bool more = INLOOP && it + gridDim.x < total;
+        if (!FIRST && !INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
+        const bool more = !FIRST && INLOOP && it + gridDim.x < total;
         const GLB char *nsrc = nullptr;
         if (more) {
             const int tix = it + gridDim.x, nn = tix / tiles_per_read, tile2 = tix - nn * tiles_per_read;
@@ -419,15 +553,16 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         // the DMA issued at the top of this step is older than these NSTORE stores
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
         }
-        buf ^= 1;
+        if (!FIRST) buf ^= 1;
     }
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
 // (Round 4, measured and dropped: the same layers with two waves per SIMD -- k_cnn_conv64s8, no gain -- and with a tile's epilogue under
-// the next tile's MFMAs -- k_cnn_conv64p, slower; layer 0 computed inside layer 1's kernel -- no gain.  Sources and records:
-// tools/experiments/r05_pruned_variants.patch, profiles/r04_tried_and_dropped.txt.)
+// the next tile's MFMAs -- k_cnn_conv64p, slower; layer 0 computed inside layer 1's kernel as float32 fmaf chains -- no gain (round 5's
+// FIRST does it on the matrix cores).  Sources and records: tools/experiments/r05_pruned_variants.patch,
+// profiles/r04_tried_and_dropped.txt.)
 
 // ---------------------------------------------------------------- layer 3: ConvTranspose1d(64 -> 2, k 7, stride 3, pad 3) from split rows
 // the arithmetic of k_cnn_conv_out on a = hi + lo 2^-11; thread j makes the outputs 3 j, 3 j + 1, 3 j + 2 of both channels.

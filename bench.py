@@ -544,18 +544,24 @@ def run_workload(w, rank, world, local, dist, backend, cpu_pool=None, cpu_procs=
                 # split float32 operands, cnn_conv_split.h), the first / last layer stay float32 vector code -- priced against the
                 # float16 matrix peak for what the matrix cores execute, with the float32-equivalent rate beside it
                 f64l = 2.0 * (2 * 64 * 64 * 7) * L1 * Rs
+                row_passes = 4.0  # split activation rows the two kernels move through HBM: in and out of each
                 if os.environ.get("ADP_CNN_FOLD", "1") != "0":
                     # layer 3 rides in layer 2's kernel as one more GEMM on the matrix cores: 16 (of the instruction's 32) rows x 64 channels per
                     # position, on tiles that overlap by 2 of their 64 NT positions -- counted as executed (the padded rows, not the overlap)
                     f64l += 2.0 * (32 * 64) * L1 * Rs
+                    row_passes -= 1.0  # layer 2's rows never leave the chip
+                if os.environ.get("ADP_CNN_FUSE_IN", "1") != "0":
+                    # layer 0 rides in layer 1's kernel: 64 channels x 16 k-values (the 7 taps padded to the instruction's 16) per position
+                    f64l += 2.0 * (64 * 16) * L1 * Rs
+                    row_passes -= 1.0  # layer 0's rows are made in LDS
                 ms64 = sum(v for k, v in kavg.items() if k.startswith("k_cnn_conv64"))
-                rows_b = 272.0 * L1 * Rs  # one split activation row per position: read once and written once per layer
+                rows_b = 272.0 * L1 * Rs  # one split activation row per position
                 out["roofline"] = {"bound": "mfma", "dtype": "f16 x 3 (split float32 operands, float32 accumulate)",
                                    "kernel": "k_cnn_conv64 x 2 (split float16 MFMA)",
                                    "achieved": 3.0 * f64l / (ms64 * 1e-3) / 1e12, "peak": F16_MFMA_PEAK_TF, "unit": "TFLOP/s",
                                    "frac": 3.0 * f64l / (ms64 * 1e-3) / 1e12 / F16_MFMA_PEAK_TF, "traffic": None,
                                    "kernel_ms": ms64, "executed_flop_per_launch": 3.0 * f64l, "algorithmic_flop_per_launch": f_alg,
-                                   "hbm_GBps_of_the_two_layers": 4.0 * rows_b / (ms64 * 1e-3) / 1e9,
+                                   "hbm_GBps_of_the_two_layers": row_passes * rows_b / (ms64 * 1e-3) / 1e9,
                                    "conv_stack_ms": conv_ms, "f32_equivalent_tflops": f_eq,
                                    # the step's float32-equivalent FLOP/s over the rate this stack can reach at best: three float16 MFMAs per
                                    # block of products = a third of the float16 matrix peak (833 TF); never above 1

@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_SERIES_PIPE", "ADP_CNN_OVERLAP", "ADP_N1_S0", "ADP_SERIES_PIPE_LLR", "ADP_CNN_FOLD")
+SWITCHES = ("ADP_SERIES_PIPE", "ADP_CNN_OVERLAP", "ADP_N1_S0", "ADP_SERIES_PIPE_LLR", "ADP_CNN_FOLD", "ADP_CNN_FUSE_IN")
 
 
 def _with_env(env, fn):
@@ -83,7 +83,10 @@ def test_cnn_path_variants_give_the_same_rows(window, k, quantise, windows):
     ref = None
     # (ADP_CNN_FOLD=0: layer 3 as a kernel of its own sums the same products in another order -- scores differ in their last bits, which
     # flips a near-tied candidate on about one read in 10^4: not on these)
-    for env in ({}, {"ADP_SERIES_PIPE": "0"}, {"ADP_CNN_FOLD": "0", "ADP_CNN_OVERLAP": "0"}, {"ADP_CNN_FOLD": "0"}, {"ADP_SERIES_PIPE": "0", "ADP_CNN_FOLD": "0", "ADP_CNN_OVERLAP": "0"}):
+    # (ADP_CNN_FUSE_IN=0: layer 0 as a kernel of its own is a float32 fmaf chain, in layer 1's prologue it is a split-operand product: the
+    # same class of last-bit difference)
+    for env in ({}, {"ADP_SERIES_PIPE": "0"}, {"ADP_CNN_FOLD": "0", "ADP_CNN_OVERLAP": "0"}, {"ADP_CNN_FOLD": "0"}, {"ADP_CNN_FUSE_IN": "0"},
+                {"ADP_CNN_FUSE_IN": "0", "ADP_CNN_FOLD": "0"}, {"ADP_SERIES_PIPE": "0", "ADP_CNN_FOLD": "0", "ADP_CNN_OVERLAP": "0"}):
         def run():
             eng = lib.Engine(spc, n, m, device=0)
             try:
