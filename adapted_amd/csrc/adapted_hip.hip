@@ -960,7 +960,7 @@ int adp_detect_llr_i16(adp_handle *h, const int16_t *raw, const int32_t *full_le
 
 __global__ void k_debug_log(const double *in, double *out, int n)
 {
-    __shared__ double lt_[3 * LOGCR_N];
+    __shared__ __attribute__((aligned(16))) double lt_[3 * LOGCR_N];
     for (int i = threadIdx.x; i < 3 * LOGCR_N; i += blockDim.x) lt_[i] = g_logcr_table[i];
     __syncthreads();
     const LDS double *lt = (const LDS double *)lt_;

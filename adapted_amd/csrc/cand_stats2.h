@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(THREADS) k_cand_stats2(const float *__restrict
                                                             const float *__restrict__ series, int cap, const int8_t *__restrict__ have,
                                                             CandStat *__restrict__ out)
 {
-    extern __shared__ unsigned char cs2_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char cs2_raw[];
     typedef Cs2Sh<HB> Sh;
     constexpr int NB = Sh::NB, NW = THREADS / 64, BPT = NB / THREADS, POOL = 3 * NB, NQ = CS2_MAXC * CS2_QPC;
     static_assert(BPT >= 1 && BPT <= 8 && NW <= 16, "shape");

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64(const float *__restrict__
                                                        int n_reads, int L1, int Lpad, int tiles_per_read)
 {
     constexpr int PB = 64 * NT, S = PB + 8, TILE = CNN_C * S, NDMA = TILE / 256;
-    extern __shared__ float cnn_lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) float cnn_lds_raw[];
     LDS float *lds = (LDS float *)cnn_lds_raw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int mh = wave & 1, ph = wave >> 1;

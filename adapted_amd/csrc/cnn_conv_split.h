@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     constexpr int PBS = LAST ? PB - 2 : PB; // positions a tile advances by
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
     static_assert(NSTORE * 256 >= PB * 17 && (NSTORE - 1) * 256 < PB * 17, "the epilogue issues exactly NSTORE stores per thread: the s_waitcnt below counts them");
-    extern __shared__ float cns_lds_raw[];
+    extern __shared__ __attribute__((aligned(16))) float cns_lds_raw[];
     LDS char *lds = (LDS char *)cns_lds_raw;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mh = wave & 1, ph = wave >> 1;

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) k_cnn_argmax(const float *__restrict__ sco
 __global__ void __launch_bounds__(1024) k_cnn_rowlink(const long long *__restrict__ apos, const long long *__restrict__ ppos, int n_all,
                                                       int mbsize, int32_t *__restrict__ lnz)
 {
-    __shared__ int part[1024];
+    __shared__ __attribute__((aligned(16))) int part[1024];
     const int m0 = blockIdx.x * mbsize;
     const int n = min(n_all - m0, mbsize);
     apos += m0; ppos += m0; lnz += m0;
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64) k_cnn_topk(const float *__restrict__ score
                                                  uint32_t *__restrict__ stw_g, int wpr,
                                                  int32_t *__restrict__ cand, int32_t *__restrict__ cnt)
 {
-    extern __shared__ uint32_t ct_raw[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t ct_raw[];
     const int m0 = (blockIdx.x / mbsize) * mbsize;
     const int n = min(n_all - m0, mbsize);
     const int r = blockIdx.x - m0;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(1024) k_cnn_bounds(const long long *__restrict
                                                      const int32_t *__restrict__ cand, const int32_t *__restrict__ cnt, int n_all, int mbsize, int k,
                                                      int ds, int off, int64_t *__restrict__ bounds)
 {
-    __shared__ int part[1024];
+    __shared__ __attribute__((aligned(16))) int part[1024];
     const int t = threadIdx.x;
     const int kk = k < 1 ? 1 : k; // columns behind the adapter
     const int m0 = blockIdx.x * mbsize;

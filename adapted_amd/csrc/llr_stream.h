@@ -52,9 +52,9 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
                                                    const int64_t *__restrict__ ranges, const int32_t *__restrict__ full_len,
                                                    int tails_nan = 0, SpHead *__restrict__ sp_head = nullptr, float sp_thr = 0.f)
 {
-    extern __shared__ float tile[];
+    extern __shared__ __attribute__((aligned(16))) float tile[]; // (16-byte aligned: the static words in front of it would leave every float4 access of the tile misaligned -- slow, not wrong)
     __shared__ int s_nan;
-    __shared__ int s_sp[2];
+    __shared__ __attribute__((aligned(16))) int s_sp[2];
     const int r = blockIdx.x;
     const MbState st = mbs[r / mbsize];
     if (st.status != ADP_MB_OK) { if (threadIdx.x == 0) nvalid[r] = 0; return; }
@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(64 * GAINS_WPB, 4) k_gains(const float *__rest
 {
     // GAINS_WPB waves (reads) per block share log_cr's table; everything else is private to a wave, so the only
     // block-wide barrier is the one after the table copy
-    __shared__ double sg_[GAINS_WPB][64 * (CK + 1)];
-    __shared__ double lt_[3 * LOGCR_N]; // log_cr's table
+    __shared__ __attribute__((aligned(16))) double sg_[GAINS_WPB][64 * (CK + 1)];
+    __shared__ __attribute__((aligned(16))) double lt_[3 * LOGCR_N]; // log_cr's table
     LDS double *sg = (LDS double *)sg_[threadIdx.x >> 6];
     const int r = blockIdx.x * GAINS_WPB + (threadIdx.x >> 6);
     const int ln = lane_id();

@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(SIG sig, int n_rea
                                                                uint32_t *__restrict__ hv, int row_step, int col_div, int pdiv,
                                                                const int32_t *__restrict__ full_len)
 {
-    __shared__ uint32_t tab_[2 * N1H_SLOTS];
+    __shared__ __attribute__((aligned(16))) uint32_t tab_[2 * N1H_SLOTS];
     const int mb = blockIdx.y;
     if (mbs[mb].status != ADP_MB_OK) return;
     const N1Fused f = fz[mb];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_heavy_scan(SIG sig, int n_rea
 __global__ void __launch_bounds__(64) k_n1_heavy_pick(const MbState *__restrict__ mbs, N1Fused *__restrict__ fz, uint32_t *__restrict__ hv,
                                                        int n_mb)
 {
-    __shared__ uint32_t keys_[N1H_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t keys_[N1H_MAX];
     const int mb = blockIdx.x;
     const int ln = threadIdx.x;
     uint32_t *g = hv + (size_t)mb * N1H_WORDS;
@@ -266,10 +266,10 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_fused(SIG sig, int n_reads, i
                                                           unsigned long long *__restrict__ fcnt, float *__restrict__ cbuf,
                                                           uint32_t *__restrict__ hv, const int32_t *__restrict__ full_len)
 {
-    __shared__ float cbm_[N1F_LDS_M];
-    __shared__ float cbb_[N1F_LDS_B];
-    __shared__ uint32_t cnt2_[2], base2[2];
-    __shared__ uint32_t hkeys_[N1H_MAX], hcnt_[N1H_MAX];
+    __shared__ __attribute__((aligned(16))) float cbm_[N1F_LDS_M];
+    __shared__ __attribute__((aligned(16))) float cbb_[N1F_LDS_B];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt2_[2], base2[2];
+    __shared__ __attribute__((aligned(16))) uint32_t hkeys_[N1H_MAX], hcnt_[N1H_MAX];
     const LDS uint32_t *hkeys = (const LDS uint32_t *)hkeys_;
     LDS uint32_t *hcnt = (LDS uint32_t *)hcnt_;
     LDS float *cbm = (LDS float *)cbm_;
@@ -512,10 +512,10 @@ __global__ void __launch_bounds__(1024) k_n1_fused_finish(MbState *__restrict__ 
                                                            unsigned long long *__restrict__ fcnt, const float *__restrict__ cbuf,
                                                            double thresh, const uint32_t *__restrict__ hv)
 {
-    __shared__ uint32_t hist_[N1F_BINS];
-    __shared__ N1Sel S_;
-    __shared__ float hval_[N1H_MAX];
-    __shared__ uint32_t hwm_[N1H_MAX], hwb_[N1H_MAX], hsum_[2];
+    __shared__ __attribute__((aligned(16))) uint32_t hist_[N1F_BINS];
+    __shared__ __attribute__((aligned(16))) N1Sel S_;
+    __shared__ __attribute__((aligned(16))) float hval_[N1H_MAX];
+    __shared__ __attribute__((aligned(16))) uint32_t hwm_[N1H_MAX], hwb_[N1H_MAX], hsum_[2];
     LDS uint32_t *hist = (LDS uint32_t *)hist_;
     LDS N1Sel *S = (LDS N1Sel *)&S_;
     const int mb = blockIdx.x;

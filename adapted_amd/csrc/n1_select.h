@@ -90,9 +90,9 @@ __global__ void __launch_bounds__(N1_THREADS) k_n1_hist(SIG sig, int n_reads, in
                                                          int row_step, int when, uint32_t *__restrict__ cbuf, int collect, int col_div, int pdiv = 8,
                                                          const int32_t *__restrict__ full_len = nullptr)
 {
-    __shared__ uint32_t hist_[N1_BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t hist_[N1_BINS];
     __shared__ uint32_t sbelow, sbelow2, cb_cnt_, cb_base;
-    __shared__ uint32_t cb_[PASS == 1 ? N1_CB_LDS : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t cb_[PASS == 1 ? N1_CB_LDS : 1];
     LDS uint32_t *hist = (LDS uint32_t *)hist_;
     LDS uint32_t *cb = (LDS uint32_t *)cb_;
     LDS uint32_t *cb_cnt = (LDS uint32_t *)&cb_cnt_;
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) k_n1_pick(MbState *__restrict__ mbs, uint
                                                  uint32_t *__restrict__ gbelow, unsigned long long *__restrict__ gcnt,
                                                  int mode, double thresh)
 {
-    __shared__ unsigned long long part[256];
+    __shared__ __attribute__((aligned(16))) unsigned long long part[256];
     __shared__ int s_bin, s_lowbin;
     __shared__ unsigned long long s_before, s_total;
     const int mb = blockIdx.x;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(1024) k_n1_finish(MbState *__restrict__ mbs, c
                                                     unsigned long long *__restrict__ gcnt, uint32_t *__restrict__ gbelow, int mode,
                                                     double thresh)
 {
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[256];
     __shared__ uint32_t s_min, s_max, s_below, s_prefix, s_k;
     __shared__ int s_low, s_lastw;
     const int mb = blockIdx.x;

@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(64, 8) k_polya_peak(const double *__restrict__
                                                    uint32_t *__restrict__ mk_all, int32_t *__restrict__ polya_idx,
                                                    const int32_t *__restrict__ npk_all, const double *__restrict__ pkv_all = nullptr)
 {
-    extern __shared__ uint32_t stw_raw[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t stw_raw[];
     LDS uint32_t *stw = (LDS uint32_t *)stw_raw; // ordinal k is slot k + 4 (slots 0..3 stay PST_NONE)
     const int ln = lane_id();
     const int half = Lp / 2 + 1;

@@ -45,15 +45,22 @@ typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
 // The barrier between the waves of the pipeline: LDS traffic done (lgkmcnt), then s_barrier.  NOT __syncthreads(): that also waits
 // for the wave's outstanding global loads and stores (vmcnt(0)) -- the loader's prefetch and the storers' writes would be waited for
 // in every chunk, a memory round trip (~2-4 us) per 64 steps (measured: 12.0 ms per launch with it, the chains idle 2/3 of the time)
+#ifdef ADP_PHASE_TIMING
+// (diagnostic build: per role of workgroup 0 -- the longest chains -- the cycles between leaving a barrier and reaching the next one,
+// g_dbg[24 + 2 wave], and the cycles of the whole loop, g_dbg[25 + 2 wave]; tools/experiments/series_phase_shares.py)
+static __device__ inline long long sp_now() { long long t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; }
+#define SP_BARRIER() do { const long long tb_ = sp_now(); sp_work_ += tb_ - sp_t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); sp_t_ = sp_now(); } while (0)
+#else
 #define SP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 // grid = ceil(n_reads / SP_G); block = SP_THREADS; dynamic LDS = SP_LDS_FLOATS floats.  a_plan / n_plan / perm: k_series_plan, k_series_order
 __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__restrict__ sigs, int n_reads, int m, const int32_t *__restrict__ a_plan,
                                                                 const int32_t *__restrict__ n_plan, const int32_t *__restrict__ perm, int wv, int wm,
                                                                 float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
-    extern __shared__ float sp_raw[];
-    __shared__ int32_t rid_[SP_G], a_[SP_G], n_[SP_G];
+    extern __shared__ __attribute__((aligned(16))) float sp_raw[]; // (aligned: behind 580 bytes of static LDS every 16-byte access of the rings was misaligned -- ~270 cycles each, round 5)
+    __shared__ __attribute__((aligned(16))) int32_t rid_[SP_G], a_[SP_G], n_[SP_G];
     __shared__ int nmax_;
     LDS float *ring = (LDS float *)sp_raw;
     LDS float *tbuf = ring + SP_G * SP_S;
@@ -79,25 +86,43 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
     if (nmax <= 0) return; // (uniform: nothing in this group has series)
     const int nchunks = (nmax + SP_CH - 1) / SP_CH;
     constexpr int MASK = SP_RB - 1, NU = SP_G / 4;
+#ifdef ADP_PHASE_TIMING
+    long long sp_work_ = 0, sp_t_ = sp_now();
+    const long long sp_t0_ = sp_t_;
+    struct SpStamp { long long &w, &t; const long long &t0; int wave, ln; __device__ ~SpStamp() { if (blockIdx.x == 0 && ln == 0) { g_dbg[48 + 2 * wave] = (unsigned long long)w; g_dbg[49 + 2 * wave] = (unsigned long long)(sp_now() - t0); } } } sp_stamp_{sp_work_, sp_t_, sp_t0_, wave, ln};
+    if (blockIdx.x == 0 && ln == 0) { // where the waves sit: HW_ID's simd_id [5:4] and cu_id [11:8], a nibble pair per wave
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+        reinterpret_cast<unsigned char *>(&g_dbg[60])[wave] = (unsigned char)(((id >> 4) & 3) | (((id >> 8) & 15) << 4));
+    }
+#endif
 
     if (wave == 0) {
         // ---- loader: instruction u of a chunk brings 64 samples of the reads 4u .. 4u + 3, 16 lanes x 16 bytes each
         const int sub = ln & 15;
         const GLB float *xb[NU];
-        int last[NU];
+        int last[NU], nend[NU];
 #pragma unroll
         for (int u = 0; u < NU; u++) {
             const int q = 4 * u + (ln >> 4);
             xb[u] = (const GLB float *)sigs + (size_t)rid_of[q] * m + a_of[q];
             const int nq = n_of[q];
             last[u] = nq >= 4 ? nq - 4 : 0; // (what lies behind a slice's end is never used: any readable address will do)
+            nend[u] = nq;
         }
         // a chunk's loads are issued a WHOLE iteration before their samples go to LDS (two register sets in turn): issued at the end
         // of one iteration and consumed at the start of the next, every chunk waited a memory round trip (~2 us against ~0.8 us of chains)
         sp_f4u preA[NU], preB[NU];
         auto fetch = [&](int c, sp_f4u (&pre)[NU]) {
 #pragma unroll
-            for (int u = 0; u < NU; u++) { const int i = c * SP_CH + 4 * sub; pre[u] = *reinterpret_cast<const GLB sp_f4u *>(xb[u] + (i < last[u] ? i : last[u])); }
+            for (int u = 0; u < NU; u++) {
+                const int i = c * SP_CH + 4 * sub;
+#if defined(SP_ABL) && (SP_ABL & 1) // (timing only: no global loads)
+                pre[u] = (sp_f4u){(float)i, 1.f, 2.f, 3.f};
+#else
+                pre[u] = *reinterpret_cast<const GLB sp_f4u *>(xb[u] + (i < last[u] ? i : last[u]));
+#endif
+            }
         };
         auto put = [&](int c, const sp_f4u (&pre)[NU]) {
 #pragma unroll
@@ -108,7 +133,7 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                 LDS float *dst = ring + q * SP_S + (i & MASK);
                 const int lim = last[u];
                 if (i <= lim) *reinterpret_cast<LDS adp_v4f *>(dst) = (adp_v4f){pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-                else {
+                else if (i < nend[u]) { // (a vector wholly behind the end: nothing reads its cells -- the lanes of ended reads pass)
                     // the load was taken at `lim` instead of i: sample i + j sits at position i + j - lim of the vector, if inside it
                     const int sh = i - lim;
                     const float v[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
@@ -151,21 +176,38 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0;
                 for (; i < hi && i < wm; i++) { asum += mybuf[i & MASK]; if (i == wm - 1) myout[i - i0] = asum / (float)wm; }
-                adp_v4f a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
-                adp_v4f o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - wm) & MASK]);
-                for (; i + 4 <= hi; i += 4) {
-                    const adp_v4f a4 = a4n, o4 = o4n;
-                    const int inx = (i + 8 <= hi) ? i + 4 : i; // (the next group's samples first: an LDS round trip per group otherwise)
-                    a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[inx & MASK]);
-                    o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(inx - wm) & MASK]);
-                    adp_v4f r4;
-                    asum += a4.x - o4.x; r4.x = asum * inv;
-                    asum += a4.y - o4.y; r4.y = asum * inv;
-                    asum += a4.z - o4.z; r4.z = asum * inv;
-                    asum += a4.w - o4.w; r4.w = asum * inv;
-                    *reinterpret_cast<LDS adp_v4f *>(&myout[i - i0]) = r4;
+                if (i == i0 && hi == i0 + SP_CH) {
+                    // a whole chunk (nearly all of them): its 2 x 64 samples come to registers in one burst of LDS reads, the chain
+                    // runs without a wait, the 64 results leave in one burst (with a group's reads one group ahead -- round 4 -- every
+                    // group of four steps still waited ~0.2 us for them: 3.6 us per chunk where the instructions take 0.4)
+                    adp_v4f a4[SP_CH / 4], o4[SP_CH / 4];
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        a4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 & MASK) + 4 * j]); // (a chunk never wraps in the ring)
+                        o4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 + 4 * j - wm) & MASK]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        adp_v4f r4;
+                        asum += a4[j].x - o4[j].x; r4.x = asum * inv;
+                        asum += a4[j].y - o4[j].y; r4.y = asum * inv;
+                        asum += a4[j].z - o4[j].z; r4.z = asum * inv;
+                        asum += a4[j].w - o4[j].w; r4.w = asum * inv;
+                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4;
+                    }
+                } else {
+                    for (; i + 4 <= hi; i += 4) {
+                        const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
+                        const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - wm) & MASK]);
+                        adp_v4f r4;
+                        asum += a4.x - o4.x; r4.x = asum * inv;
+                        asum += a4.y - o4.y; r4.y = asum * inv;
+                        asum += a4.z - o4.z; r4.z = asum * inv;
+                        asum += a4.w - o4.w; r4.w = asum * inv;
+                        *reinterpret_cast<LDS adp_v4f *>(&myout[i - i0]) = r4;
+                    }
+                    for (; i < hi; i++) { asum += mybuf[i & MASK] - mybuf[(i - wm) & MASK]; myout[i - i0] = asum * inv; }
                 }
-                for (; i < hi; i++) { asum += mybuf[i & MASK] - mybuf[(i - wm) & MASK]; myout[i - i0] = asum * inv; }
             }
             SP_BARRIER();
         }
@@ -199,13 +241,28 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                         s0[g] = assqdm;
                     }
                 }
-                adp_v4f a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
-                adp_v4f o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - wv) & MASK]);
+                if (i == i0 && hi == i0 + SP_CH) {
+                    // (a whole chunk from registers, as in the mean wave)
+                    adp_v4f a4[SP_CH / 4], o4[SP_CH / 4];
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        a4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 & MASK) + 4 * j]);
+                        o4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 + 4 * j - wv) & MASK]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        adp_v4f t4;
+                        { const float d = a4[j].x - o4[j].x, p = o4[j].x - amean; amean += d * inv; t4.x = ((a4[j].x - amean) + p) * d; }
+                        { const float d = a4[j].y - o4[j].y, p = o4[j].y - amean; amean += d * inv; t4.y = ((a4[j].y - amean) + p) * d; }
+                        { const float d = a4[j].z - o4[j].z, p = o4[j].z - amean; amean += d * inv; t4.z = ((a4[j].z - amean) + p) * d; }
+                        { const float d = a4[j].w - o4[j].w, p = o4[j].w - amean; amean += d * inv; t4.w = ((a4[j].w - amean) + p) * d; }
+                        *reinterpret_cast<LDS adp_v4f *>(&myt[4 * j]) = t4;
+                    }
+                    i = hi;
+                }
                 for (; i + 4 <= hi; i += 4) {
-                    const adp_v4f a4 = a4n, o4 = o4n;
-                    const int inx = (i + 8 <= hi) ? i + 4 : i;
-                    a4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[inx & MASK]);
-                    o4n = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(inx - wv) & MASK]);
+                    const adp_v4f a4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[i & MASK]);
+                    const adp_v4f o4 = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i - wv) & MASK]);
                     adp_v4f t4;
                     { const float d = a4.x - o4.x, p = o4.x - amean; amean += d * inv; t4.x = ((a4.x - amean) + p) * d; }
                     { const float d = a4.y - o4.y, p = o4.y - amean; amean += d * inv; t4.y = ((a4.y - amean) + p) * d; }
@@ -229,6 +286,9 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         const float inv = (float)(1.0 / (double)wv);
         float s = 0.f;
         bool started = false;
+#ifdef ADP_PHASE_TIMING
+        long long sp_ld_ = 0, sp_cp_ = 0, sp_wr_ = 0;
+#endif
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - 1, i0 = c * SP_CH;
@@ -238,11 +298,50 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                 const int hi = n < i0 + SP_CH ? n : i0 + SP_CH;
                 int i = i0 > wv ? i0 : wv;
                 if (i < hi && !started) { s = s0[g]; started = true; }
-                adp_v4f t4n = *reinterpret_cast<const LDS adp_v4f *>(&myt[i - i0 < SP_CH ? i - i0 : 0]);
+                if (i == i0 && hi == i0 + SP_CH) {
+                    // (a whole chunk from registers, as in the mean wave)
+                    adp_v4f t4[SP_CH / 4];
+#ifdef ADP_PHASE_TIMING
+                    const long long ta_ = sp_now();
+#endif
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) t4[j] = *reinterpret_cast<const LDS adp_v4f *>(&myt[4 * j]);
+#ifdef ADP_PHASE_TIMING
+                    const long long tb2_ = sp_now();
+                    sp_ld_ += tb2_ - ta_;
+#endif
+#ifdef ADP_PHASE_TIMING
+                    adp_v4f r4s[SP_CH / 4];
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        adp_v4f r4;
+                        s += t4[j].x; if (s < 0) s = 0; r4.x = s * inv;
+                        s += t4[j].y; if (s < 0) s = 0; r4.y = s * inv;
+                        s += t4[j].z; if (s < 0) s = 0; r4.z = s * inv;
+                        s += t4[j].w; if (s < 0) s = 0; r4.w = s * inv;
+                        r4s[j] = r4;
+                    }
+                    asm volatile("" : "+v"(s));
+                    const long long tc_ = sp_now();
+                    sp_cp_ += tc_ - tb2_;
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4s[j];
+                    sp_wr_ += sp_now() - tc_;
+#else
+#pragma unroll
+                    for (int j = 0; j < SP_CH / 4; j++) {
+                        adp_v4f r4;
+                        s += t4[j].x; if (s < 0) s = 0; r4.x = s * inv;
+                        s += t4[j].y; if (s < 0) s = 0; r4.y = s * inv;
+                        s += t4[j].z; if (s < 0) s = 0; r4.z = s * inv;
+                        s += t4[j].w; if (s < 0) s = 0; r4.w = s * inv;
+                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4;
+                    }
+#endif
+                    i = hi;
+                }
                 for (; i + 4 <= hi; i += 4) {
-                    const adp_v4f t4 = t4n;
-                    const int inx = (i + 8 <= hi) ? i + 4 : i;
-                    t4n = *reinterpret_cast<const LDS adp_v4f *>(&myt[inx - i0]);
+                    const adp_v4f t4 = *reinterpret_cast<const LDS adp_v4f *>(&myt[i - i0]);
                     adp_v4f r4;
                     s += t4.x; if (s < 0) s = 0; r4.x = s * inv;
                     s += t4.y; if (s < 0) s = 0; r4.y = s * inv;
@@ -255,6 +354,9 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
             SP_BARRIER();
         }
         if (ln < SP_G && n > 0 && (s != s || (!started && s0[g] != s0[g]))) have[rid_of[g]] = 0;
+#ifdef ADP_PHASE_TIMING
+        if (blockIdx.x == 0 && ln == 0) { g_dbg[61] = (unsigned long long)sp_ld_; g_dbg[62] = (unsigned long long)sp_cp_; g_dbg[63] = (unsigned long long)sp_wr_; }
+#endif
     } else {
         // ---- storers: wave 4 the variances (two chunks behind part 1), wave 5 the means (one chunk behind): 16 lanes x 16 bytes per read
         const bool var = wave == 4;
@@ -273,13 +375,19 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - lag;
             if (c >= 0) {
+                adp_v4f vv4[NU]; // (all of the chunk's LDS reads first: one wait, not one per store)
+#pragma unroll
+                for (int u = 0; u < NU; u++) vv4[u] = *reinterpret_cast<const LDS adp_v4f *>(ob + (c & 1) * SP_G * SP_SO + (4 * u + (ln >> 4)) * SP_SO + 4 * sub);
 #pragma unroll
                 for (int u = 0; u < NU; u++) {
-                    const int q = 4 * u + (ln >> 4), e = 4 * sub, i = c * SP_CH + e;
-                    const adp_v4f v = *reinterpret_cast<const LDS adp_v4f *>(ob + (c & 1) * SP_G * SP_SO + q * SP_SO + e);
+                    const int e = 4 * sub, i = c * SP_CH + e;
+                    const adp_v4f v = vv4[u];
                     // series index of step i is i - (w - 1), defined for w - 1 <= i < n
+#if defined(SP_ABL) && (SP_ABL & 2) // (timing only: no global stores)
+                    if (v.x == 12345.678f)
+#endif
                     if (i >= w - 1 && i + 3 < nq[u]) *reinterpret_cast<GLB sp_f4u *>(sp[u] + (i - w + 1)) = (sp_f4u){v.x, v.y, v.z, v.w};
-                    else {
+                    else if (i + 3 >= w - 1 && i < nq[u]) { // (a vector wholly outside the series: the lanes of ended reads pass)
                         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int j = 0; j < 4; j++) if (i + j >= w - 1 && i + j < nq[u]) sp[u][i + j - w + 1] = vv[j];

@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(64) k_trace_cumsum(const double *__restrict__ 
                                                      double *__restrict__ c, double *__restrict__ c2)
 {
     constexpr int TILE = 512;
-    __shared__ double sx[TILE], sc[TILE], sq[TILE];
+    __shared__ __attribute__((aligned(16))) double sx[TILE], sc[TILE], sq[TILE];
     const int r = blockIdx.x, ln = threadIdx.x;
     const int n = len[r];
     const double *x = raw + (size_t)r * L;
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64) k_trace_gains(const double *__restrict__ c
                                                     const int32_t *__restrict__ start_, const int32_t *__restrict__ end_, int L, TraceArgs a,
                                                     double *__restrict__ gain)
 {
-    __shared__ double lt_[3 * LOGCR_N];
+    __shared__ __attribute__((aligned(16))) double lt_[3 * LOGCR_N];
     const int r = blockIdx.x, ln = threadIdx.x;
     for (int i = ln; i < 3 * LOGCR_N; i += 64) lt_[i] = g_logcr_table[i];
     const long n = len[r], start = start_[r], end = end_[r];

@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(256) k_series_plan(const int32_t *__restrict__
                                                      int kmax, adp_cfg cfg, int cap, int8_t *__restrict__ have, int32_t *__restrict__ a_of,
                                                      int32_t *__restrict__ n_of, uint32_t *__restrict__ cnt)
 {
-    __shared__ uint32_t hs_[MS_NBKT];
+    __shared__ __attribute__((aligned(16))) uint32_t hs_[MS_NBKT];
     LDS uint32_t *hs = (LDS uint32_t *)hs_;
     hs[threadIdx.x] = 0;
     __syncthreads();
@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(256) k_series_plan(const int32_t *__restrict__
 __global__ void __launch_bounds__(256) k_series_order(int n_reads, int cap, const int32_t *__restrict__ n_of, const uint32_t *__restrict__ cnt,
                                                       uint32_t *__restrict__ cursor, int32_t *__restrict__ perm)
 {
-    __shared__ uint32_t start_[MS_NBKT];
+    __shared__ __attribute__((aligned(16))) uint32_t start_[MS_NBKT];
     LDS uint32_t *start = (LDS uint32_t *)start_;
     {   // reads in longer classes come first: start[b] = sum of cnt[b' > b]
         const int b = threadIdx.x;
@@ -885,8 +885,8 @@ __global__ void __launch_bounds__(128) k_mvs_series_wave(const float *__restrict
                                                          const int32_t *__restrict__ n_plan, const int32_t *__restrict__ perm, adp_cfg cfg,
                                                          float *__restrict__ series, int cap, int8_t *__restrict__ have)
 {
-    extern __shared__ float ms_raw[];
-    __shared__ int32_t a_of_[MS_G], n_of_[MS_G], rid_of_[MS_G];
+    extern __shared__ __attribute__((aligned(16))) float ms_raw[];
+    __shared__ __attribute__((aligned(16))) int32_t a_of_[MS_G], n_of_[MS_G], rid_of_[MS_G];
     LDS int32_t *a_of = (LDS int32_t *)a_of_, *n_of = (LDS int32_t *)n_of_, *rid_of = (LDS int32_t *)rid_of_;
     const int wave = threadIdx.x >> 6, ln = lane_id();
     const int r0 = blockIdx.x * MS_G;
@@ -927,7 +927,7 @@ template <class SIG>
 __global__ void __launch_bounds__(64, VAL_WPE) __attribute__((amdgpu_waves_per_eu(VAL_WPE, VAL_WPE))) k_validate(ValidateInT<SIG> in, adp_cfg cfg, adp_row *__restrict__ rows,
                                                  PartReq *__restrict__ preq)
 {
-    __shared__ WaveScratch ws_;
+    __shared__ __attribute__((aligned(16))) WaveScratch ws_;
     LDS WaveScratch *ws = (LDS WaveScratch *)&ws_;
     LDS SegCache *sc = nullptr; // LDS mirror of the slice: measured slower (occupancy), kept switchable
     const int ln = lane_id();
@@ -1197,7 +1197,7 @@ template <class SIG>
 __global__ void __launch_bounds__(64) k_start_peak(SIG sigs, const int32_t *__restrict__ full_len, int n_reads,
                                                    int m, adp_cfg cfg, SpOut *__restrict__ out)
 {
-    extern __shared__ float sp_tile_raw[];
+    extern __shared__ __attribute__((aligned(16))) float sp_tile_raw[];
     LDS float *tile = (LDS float *)sp_tile_raw;
     const int r = blockIdx.x;
     const int ln = lane_id();
@@ -1281,7 +1281,7 @@ template <class SIG>
 __global__ void __launch_bounds__(64) k_sp_head(SIG sigs, const int32_t *__restrict__ full_len, int n_reads, int m, adp_cfg cfg,
                                                 int scan_to, SpHead *__restrict__ hd)
 {
-    extern __shared__ float sp_tile_raw[];
+    extern __shared__ __attribute__((aligned(16))) float sp_tile_raw[];
     LDS float *tile = (LDS float *)sp_tile_raw;
     const int r = blockIdx.x;
     const int ln = lane_id();
@@ -1339,7 +1339,7 @@ template <class SIG>
 __global__ void __launch_bounds__(64) k_sp_tail(SIG sigs, const int32_t *__restrict__ full_len, int n_reads, int m, adp_cfg cfg,
                                                 int cov0, int cov1, const SpHead *__restrict__ hd, SpOut *__restrict__ out)
 {
-    extern __shared__ float sp_tile_raw[];
+    extern __shared__ __attribute__((aligned(16))) float sp_tile_raw[];
     LDS float *tile = (LDS float *)sp_tile_raw;
     const int r = blockIdx.x;
     const int ln = lane_id();
@@ -1462,7 +1462,7 @@ __global__ void k_llr_bounds(const int32_t *__restrict__ adapter_idx, const int3
 __global__ void __launch_bounds__(256) k_cnn_pool(const float *__restrict__ sigs, int n_reads, int m, int off, int ds, int Lc,
                                                    float *__restrict__ out, int32_t *__restrict__ nan_cnt)
 {
-    extern __shared__ float cp_tiles_raw[]; // 4 waves x 64 * ds floats
+    extern __shared__ __attribute__((aligned(16))) float cp_tiles_raw[]; // 4 waves x 64 * ds floats
     const int r = blockIdx.x;
     const int ln = lane_id(), wv = threadIdx.x >> 6;
     LDS float *tile = (LDS float *)cp_tiles_raw + (size_t)wv * 64 * ds;
@@ -1481,7 +1481,7 @@ __global__ void __launch_bounds__(256) k_cnn_pool(const float *__restrict__ sigs
 
 __global__ void __launch_bounds__(64) k_cnn_prepare(int n_reads, int Lc, float *__restrict__ out, const int32_t *__restrict__ nan_cnt)
 {
-    __shared__ WaveScratch ws_;
+    __shared__ __attribute__((aligned(16))) WaveScratch ws_;
     const int r = blockIdx.x;
     const int ln = lane_id();
     float *o = out + (size_t)r * Lc;
