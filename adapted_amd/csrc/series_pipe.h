@@ -41,6 +41,7 @@ static __host__ __device__ inline bool sp_takes(int wv, int wm)
 }
 
 typedef float sp_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float sp_f2 __attribute__((ext_vector_type(2)));
 
 // The barrier between the waves of the pipeline: LDS traffic done (lgkmcnt), then s_barrier.  NOT __syncthreads(): that also waits
 // for the wave's outstanding global loads and stores (vmcnt(0)) -- the loader's prefetch and the storers' writes would be waited for
@@ -186,14 +187,17 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                         a4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 & MASK) + 4 * j]); // (a chunk never wraps in the ring)
                         o4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 + 4 * j - wm) & MASK]);
                     }
+                    // (what is not on the chain goes two steps per instruction -- v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations)
 #pragma unroll
                     for (int j = 0; j < SP_CH / 4; j++) {
-                        adp_v4f r4;
-                        asum += a4[j].x - o4[j].x; r4.x = asum * inv;
-                        asum += a4[j].y - o4[j].y; r4.y = asum * inv;
-                        asum += a4[j].z - o4[j].z; r4.z = asum * inv;
-                        asum += a4[j].w - o4[j].w; r4.w = asum * inv;
-                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4;
+                        const sp_f2 d01 = (sp_f2){a4[j].x, a4[j].y} - (sp_f2){o4[j].x, o4[j].y}, d23 = (sp_f2){a4[j].z, a4[j].w} - (sp_f2){o4[j].z, o4[j].w};
+                        sp_f2 s01, s23;
+                        asum += d01.x; s01.x = asum;
+                        asum += d01.y; s01.y = asum;
+                        asum += d23.x; s23.x = asum;
+                        asum += d23.y; s23.y = asum;
+                        const sp_f2 r01 = s01 * (sp_f2){inv, inv}, r23 = s23 * (sp_f2){inv, inv};
+                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = (adp_v4f){r01.x, r01.y, r23.x, r23.y};
                     }
                 } else {
                     for (; i + 4 <= hi; i += 4) {
@@ -249,14 +253,19 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                         a4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 & MASK) + 4 * j]);
                         o4[j] = *reinterpret_cast<const LDS adp_v4f *>(&mybuf[(i0 + 4 * j - wv) & MASK]);
                     }
+                    // per step: p = o - mean, mean += d / w (the chain), q = a - mean; d, d / w, q + p and (q + p) d go two steps per instruction
 #pragma unroll
                     for (int j = 0; j < SP_CH / 4; j++) {
-                        adp_v4f t4;
-                        { const float d = a4[j].x - o4[j].x, p = o4[j].x - amean; amean += d * inv; t4.x = ((a4[j].x - amean) + p) * d; }
-                        { const float d = a4[j].y - o4[j].y, p = o4[j].y - amean; amean += d * inv; t4.y = ((a4[j].y - amean) + p) * d; }
-                        { const float d = a4[j].z - o4[j].z, p = o4[j].z - amean; amean += d * inv; t4.z = ((a4[j].z - amean) + p) * d; }
-                        { const float d = a4[j].w - o4[j].w, p = o4[j].w - amean; amean += d * inv; t4.w = ((a4[j].w - amean) + p) * d; }
-                        *reinterpret_cast<LDS adp_v4f *>(&myt[4 * j]) = t4;
+                        const sp_f2 a01 = {a4[j].x, a4[j].y}, a23 = {a4[j].z, a4[j].w}, o01 = {o4[j].x, o4[j].y}, o23 = {o4[j].z, o4[j].w};
+                        const sp_f2 d01 = a01 - o01, d23 = a23 - o23;
+                        const sp_f2 e01 = d01 * (sp_f2){inv, inv}, e23 = d23 * (sp_f2){inv, inv};
+                        sp_f2 p01, q01, p23, q23;
+                        p01.x = o01.x - amean; amean += e01.x; q01.x = a01.x - amean;
+                        p01.y = o01.y - amean; amean += e01.y; q01.y = a01.y - amean;
+                        p23.x = o23.x - amean; amean += e23.x; q23.x = a23.x - amean;
+                        p23.y = o23.y - amean; amean += e23.y; q23.y = a23.y - amean;
+                        const sp_f2 t01 = (q01 + p01) * d01, t23 = (q23 + p23) * d23;
+                        *reinterpret_cast<LDS adp_v4f *>(&myt[4 * j]) = (adp_v4f){t01.x, t01.y, t23.x, t23.y};
                     }
                     i = hi;
                 }
@@ -286,9 +295,6 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
         const float inv = (float)(1.0 / (double)wv);
         float s = 0.f;
         bool started = false;
-#ifdef ADP_PHASE_TIMING
-        long long sp_ld_ = 0, sp_cp_ = 0, sp_wr_ = 0;
-#endif
         SP_BARRIER();                                   // P
         for (int k = 0; k < nchunks + 2; k++) {
             const int c = k - 1, i0 = c * SP_CH;
@@ -299,45 +305,21 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
                 int i = i0 > wv ? i0 : wv;
                 if (i < hi && !started) { s = s0[g]; started = true; }
                 if (i == i0 && hi == i0 + SP_CH) {
-                    // (a whole chunk from registers, as in the mean wave)
+                    // a whole chunk from registers, as in the mean wave.  (The clamp as max(ssq + t, 0) would shorten the chain from 18.5 to 13
+                    // cycles per step -- tools/chain_latency.hip -- but drops a NaN the comparison keeps, and this wave is not the slowest.)
                     adp_v4f t4[SP_CH / 4];
-#ifdef ADP_PHASE_TIMING
-                    const long long ta_ = sp_now();
-#endif
 #pragma unroll
                     for (int j = 0; j < SP_CH / 4; j++) t4[j] = *reinterpret_cast<const LDS adp_v4f *>(&myt[4 * j]);
-#ifdef ADP_PHASE_TIMING
-                    const long long tb2_ = sp_now();
-                    sp_ld_ += tb2_ - ta_;
-#endif
-#ifdef ADP_PHASE_TIMING
-                    adp_v4f r4s[SP_CH / 4];
 #pragma unroll
                     for (int j = 0; j < SP_CH / 4; j++) {
-                        adp_v4f r4;
-                        s += t4[j].x; if (s < 0) s = 0; r4.x = s * inv;
-                        s += t4[j].y; if (s < 0) s = 0; r4.y = s * inv;
-                        s += t4[j].z; if (s < 0) s = 0; r4.z = s * inv;
-                        s += t4[j].w; if (s < 0) s = 0; r4.w = s * inv;
-                        r4s[j] = r4;
+                        sp_f2 s01, s23;
+                        s += t4[j].x; if (s < 0) s = 0; s01.x = s;
+                        s += t4[j].y; if (s < 0) s = 0; s01.y = s;
+                        s += t4[j].z; if (s < 0) s = 0; s23.x = s;
+                        s += t4[j].w; if (s < 0) s = 0; s23.y = s;
+                        const sp_f2 r01 = s01 * (sp_f2){inv, inv}, r23 = s23 * (sp_f2){inv, inv};
+                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = (adp_v4f){r01.x, r01.y, r23.x, r23.y};
                     }
-                    asm volatile("" : "+v"(s));
-                    const long long tc_ = sp_now();
-                    sp_cp_ += tc_ - tb2_;
-#pragma unroll
-                    for (int j = 0; j < SP_CH / 4; j++) *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4s[j];
-                    sp_wr_ += sp_now() - tc_;
-#else
-#pragma unroll
-                    for (int j = 0; j < SP_CH / 4; j++) {
-                        adp_v4f r4;
-                        s += t4[j].x; if (s < 0) s = 0; r4.x = s * inv;
-                        s += t4[j].y; if (s < 0) s = 0; r4.y = s * inv;
-                        s += t4[j].z; if (s < 0) s = 0; r4.z = s * inv;
-                        s += t4[j].w; if (s < 0) s = 0; r4.w = s * inv;
-                        *reinterpret_cast<LDS adp_v4f *>(&myout[4 * j]) = r4;
-                    }
-#endif
                     i = hi;
                 }
                 for (; i + 4 <= hi; i += 4) {
@@ -354,9 +336,6 @@ __global__ void __launch_bounds__(SP_THREADS) k_mvs_series_pipe(const float *__r
             SP_BARRIER();
         }
         if (ln < SP_G && n > 0 && (s != s || (!started && s0[g] != s0[g]))) have[rid_of[g]] = 0;
-#ifdef ADP_PHASE_TIMING
-        if (blockIdx.x == 0 && ln == 0) { g_dbg[61] = (unsigned long long)sp_ld_; g_dbg[62] = (unsigned long long)sp_cp_; g_dbg[63] = (unsigned long long)sp_wr_; }
-#endif
     } else {
         // ---- storers: wave 4 the variances (two chunks behind part 1), wave 5 the means (one chunk behind): 16 lanes x 16 bytes per read
         const bool var = wave == 4;

@@ -26,4 +26,3 @@ for w in range(6):
     print("wave %d %-12s work %9d cycles = %.2f us per chunk, loop %9d cycles = %.2f ms at 2.4 GHz (%.2f us per chunk)"
           % (w, names[w], work, work / 2400.0 / ((L + 63) // 64), tot, tot / 2.4e6, tot / 2400.0 / ((L + 63) // 64)))
 print("simd of waves 0..5:", [int((int(d[60]) >> (8 * w)) & 3) for w in range(6)], " cu:", [int((int(d[60]) >> (8 * w + 4)) & 15) for w in range(6)])
-print("var part 2, whole chunks: LDS reads %.2f us per chunk, chain %.2f us, LDS writes %.2f us per chunk" % tuple(int(d[j]) / 2400.0 / ((L + 63) // 64) for j in (61, 62, 63)))
