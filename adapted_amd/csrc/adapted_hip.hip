@@ -1421,6 +1421,7 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
     // rows of layer 0 in HBM
     const bool fuse_in = env_int("ADP_CNN_FUSE_IN", 1) != 0;
     const int tiles_last = (L1 + PB - 3) / (PB - 2); // tiles of the folded layer: they advance by PB - 2 positions
+    const int tiles_first = (L1 + PB - 7) / (PB - 6); // ... of the layer that makes its input rows: by PB - 6
     const bool overlap = env_int("ADP_CNN_OVERLAP", 1) != 0 && !fold && !fuse_in;
     if (overlap && !h->ev_conv[0]) {
         for (int i = 0; i < 3; i++) if (hipEventCreateWithFlags(&h->ev_conv[i], hipEventDisableTiming) != hipSuccess) { g_err = "hipEventCreate failed"; return ADP_ERR_HIP; }
@@ -1455,9 +1456,9 @@ static int cnn_forward_split(adp_handle *h, adp_handle *wh, const float *prepare
                              : launch_conv64s<2, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_last, flag, w3sp, W + CNN_B3, inv_s3, sc, Lo);
             } else if (layer == 0 && fuse_in) {
                 const CnsFirst first{x, Lc, wsp + (size_t)2 * CNS_WSP_LAYER + CNS_W3SP, W + CNN_B0, wh->cnn_sw[3]};
-                rc = NT == 4 ? launch_conv64s<4, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
-                   : NT == 3 ? launch_conv64s<3, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
-                             : launch_conv64s<2, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag, nullptr, nullptr, 0.f, nullptr, 0, first);
+                rc = NT == 4 ? launch_conv64s<4, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_first, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
+                   : NT == 3 ? launch_conv64s<3, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_first, flag, nullptr, nullptr, 0.f, nullptr, 0, first)
+                             : launch_conv64s<2, false, true>(h, in, out, w, b, sw, n, L1, Lrows, tiles_first, flag, nullptr, nullptr, 0.f, nullptr, 0, first);
             } else
                 rc = NT == 4 ? launch_conv64s<4, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)
                    : NT == 3 ? launch_conv64s<3, false>(h, in, out, w, b, sw, n, L1, Lrows, tiles, flag)

@@ -28,6 +28,10 @@
 // from LDS), K = (tap, channel).
 #pragma once
 #include "cnn_conv.h"
+#ifdef ADP_PHASE_TIMING
+#include "common.h"
+extern __device__ unsigned long long g_dbg[ADP_NDBG];
+#endif
 
 typedef _Float16 cnn_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cnn_h4 __attribute__((ext_vector_type(4)));
@@ -215,9 +219,9 @@ __global__ void __launch_bounds__(256) k_cnn_conv_in_s(const float *__restrict__
 // (d = 1, 2).  A tile's first and last position only lend their partial sums: tiles advance by PB - 2 positions and start at -1.
 // No rows of layer 2 in HBM (1.8 MB per read written and read back) and no k_cnn_conv_out_s.
 // FIRST (round 5): layer 0 -- Conv1d(1 -> 64, k 7, stride 3, pad 3) + ReLU -- in this kernel's prologue.  No input rows in HBM: the
-// tile's PB + 6 rows are made in LDS from the prepared signal by 3 MFMAs per 32 rows and channel half (k_cns_split_w0's A fragments;
+// tile's input rows are made in LDS from the prepared signal by 3 MFMAs per 32 rows and channel half (k_cns_split_w0's A fragments;
 // the samples of a row are its B fragment, loaded a tile ahead), converted like an epilogue's results; rows outside [0, L1) are the
-// zero padding.  (Round 3 made these rows with float32 fmaf chains in the one wave per SIMD: no gain; on the matrix cores they cost
+// zero padding.  Tiles advance by PB - 6 positions: the PB rows made are what PB - 6 positions need.  (Round 3 made these rows with float32 fmaf chains in the one wave per SIMD: no gain; on the matrix cores they cost
 // 11 MFMAs per wave and tile.)  No k_cnn_conv_in_s, 1.8 MB per read not written and not read back.
 template <int NT, bool LAST = false, bool FIRST = false>
 __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restrict__ in, _Float16 *__restrict__ out,
@@ -229,7 +233,10 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 {
     static_assert(!(FIRST && LAST), "layer 1 takes layer 0 in, layer 2 takes layer 3 in");
     constexpr int PB = 64 * NT, R = PB + 6, TILE_B = (R * CNS_ROWB + 1023) / 1024 * 1024, NDMA = TILE_B / 1024;
-    constexpr int PBS = LAST ? PB - 2 : PB; // positions a tile advances by
+    // positions a tile advances by.  FIRST: PB - 6, so that the rows a tile needs (PBS + 6) are exactly its 2 NT subtiles of 32 -- a seventh
+    // subtile for six rows cost a quarter of the prologue at NT = 3; the tile's last six positions are computed from rows nobody made and
+    // are dropped (zeroed before the range check, not stored): 3 % more tiles
+    constexpr int PBS = LAST ? PB - 2 : FIRST ? PB - 6 : PB;
     constexpr int NSTORE = (PB * 17 + 255) / 256; // vector-memory instructions of one epilogue: 16-byte pieces of PB rows over 256 threads
     static_assert(NSTORE * 256 >= PB * 17 && (NSTORE - 1) * 256 < PB * 17, "the epilogue issues exactly NSTORE stores per thread: the s_waitcnt below counts them");
     extern __shared__ __attribute__((aligned(16))) float cns_lds_raw[];
@@ -274,10 +281,10 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         for (int cg = 0; cg < 4; cg++) { ah[cg] = wp[(size_t)(cg * 2) * 64]; al[cg] = wp[(size_t)(cg * 2 + 1) * 64]; }
     }
     // FIRST: the second tile buffer is not one (the rows are made in place): it holds the samples of the next tile's rows (LDS-DMA, a dword
-    // per lane: x[3 (tile PB - 3) - 3 ..], 3 R + 4 of them), layer 0's A fragments and its bias vector -- nothing of layer 0 in registers
+    // per lane: x[3 (tile PBS - 3) - 3 ..], 3 PB + 4 of them), layer 0's A fragments and its bias vector -- nothing of layer 0 in registers
     // across the k-loop
-    constexpr int NRS = (R + 31) / 32, NXD = (3 * R + 4 + 63) / 64;
-    constexpr int XOFF = (32 * NRS * CNS_ROWB + 1023) / 1024 * 1024; // (whole 32-row subtiles are written: no branch around the last one's stores)
+    constexpr int NRS = 2 * NT, NXD = (3 * PB + 4 + 63) / 64; // (rows made per tile: PB = PBS + 6)
+    constexpr int XOFF = TILE_B;
     constexpr int W0OFF = XOFF + 4096, B0OFF = XOFF + 8192;
     static_assert(NXD * 256 + 7 * 4 + 3 * 32 * 4 <= 4096 && B0OFF + 512 <= 2 * TILE_B, "layer 0's operands fit in the second tile buffer");
     float k1_ = 0.f, k2_ = 0.f;
@@ -290,7 +297,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     auto load_x = [&](int tix) { // (every piece is issued: an index outside the signal reads its nearest sample, and make_rows puts the zero in)
         const int n = tix / tiles_per_read, tile = tix - n * tiles_per_read;
         const float *xr = F.x + (size_t)n * F.Lc;
-        const int base = 3 * (tile * PB - 3) - 3;
+        const int base = 3 * (tile * PBS - 3) - 3;
         for (int inst = wave; inst < NXD; inst += 4) {
             int i = base + inst * 64 + lane;
             i = i < 0 ? 0 : i >= F.Lc ? F.Lc - 1 : i;
@@ -326,7 +333,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         const LDS float *xs = reinterpret_cast<const LDS float *>(lds + XOFF);
 #pragma unroll
         for (int rs = ph; rs < NRS; rs += 2) {
-            const int r = 32 * rs + l31, p = tile * PB - 3 + r;
+            const int r = 32 * rs + l31, p = tile * PBS - 3 + r;
             const bool inside = p >= 0 && p < L1; // (a row outside the read is layer 1's zero padding)
             cnn_h8 xh, xl;
             float mxx = 0.0f;
@@ -371,6 +378,16 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     };
     if (it < total) { if constexpr (FIRST) load_x(it); else dma(it, 0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ADP_PHASE_TIMING
+    // (diagnostic build: cycles of wave 0 of workgroup 0 per phase of a step, summed over the launch: g_dbg[64] rows made / tile awaited,
+    // [65] k-loop, [66] conversion, [67] layer 3 or copy-out, [68] steps; layers 2 + 3: 70 .. 74)
+    auto cns_now = []() { long long t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
+    long long ph_[4] = {0, 0, 0, 0}, pt_ = cns_now();
+    long long nst_ = 0;
+#define CNS_PH(k) do { const long long t_ = cns_now(); ph_[k] += t_ - pt_; pt_ = t_; } while (0)
+#else
+#define CNS_PH(k) do { } while (0)
+#endif
     for (; it < total; it += gridDim.x) {
         // every wave has waited for its own share of tile `it` (before the loop / at the end of the previous step) and has
         // finished reading the other buffer
@@ -395,6 +412,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         // the next tile's LDS-DMA pieces are issued INSIDE the k-loop, one per k-step (a piece costs ~60 cycles of issue among MFMAs,
         // 100-185 in a burst in front of them: MI355X_MICROARCH.md), still older than this step's stores for the counted wait below
         // (NT = 4 sits at the register limit -- 512 with the accumulators of four tiles: there the pieces stay a burst at the step's top)
+        CNS_PH(0);
         constexpr bool INLOOP = NT < 4;
         if (!FIRST && !INLOOP && it + gridDim.x < total) dma(it + gridDim.x, buf ^ 1);
         const bool more = !FIRST && INLOOP && it + gridDim.x < total;
@@ -441,6 +459,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
 #endif
             asm volatile("" ::: "memory");
         }
+        CNS_PH(1);
         const int n = it / tiles_per_read, tile = it - n * tiles_per_read;
         // EPILOGUE through LDS: the waves lay their split results down in the tile they have just consumed, in the rows' HBM
         // layout, and the workgroup copies the PB rows out as one contiguous range, 16 bytes per lane (a lane's own 8-byte
@@ -454,7 +473,8 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             LDS char *srow = stg + (ph * (NT * 32) + 32 * j + l31) * CNS_ROWB + (32 * mh + 4 * lh) * 2;
             // LAST: a row outside the read is layer 3's zero padding (its activation of the padded input is not zero)
             const int pos_ = tile * PBS - 1 + ph * (NT * 32) + 32 * j + l31;
-            const bool keep_ = !LAST || (pos_ >= 0 && pos_ < L1); // (a select, not a factor: position -1 is computed from the dump row in front of the read)
+            // (a select, not a factor: position -1 is computed from the dump row in front of the read; FIRST: the last six positions from rows nobody made)
+            const bool keep_ = LAST ? (pos_ >= 0 && pos_ < L1) : FIRST ? (ph * (NT * 32) + 32 * j + l31 < PBS) : true;
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 // two values per instruction where the hardware has a packed form (v_pk_mul / v_pk_fma / v_cvt_pk_f16_f32 / v_pk_add):
@@ -465,7 +485,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                     const cnn_f2 a2 = {am[j][4 * g + 2 * q], am[j][4 * g + 2 * q + 1]}, x2 = {ax[j][4 * g + 2 * q], ax[j][4 * g + 2 * q + 1]};
                     cnn_f2 v = __builtin_elementwise_fma(x2, (cnn_f2){cx, cx}, a2 * inv_sw);
                     v = __builtin_elementwise_max(v, (cnn_f2){0.f, 0.f}); // (a NaN becomes 0, as `v > 0 ? v : 0` makes it in k_cnn_conv64)
-                    if (LAST && !keep_) v = (cnn_f2){0.f, 0.f};
+                    if ((LAST || FIRST) && !keep_) v = (cnn_f2){0.f, 0.f};
                     const cnn_h2 hi = __builtin_convertvector(v, cnn_h2);
                     const cnn_f2 rs = (v - __builtin_convertvector(hi, cnn_f2)) * 2048.0f;
                     hq[q] = hi; lq[q] = __builtin_convertvector(rs, cnn_h2);
@@ -479,6 +499,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        CNS_PH(2);
         if constexpr (LAST) {
             // ---- layer 3 on the tile's rows in LDS: wave q takes the 32-position subtiles q, q + 4, ... of the tile's 2 NT
             LDS float *psum = (LDS float *)(lds + 2 * TILE_B); // [o 2][t 7][position PB] partial sums of the taps
@@ -531,9 +552,9 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         {
             // rows tile * PB .. of read n; pieces of rows at or beyond L1 go to the read's row 0 (which nothing reads), so that
             // every store is issued and the count below stays exact
-            const int nvalid = (L1 - tile * PB < PB ? L1 - tile * PB : PB) * 17;
+            const int nvalid = (L1 - tile * PBS < PBS ? L1 - tile * PBS : PBS) * 17;
             char *rbase = reinterpret_cast<char *>(out) + (size_t)n * Lrows * CNS_ROWB;
-            char *obase = rbase + (size_t)(CNS_FRONT + tile * PB) * CNS_ROWB;
+            char *obase = rbase + (size_t)(CNS_FRONT + tile * PBS) * CNS_ROWB;
             cnn_h8 piece[NSTORE];
 #pragma unroll
             for (int c = 0; c < NSTORE; c++) {
@@ -554,7 +575,18 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
         }
         if (!FIRST) buf ^= 1;
+        CNS_PH(3);
+#ifdef ADP_PHASE_TIMING
+        nst_++;
+#endif
     }
+#ifdef ADP_PHASE_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        constexpr int slot[2][5] = {{64, 65, 66, 67, 68}, {70, 71, 72, 73, 74}}; // (layer 1 / layer 2)
+        for (int k = 0; k < 4; k++) atomicAdd(&g_dbg[slot[LAST][k]], (unsigned long long)ph_[k]);
+        atomicAdd(&g_dbg[slot[LAST][4]], (unsigned long long)nst_);
+    }
+#endif
     const bool bad = hmax[0] >= 0x7800 || hmax[1] >= 0x7800;
     if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }

@@ -1,6 +1,6 @@
 // common.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
 #pragma once
-#define ADP_NDBG 64 // debug tallies (adp_debug_fetch what = 8)
+#define ADP_NDBG 80 // debug tallies (adp_debug_fetch what = 8)
 #define ADP_NTALLY 256
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -279,13 +279,14 @@ def test_device_topk_behind_given_argmaxes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("conv", ["split", "split_unfolded", "split_layer0apart", "f32"])
-@pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4), (190 * 3, 3), (191 * 3 + 2, 3), (380 * 3 + 1, 3)])
+@pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4), (190 * 3, 3), (191 * 3 + 2, 3), (380 * 3 + 1, 3),
+                                  (186 * 3, 3), (186 * 3 + 1, 3), (372 * 3 + 1, 3), (123 * 3, 3), (251 * 3, 3)])
 def test_hip_conv_stack_equals_torch(Lc, n, conv, monkeypatch):
     """C2: the hand-written conv stacks (adp_cnn_forward) against torch's float32 conv1d / conv_transpose1d on the same device
     with the shipped weights -- "split": the default, float16 matrix cores on split operands (cnn_conv_split.h), layer 3 folded into
     layer 2's kernel (round 5: tiles that advance by 64 NT - 2 positions -- lengths around multiples of 190 sit on their seams);
-    and layer 0 made in layer 1's prologue (tiles of 64 NT positions whose rows come from 3 R + 4 samples: lengths around multiples of
-    192 / 256 sit on their seams, 7 and 100 are shorter than one subtile);
+    and layer 0 made in layer 1's prologue (tiles that advance by 64 NT - 6 positions, their 64 NT input rows made from 192 NT + 4 samples:
+    lengths around multiples of 186 / 122 / 250 sit on their seams, 7 and 100 are shorter than one subtile);
     "split_unfolded": the same stack with layer 3 as a kernel of its own (ADP_CNN_FOLD=0); "split_layer0apart": with layer 0 as a
     kernel of its own (ADP_CNN_FUSE_IN=0); "f32": the exact
     float32 matrix-core kernels (cnn_conv.h, ADP_CNN_CONV=f32).  The float32 stack and torch are float32 sums of the same 448
