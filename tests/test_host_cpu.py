@@ -617,3 +617,23 @@ def test_bench_finds_a_kernels_traffic_whatever_its_template_arguments():
     assert bench._traffic_of(t, "k_gains<2>", 96000) == 2.0
     assert bench._traffic_of(t, "k_gains", 96000) is None          # ambiguous: two instantiations
     assert bench._traffic_of(t, "k_norm_pool", 96000) is None and bench._traffic_of(None, "k_validate", 1) is None
+
+
+def test_every_lds_array_of_the_library_is_declared_16_byte_aligned():
+    """Dynamic LDS starts behind a kernel's static words: a 4-byte-aligned array there leaves every 16-byte access of it misaligned --
+    correct, and ~25 times slower (round 5: k_mvs_series_pipe's rings at byte 580, 11.9 instead of 6.2 ms).
+    Every `__shared__` ARRAY (and the two scratch structs) in adapted_amd/csrc carries `__attribute__((aligned(16)))`."""
+    import glob
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "adapted_amd", "csrc")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.hip"))):
+        with open(path) as fh:
+            for no, line in enumerate(fh, 1):
+                code = line.split("//")[0]
+                if "__shared__" not in code or "aligned(16)" in code:
+                    continue
+                if "[" in code or re.search(r"__shared__\s+(WaveScratch|N1Sel)\b", code):
+                    bad.append("%s:%d: %s" % (os.path.basename(path), no, code.strip()))
+    assert not bad, "\n".join(bad)
