@@ -222,17 +222,12 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
     double2 *c = ck + (size_t)r * nck;
     double a = 0.0, b = 0.0;
     double2 t = make_double2(0.0, 0.0);
-    // one checkpoint block (CK = 16 pooled samples) per step; its four float4 loads are issued PF blocks ahead of the add
-    // chain (PF register sets used in turn, no moves): a lane reads its own row, so one wave-instruction touches 64 rows
+    // one checkpoint block (CK = 16 pooled samples) per step; its four float4 loads are issued ahead of the add
+    // chain (register sets used in turn, no moves): a lane reads its own row, so one wave-instruction touches 64 rows
     // and only the bytes in flight per wave buy bandwidth (one block ahead: 4.1 ms per 96 000 reads, waiting on memory at
     // every step).  The loads are unconditional -- rows are padded to Lp, the block index is clamped to the row -- because a
     // load behind a condition makes the compiler wait for it where the two paths join.
     const float4 *s4 = reinterpret_cast<const float4 *>(s); // rows start 256-byte aligned (Lp % 64 == 0)
-    const int last_blk = Lp / CK - 1;
-    auto ld = [&](int blk, float4 (&q)[4]) {
-        const float4 *p4 = s4 + (blk < last_blk ? blk : last_blk) * (CK / 4);
-        q[0] = p4[0]; q[1] = p4[1]; q[2] = p4[2]; q[3] = p4[3];
-    };
     auto block = [&](int j0, const float4 (&q)[4]) {
         c[j0 / CK] = make_double2(a, b);
         const float v[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
@@ -252,16 +247,26 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
             }
         }
     };
-    constexpr int PF = 3; // blocks in flight per lane (1: 4.1 ms per 96 000 reads; 3: 3.3; 6: no better)
-    float4 q[PF][4];
+    // A lane's loads come as whole 128-byte lines (two checkpoint blocks), PFL lines ahead (round 5; 64-byte blocks, three in flight: 3.15
+    // against 2.95 ms per 96 000 reads; one block ahead: 4.1)
+    constexpr int PFL = 2;
+    float4 q[PFL][2][4];
+    const int last_line = Lp / (2 * CK) - 1;
+    auto ldl = [&](int line, float4 (&qq)[2][4]) {
+        const float4 *p4 = s4 + (line < last_line ? line : last_line) * (2 * CK / 4);
 #pragma unroll
-    for (int d = 0; d < PF; d++) ld(d, q[d]);
-    for (int j0 = 0; j0 < n; j0 += PF * CK) {
-        const int blk = j0 / CK;
+        for (int e = 0; e < 8; e++) qq[e >> 2][e & 3] = p4[e];
+    };
 #pragma unroll
-        for (int d = 0; d < PF; d++) {
-            if (d == 0 || j0 + d * CK < n) block(j0 + d * CK, q[d]);
-            ld(blk + PF + d, q[d]);
+    for (int d = 0; d < PFL; d++) ldl(d, q[d]);
+    for (int j0 = 0; j0 < n; j0 += PFL * 2 * CK) {
+        const int line = j0 / (2 * CK);
+#pragma unroll
+        for (int d = 0; d < PFL; d++) {
+            const int j1 = j0 + d * 2 * CK;
+            if (d == 0 || j1 < n) block(j1, q[d][0]);
+            if (j1 + CK < n) block(j1 + CK, q[d][1]);
+            ldl(line + PFL + d, q[d]);
         }
     }
     tail[r] = t;
