@@ -273,6 +273,8 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             __builtin_amdgcn_global_load_lds((const GLB float *)(src + inst * 1024), (LDS float *)(lds + b * TILE_B + inst * 1024), 16, 0, 0);
     };
     // LAST: layer 3's A fragments (32 registers) stay resident where the tile shape leaves room (NT = 4 is at the limit: fetched per tile)
+    float b3_0 = 0.f, b3_1 = 0.f;
+    if constexpr (LAST) { b3_0 = b3[0]; b3_1 = b3[1]; }
     constexpr bool W3_RESIDENT = LAST && NT < 4;
     cnn_h8 ah[4], al[4];
     if constexpr (W3_RESIDENT) {
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     // (diagnostic build: cycles of wave 0 of workgroup 0 per phase of a step, summed over the launch: g_dbg[64] rows made / tile awaited,
     // [65] k-loop, [66] conversion, [67] layer 3 or copy-out, [68] steps; layers 2 + 3: 70 .. 74)
     auto cns_now = []() { long long t; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); return t; };
-    long long ph_[4] = {0, 0, 0, 0}, pt_ = cns_now();
+    long long ph_[6] = {0, 0, 0, 0, 0, 0}, pt_ = cns_now();
     long long nst_ = 0;
 #define CNS_PH(k) do { const long long t_ = cns_now(); ph_[k] += t_ - pt_; pt_ = t_; } while (0)
 #else
@@ -525,6 +527,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            CNS_PH(4); // (layer 3's GEMM and its partial sums; the rest of this branch -- the combination and the score stores -- stays in [3])
             // outputs 3 jg + d of the tile's interior positions jg = tile * PBS + (j - 1), j = 1 .. PB - 2.  Every thread issues the same
             // number of stores (those without an output go to the dump row of `out`, which this layer does not write otherwise), so that
             // the counted wait below leaves them in flight and only makes sure of the next tile's DMA, which is older
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
                 const int jg = tile * PBS + j - 1;
                 const bool ok = have && jg < L1;
                 const LDS float *pq = psum + (o * CNN_K) * PB + j;
-                const float bo = b3[o];
+                const float bo = o ? b3_1 : b3_0; // (fetched once: a load here is a memory round trip in every tile's last phase)
                 const float y0 = bo + ((pq[6 * PB - 1] + pq[3 * PB]) + pq[0 * PB + 1]);
                 const float y1 = bo + (pq[4 * PB] + pq[1 * PB + 1]);
                 const float y2 = bo + (pq[5 * PB] + pq[2 * PB + 1]);
@@ -584,6 +587,7 @@ __global__ void __launch_bounds__(256, 1) k_cnn_conv64s(const _Float16 *__restri
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         constexpr int slot[2][5] = {{64, 65, 66, 67, 68}, {70, 71, 72, 73, 74}}; // (layer 1 / layer 2)
         for (int k = 0; k < 4; k++) atomicAdd(&g_dbg[slot[LAST][k]], (unsigned long long)ph_[k]);
+        if (LAST) atomicAdd(&g_dbg[75], (unsigned long long)ph_[4]);
         atomicAdd(&g_dbg[slot[LAST][4]], (unsigned long long)nst_);
     }
 #endif

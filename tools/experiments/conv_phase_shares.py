@@ -24,3 +24,4 @@ for name, sl in (("layers 0 + 1", (64, 65, 66, 67, 68)), ("layers 2 + 3", (70, 7
           "conversion into LDS %.0f (%.0f %%), %s %.0f (%.0f %%)"
           % (name, steps, tot, tot / 2000.0, ph[0], 100 * ph[0] / tot, ph[1], 100 * ph[1] / tot, ph[2], 100 * ph[2] / tot,
              "copy-out" if name.startswith("layers 0") else "layer 3 + scores out", ph[3], 100 * ph[3] / tot))
+print("layers 2 + 3, the last phase apart: layer 3's GEMM + partial sums %.0f cycles per step, combination + score stores %.0f" % (int(d[75]) / max(1, int(d[74])), int(d[73]) / max(1, int(d[74]))))
