@@ -280,7 +280,8 @@ def test_device_topk_behind_given_argmaxes():
 @pytest.mark.gpu
 @pytest.mark.parametrize("conv", ["split", "split_unfolded", "split_layer0apart", "f32"])
 @pytest.mark.parametrize("Lc,n", [(1650, 37), (20050, 9), (1651, 5), (1652, 5), (100, 3), (7, 2), (193 * 3, 4), (256 * 3 + 1, 4), (190 * 3, 3), (191 * 3 + 2, 3), (380 * 3 + 1, 3),
-                                  (186 * 3, 3), (186 * 3 + 1, 3), (372 * 3 + 1, 3), (123 * 3, 3), (251 * 3, 3)])
+                                  (186 * 3, 3), (186 * 3 + 1, 3), (372 * 3 + 1, 3), (123 * 3, 3), (251 * 3, 3),
+                                  (512 * 3, 3), (1024 * 3, 2)])  # (the last two: several tiles of the 256-position shape, NT = 4)
 def test_hip_conv_stack_equals_torch(Lc, n, conv, monkeypatch):
     """C2: the hand-written conv stacks (adp_cnn_forward) against torch's float32 conv1d / conv_transpose1d on the same device
     with the shipped weights -- "split": the default, float16 matrix cores on split operands (cnn_conv_split.h), layer 3 folded into
