@@ -212,12 +212,16 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
 
 // ---------------------------------------------------------------- cumulative sums
 // one lane per read.  ck[r][q] = (c, c2) BEFORE pooled sample q*CK; tail[r] = (c[n-2], c2[n-2]).
+// Two kernels share the launch's waves (round 5): a wave whose 64 reads have (nearly) one length belongs to k_cumsum_gather, every other wave
+// to k_cumsum -- each returns at once from the other's.
+static __device__ __forceinline__ bool csum_uniform(int n) { return wave_max(n) - wave_min(n) < 8 * CK; }
 __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int n_reads,
                                                int nck, double2 *__restrict__ ck, double2 *__restrict__ tail)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
+    const int n = r < n_reads ? nvalid[r] : 0;
+    if (csum_uniform(n)) return; // (k_cumsum_gather's wave)
     if (r >= n_reads) return;
-    const int n = nvalid[r];
     const float *s = down + (size_t)r * Lp;
     double2 *c = ck + (size_t)r * nck;
     double a = 0.0, b = 0.0;
@@ -270,6 +274,86 @@ __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, c
         }
     }
     tail[r] = t;
+}
+
+// k_cumsum for waves of one length.  What bounds k_cumsum is not its chains (21 cycles per sample: 0.4 ms per 96 000 reads,
+// tools/chain_latency.hip) and not its loads: WITHOUT its checkpoint stores it takes 1.3 ms instead of 2.9 -- a 16-byte piece per lane and
+// instruction into 64 different lines, every 16 samples (profiles/r05_tried_and_dropped.txt item 12).  Here the checkpoints wait in LDS for
+// eight blocks and leave as whole 128-byte lines, eight reads per instruction; the loop is the wave's (all lanes to the longest read), which
+// is why reads of very different lengths stay with k_cumsum.  Same additions in the same order.
+#define CSUM_Q 8 // checkpoints gathered per read before they are stored: 8 x 16 bytes = one line
+typedef double csum_d2 __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(64) k_cumsum_gather(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int n_reads,
+                                                      int nck, double2 *__restrict__ ck, double2 *__restrict__ tail)
+{
+    __shared__ __attribute__((aligned(16))) csum_d2 cks_[64 * (CSUM_Q + 1)]; // [lane][CSUM_Q] with a piece of padding per row
+    LDS csum_d2 *cks = (LDS csum_d2 *)cks_;
+    const int ln = threadIdx.x, r0 = blockIdx.x * 64;
+    const int r = r0 + ln;
+    const int n = r < n_reads ? nvalid[r] : 0;
+    if (!csum_uniform(n)) return; // (k_cumsum's wave; a uniform wave is a full one: r < n_reads for every lane, or all lengths below 8 CK)
+    const int nmax = wave_max(n);
+    const float *s = down + (size_t)(r < n_reads ? r : n_reads - 1) * Lp;
+    double a = 0.0, b = 0.0;
+    double2 t = make_double2(0.0, 0.0);
+    const float4 *s4 = reinterpret_cast<const float4 *>(s); // rows start 256-byte aligned (Lp % 64 == 0)
+    auto block = [&](int j0, int slot, const float4 (&q)[4]) {
+        cks[ln * (CSUM_Q + 1) + slot] = (csum_d2){a, b};
+        const float v[16] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w};
+        if (j0 + CK < n) { // a block in front of the read's last sample: no tests (convert, add, multiply, add per sample)
+#pragma unroll
+            for (int u = 0; u < CK; u++) { const double x = (double)v[u]; a += x; b += x * x; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < CK; u++) {
+                const int j = j0 + u;
+                if (j < n) {
+                    if (j == n - 1) t = make_double2(a, b);
+                    double x = (double)v[u];
+                    a += x;
+                    b += x * x;
+                }
+            }
+        }
+    };
+    static_assert(CSUM_Q % 4 == 0, "a group is a whole number of prefetch rounds of two lines");
+    constexpr int PFL = 2, LPG = CSUM_Q / 2; // lines of two blocks per group of CSUM_Q blocks
+    float4 q[PFL][2][4];
+    const int last_line = n > 0 ? (n - 1) / (2 * CK) : 0; // (a read that has ended keeps asking for its last line: cached)
+    auto ldl = [&](int line, float4 (&qq)[2][4]) {
+        const float4 *p4 = s4 + (line < last_line ? line : last_line) * (2 * CK / 4);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qq[e >> 2][e & 3] = p4[e];
+    };
+#pragma unroll
+    for (int d = 0; d < PFL; d++) ldl(d, q[d]);
+    for (int g0 = 0; g0 * (CSUM_Q * CK) < nmax; g0++) { // groups of CSUM_Q blocks = 128 samples, all lanes together (the stores below are the wave's)
+#pragma unroll
+        for (int l2 = 0; l2 < LPG; l2 += PFL) {
+#pragma unroll
+            for (int d = 0; d < PFL; d++) {
+                const int line = g0 * LPG + l2 + d, j1 = line * 2 * CK, slot = 2 * (l2 + d);
+                if (j1 < n) block(j1, slot, q[d][0]);
+                if (j1 + CK < n) block(j1 + CK, slot + 1, q[d][1]);
+                ldl(line + PFL, q[d]);
+            }
+        }
+        // the group's checkpoints: lane l stores piece l & 7 of read 8 it + (l >> 3) -- eight reads' lines per instruction; a read's last line
+        // is cut at its length (what lies at or beyond a read's last sample was never a checkpoint)
+        ws_sync();
+        const int q0 = g0 * CSUM_Q;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int rd = 8 * it + (ln >> 3), pc = ln & 7;
+            const int nrd = __shfl(n, rd);
+            if (r0 + rd < n_reads && (q0 + pc) * CK < nrd) {
+                const csum_d2 v = cks[rd * (CSUM_Q + 1) + pc];
+                ck[(size_t)(r0 + rd) * nck + q0 + pc] = make_double2(v.x, v.y);
+            }
+        }
+        ws_sync();
+    }
+    if (r < n_reads) tail[r] = t;
 }
 
 // ---------------------------------------------------------------- gains
