@@ -725,10 +725,12 @@ static int llr_enqueue(adp_handle *h, SIG dsig, const int32_t *dlen, int n, int 
         if (ps && ps->wait[1]) HIPCHK(hipStreamWaitEvent(st, ps->wait[1], 0));
         if (upto >= 3) {
             Scope s(h, "k_cumsum");
+            const int split = env_int("ADP_CUMSUM_GATHER", 1) != 0;
             hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
-                               h->nck, h->ck.as<double2>(), h->tail.as<double2>());
-            hipLaunchKernelGGL(k_cumsum_gather, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
-                               h->nck, h->ck.as<double2>(), h->tail.as<double2>());
+                               h->nck, h->ck.as<double2>(), h->tail.as<double2>(), split);
+            if (split)
+                hipLaunchKernelGGL(k_cumsum_gather, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n,
+                                   h->nck, h->ck.as<double2>(), h->tail.as<double2>());
         }
         if (upto >= 4) {
             Scope s(h, "k_gains<1>");
@@ -1723,7 +1725,7 @@ int adp_llr_refine_polya(adp_handle *h, const float *signals, const int32_t *ful
     hipLaunchKernelGGL(k_norm_pool<SigF32>, dim3(n), dim3(256), (size_t)NP_TILE * h->ds * 4, st, SigF32{dsig}, m, h->T, h->off, h->ds, h->L, h->Lp, 1, mbs,
                        h->down.as<float>(), h->nvalid.as<int32_t>(), (const int64_t *)drng, dlen);
     hipLaunchKernelGGL(k_cumsum, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
-                       h->ck.as<double2>(), h->tail.as<double2>());
+                       h->ck.as<double2>(), h->tail.as<double2>(), 1);
     hipLaunchKernelGGL(k_cumsum_gather, dim3((n + 63) / 64), dim3(64), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, n, h->nck,
                        h->ck.as<double2>(), h->tail.as<double2>());
     hipLaunchKernelGGL(k_gains<1>, dim3((n + GAINS_WPB - 1) / GAINS_WPB), dim3(64 * GAINS_WPB), 0, st, h->down.as<float>(), h->nvalid.as<int32_t>(), h->Lp, h->nck,

@@ -216,11 +216,11 @@ __global__ void __launch_bounds__(256) k_norm_pool(SIG sig, int m, int T, int of
 // to k_cumsum -- each returns at once from the other's.
 static __device__ __forceinline__ bool csum_uniform(int n) { return wave_max(n) - wave_min(n) < 8 * CK; }
 __global__ void __launch_bounds__(64) k_cumsum(const float *__restrict__ down, const int32_t *__restrict__ nvalid, int Lp, int n_reads,
-                                               int nck, double2 *__restrict__ ck, double2 *__restrict__ tail)
+                                               int nck, double2 *__restrict__ ck, double2 *__restrict__ tail, int split)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     const int n = r < n_reads ? nvalid[r] : 0;
-    if (csum_uniform(n)) return; // (k_cumsum_gather's wave)
+    if (split && csum_uniform(n)) return; // (k_cumsum_gather's wave; split = 0, ADP_CUMSUM_GATHER=0: every wave is this kernel's)
     if (r >= n_reads) return;
     const float *s = down + (size_t)r * Lp;
     double2 *c = ck + (size_t)r * nck;

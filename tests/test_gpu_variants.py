@@ -12,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SWITCHES = ("ADP_SERIES_PIPE", "ADP_CNN_OVERLAP", "ADP_N1_S0", "ADP_SERIES_PIPE_LLR", "ADP_CNN_FOLD", "ADP_CNN_FUSE_IN")
+SWITCHES = ("ADP_SERIES_PIPE", "ADP_CNN_OVERLAP", "ADP_N1_S0", "ADP_SERIES_PIPE_LLR", "ADP_CNN_FOLD", "ADP_CNN_FUSE_IN", "ADP_CUMSUM_GATHER")
 
 
 def _with_env(env, fn):
@@ -162,3 +162,28 @@ def test_polya_peak_on_a_prefix_of_the_maxima_equals_the_whole_list():
     assert got[0][0] == got[1][0]
     pe = got[0][1]
     assert (pe > 0).sum() >= n // 3 and (pe == 0).sum() >= 5   # both kinds of read are there
+
+
+def test_cumsum_kernels_share_a_launch_by_the_lengths_of_a_waves_reads():
+    """k_cumsum_gather takes the waves whose 64 reads have one length, k_cumsum the others (round 5): a batch with a wave of full-length reads,
+    a wave of mixed lengths, a wave of equal SHORT reads (fewer pooled samples than one gathered line holds) and a ragged last wave gives the
+    rows of the launch in which k_cumsum takes every wave (ADP_CUMSUM_GATHER=0)."""
+    from adapted_amd import lib, synth
+
+    spc = _spc("llr", None)
+    m = spc.sig_preload_size
+    n = 200
+    lens = np.full(n, m, dtype=np.int32)
+    lens[64:128] = [max(1012, synth.pareto_length(5, i, lo=1500, hi=2 * m)) for i in range(64)]
+    lens[128:192] = 2600
+    lens[192:] = [m, 5000, m, 1800, m, m, 9000, 1012]
+    sig, lens = synth.synth_batch(31, 0, n, m, lens)
+
+    def run():
+        eng = lib.Engine(spc, n, m, device=0)
+        try:
+            rows, _ = eng.detect_llr_rows(sig, lens, n, 100, with_start_peak=True)
+            return _canon(rows, lib)
+        finally:
+            eng.close()
+    assert _with_env({}, run) == _with_env({"ADP_CUMSUM_GATHER": "0"}, run)
